@@ -1,0 +1,332 @@
+"""Generate tests/golden/*.npz from the REFERENCE's own importable leaf modules.
+
+Run only in the build container (the reference never travels):
+
+    MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+It imports ``contour_uncertainty.*`` from /root/reference, feeds it seeded inputs and stores inputs + outputs
+(+ gradients) as small fixtures.  Weights for the network fixtures come from ``oracle.unet.init_unet_state`` (seeded
+``torch.Generator``), are loaded into the reference ``UNet`` with ``strict=True`` (which also pins parameter names and
+shapes) and are NOT stored: tests regenerate them from the same seed.
+"""
+from __future__ import annotations
+
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+REF = Path("/root/reference")
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(REF))
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+from oracle import unet as OU  # noqa: E402
+
+OUT = ROOT / "tests" / "golden"
+OUT.mkdir(parents=True, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+def stats(t: torch.Tensor):
+    t = t.detach().double().flatten()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().sqrt().item()])
+
+
+# ----------------------------------------------------------------------------------------------- (i) dsnt head
+def gen_dsnt():
+    from contour_uncertainty.task.regression.dsnt import utils as R
+    out = {}
+    for size, n, k, scale, seed in ((16, 2, 3, 3.0, 1), (64, 2, 5, 6.0, 2), (256, 1, 2, 8.0, 3)):
+        g = torch.Generator().manual_seed(seed)
+        logits = (torch.randn(n, k, size, size, generator=g) * scale).requires_grad_(True)
+        hm = R.flat_softmax(logits)
+        coords, var, covar = R.dsnt(hm)
+        px = R.normalized_to_pixel_coordinates(coords, size)
+        # upstream grads to exercise backward
+        gc = torch.randn(coords.shape, generator=g)
+        gv = torch.randn(var.shape, generator=g)
+        gcv = torch.randn(covar.shape, generator=g)
+        (coords * gc).sum().add((var * gv).sum()).add((covar * gcv).sum()).backward()
+        tag = f"s{size}"
+        out[f"{tag}_logits"] = npy(logits)
+        out[f"{tag}_coords"] = npy(coords)
+        out[f"{tag}_var"] = npy(var)
+        out[f"{tag}_covar"] = npy(covar)
+        out[f"{tag}_pixel"] = npy(px)
+        out[f"{tag}_g_coords"] = npy(gc)
+        out[f"{tag}_g_var"] = npy(gv)
+        out[f"{tag}_g_covar"] = npy(gcv)
+        if size <= 64:
+            out[f"{tag}_dlogits"] = npy(logits.grad)
+        else:
+            out[f"{tag}_dlogits_stats"] = stats(logits.grad)
+            out[f"{tag}_dlogits_row"] = npy(logits.grad[0, 0, 100])
+    out["linspace4"] = npy(R.normalized_linspace(4))          # docstring KAT utils.py:54-58
+    np.savez_compressed(OUT / "dsnt_head.npz", **out)
+
+
+# ----------------------------------------------------------------------------------------------- (ii) NLL heads
+def rand_spd(m, g, lo=4.0, hi=400.0):
+    a = torch.randn(m, 2, 2, generator=g)
+    s = a @ a.transpose(-1, -2)
+    s = s / s.diagonal(dim1=-2, dim2=-1).mean(-1)[:, None, None]
+    return s * (lo + (hi - lo) * torch.rand(m, 1, 1, generator=g)) + 0.05 * torch.eye(2)
+
+
+def gen_nll():
+    from contour_uncertainty.distributions.bivariateskewnormal import BivariateSkewNormal as BSN
+    g = torch.Generator().manual_seed(7)
+    m = 48
+    mu = (torch.rand(m, 2, 1, generator=g) * 200 + 20)
+    y = mu + torch.randn(m, 2, 1, generator=g) * 6
+    cov = rand_spd(m, g)
+    alpha = torch.randn(m, 2, 1, generator=g) * 3
+    # edge rows: near-singular, isotropic (repeated eigenvalue), huge |alpha| with Phi -> 0, alpha = 0
+    cov[0] = torch.tensor([[25.0, 24.99], [24.99, 25.0]])
+    cov[1] = torch.tensor([[30.0, 1e-3], [1e-3, 30.0001]])
+    alpha[2] = torch.tensor([[40.0], [-35.0]])
+    y[2] = mu[2] - torch.tensor([[9.0], [-7.0]])
+    alpha[3] = 0.0
+    out = {"mu": npy(mu), "y": npy(y), "cov": npy(cov), "alpha": npy(alpha)}
+
+    # skew NLL (bivariateskewnormal.py:51-61) + grads
+    mu_r, cov_r, al_r = (t.clone().requires_grad_(True) for t in (mu, cov, alpha))
+    nll, t1, t2, t3 = BSN.nll(y, mu_r, cov_r, al_r)
+    nll.mean().backward()
+    out.update(skew_nll=npy(nll), skew_t1=npy(t1), skew_t2=npy(t2), skew_t3=npy(t3),
+               skew_dmu=npy(mu_r.grad), skew_dcov=npy(cov_r.grad), skew_dalpha=npy(al_r.grad))
+
+    # Gaussian NLL written exactly like dsnt_al.py:64-71 (literal broadcast) + grads
+    mu_r, cov_r = (t.clone().requires_grad_(True) for t in (mu, cov))
+    w_log, w_mse = 1.0, 1.0
+    lt1 = w_log * torch.log(torch.det(cov_r))
+    lt2 = w_mse * (((mu_r - y).transpose(-1, -2) @ torch.inverse(cov_r)) @ (mu_r - y))
+    loss = (lt1 + lt2).mean()
+    loss.backward()
+    out.update(gauss_loss=npy(loss), gauss_t1_mean=npy(lt1.mean()), gauss_t2_mean=npy(lt2.mean()),
+               gauss_dmu=npy(mu_r.grad), gauss_dcov=npy(cov_r.grad))
+
+    # densities on a small grid (bivariatenormal.py:15-36, bivariateskewnormal.py:19-34)
+    from contour_uncertainty.distributions.bivariatenormal import BivariateNormal as BN
+    xx, yy = np.meshgrid(np.linspace(0, 64, 64), np.linspace(0, 64, 64))
+    pos = torch.tensor(np.dstack((xx, yy))).float()
+    loc = torch.tensor([30.0, 25.0])
+    c = torch.tensor([[25.0, 4.0], [4.0, 50.0]])
+    al = torch.tensor([3.0, -1.5])
+    out.update(grid_pos=npy(pos), grid_loc=npy(loc), grid_cov=npy(c), grid_alpha=npy(al),
+               grid_gauss_logpdf=npy(BN.logpdf(pos, loc, c)), grid_skew_logpdf=npy(BSN.logpdf(pos, loc, c, al)))
+    # reference's own manual KAT constants (bivariatenormal.py:98-103): pdf vs scipy
+    from scipy.stats import multivariate_normal
+    mu_k = torch.tensor([100.0, 100.0])
+    cov_k = torch.tensor([[25.0, 4.0], [4.0, 50.0]])
+    pts = torch.tensor([[100.0, 100.0], [104.0, 97.0], [90.0, 111.0]])
+    out.update(kat_pts=npy(pts), kat_ref=npy(BN.pdf(pts, mu_k, cov_k)),
+               kat_scipy=multivariate_normal(mean=mu_k.numpy(), cov=cov_k.numpy()).pdf(pts.numpy()))
+    np.savez_compressed(OUT / "nll_heads.npz", **out)
+
+
+# ----------------------------------------------------------------------------------------------- (iii) network
+def ref_unet(spec: OU.UNetSpec, sd, bottleneck_out):
+    from contour_uncertainty.models.nnUnet.unet2 import UNet
+    n = len(spec.strides)
+    net = UNet((spec.in_channels, 0, 0), (spec.num_classes, 0, 0), [256, 256], [[3, 3]] * n,
+               [[s, s] for s in spec.strides], bottleneck_out=bottleneck_out)
+    missing = net.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    # state_dict order must match too
+    assert list(net.state_dict().keys()) == list(sd.keys()), "parameter order differs from the reference"
+    return net
+
+
+def gen_unet_small():
+    """4-stage net (32,64,128,256) at 32x32, N=2, K=5: full logits + bottleneck + per-parameter grad stats."""
+    spec = OU.UNetSpec(in_channels=1, num_classes=5, strides=(1, 2, 2, 2))
+    g = torch.Generator().manual_seed(11)
+    sd = OU.init_unet_state(spec, g)
+    # make norm affine / biases non-trivial so their gradients and use are exercised
+    for k in sd:
+        if k.endswith("norm.weight"):
+            sd[k] = 1 + 0.1 * torch.randn(sd[k].shape, generator=g)
+        elif k.endswith("bias"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+    x = torch.rand(2, 1, 32, 32, generator=g)
+    net = ref_unet(spec, sd, bottleneck_out=True)
+    net.train()
+    logits, bott = net(x)
+    gl = torch.randn(logits.shape, generator=g)
+    gb = torch.randn(bott.shape, generator=g)
+    ((logits * gl).sum() + (bott * gb).sum()).backward()
+    out = {"x": npy(x), "logits": npy(logits), "bottleneck": npy(bott), "g_logits": npy(gl), "g_bott": npy(gb)}
+    names, gstats, ghead = [], [], []
+    for name, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(name)
+        gstats.append(stats(p.grad))
+        ghead.append(npy(p.grad.flatten()[:8]))
+    out["grad_names"] = np.array(names)
+    out["grad_stats"] = np.stack(gstats)
+    out["grad_head"] = np.stack([np.pad(h, (0, 8 - len(h))) for h in ghead])
+    out["no_grad_names"] = np.array([n for n, p in net.named_parameters() if p.grad is None])
+    np.savez_compressed(OUT / "unet_small.npz", **out)
+
+
+def gen_unet_full():
+    """The real 8-stage config (unet2.yaml) at 256x256, N=1: head outputs, logits statistics, slices."""
+    from contour_uncertainty.task.regression.dsnt import utils as R
+    from contour_uncertainty.models.nnUnet.unet2 import ConfidenceNet
+    spec = OU.UNetSpec()
+    g = torch.Generator().manual_seed(0)
+    sd = OU.init_unet_state(spec, g)
+    ssd = OU.init_confidence_state(42, g)
+    x = torch.rand(1, 1, 256, 256, generator=g)
+    net = ref_unet(spec, sd, bottleneck_out=True)
+    head = ConfidenceNet(42)
+    head.load_state_dict(ssd, strict=True)
+    with torch.no_grad():
+        logits, bott = net(x)
+        a = head(bott)
+        hm = R.flat_softmax(logits)
+        coords, var, covar = R.dsnt(hm)
+    out = {"x_seed": np.array(0), "logits_stats": stats(logits), "logits_row": npy(logits[0, :, 128, :]),
+           "logits_col": npy(logits[0, :, :, 77]), "bottleneck": npy(bott), "alpha_raw": npy(a),
+           "coords": npy(coords), "var": npy(var), "covar": npy(covar),
+           "n_params_unet": np.array(sum(v.numel() for v in sd.values())),
+           "n_params_skew": np.array(sum(v.numel() for v in ssd.values())),
+           "param_names": np.array(list(sd.keys()))}
+    np.savez_compressed(OUT / "unet_full.npz", **out)
+
+
+def gen_step():
+    """Two dsnt-skew and two dsnt-al training steps (6-stage net at 64x64, N=2 = BASELINE config c1 shape) composed
+    from the reference's leaf modules exactly like dsnt_skew.py:61-104 / dsnt_al.py:45-74, with torch.optim.Adam."""
+    from contour_uncertainty.task.regression.dsnt import utils as R
+    from contour_uncertainty.distributions.bivariateskewnormal import BivariateSkewNormal as BSN
+    from contour_uncertainty.models.nnUnet.unet2 import ConfidenceNet
+    from oracle.step import synthetic_batch
+    spec = OU.UNetSpec(strides=(1, 2, 2, 2, 2, 2))
+    out = {}
+    for task in ("dsnt-skew", "dsnt-al"):
+        g = torch.Generator().manual_seed(0)
+        sd = OU.init_unet_state(spec, g)
+        net = ref_unet(spec, sd, bottleneck_out=(task == "dsnt-skew"))
+        mods = [net]
+        if task == "dsnt-skew":
+            ssd = OU.init_confidence_state(42, g)
+            head = ConfidenceNet(42)
+            head.load_state_dict(ssd, strict=True)
+            mods.append(head)
+        params = [p for m in mods for p in m.parameters()]
+        opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-3)
+        img, contour = synthetic_batch(2, 64, 21, seed=1234)
+        logs_all = []
+        for it in range(2):
+            opt.zero_grad()
+            size = img.shape[2]
+            if task == "dsnt-skew":
+                heat, feats = net(img)
+                alpha = head(feats).view(2, 21, 2)
+            else:
+                heat = net(img)
+            hm = R.flat_softmax(heat)
+            coords, var, covar = R.dsnt(hm)
+            mu = R.normalized_to_pixel_coordinates(coords, size)
+            pvar = var * (size / 2) ** 2
+            pcov = covar * (size / 2) ** 2
+            S = torch.zeros(2, 21, 2, 2)
+            S[:, :, 0, 0] = pvar[..., 0]
+            S[:, :, 0, 1] = pcov
+            S[:, :, 1, 0] = pcov
+            S[:, :, 1, 1] = pvar[..., 1]
+            dist = R.euclidean_losses(mu, contour).mean()
+            mu_f = mu.flatten(0, 1).unsqueeze(-1)
+            y_f = contour.flatten(0, 1).unsqueeze(-1)
+            S_f = S.flatten(0, 1)
+            if task == "dsnt-skew":
+                a_f = alpha.flatten(0, 1).unsqueeze(-1)
+                nll, t1, t2, t3 = BSN.nll(y_f, mu_f, S_f, a_f)
+                loss = nll.mean()
+                logs = [loss, dist, t1.mean(), t2.mean(), t3.mean(), torch.norm(a_f, dim=-1).mean()]
+            else:
+                t1 = torch.log(torch.det(S_f))
+                t2 = ((mu_f - y_f).transpose(-1, -2) @ torch.inverse(S_f)) @ (mu_f - y_f)
+                loss = (t1 + t2).mean()
+                logs = [loss, dist, t1.mean(), t2.mean()]
+            loss.backward()
+            if it == 0:
+                out[f"{task}_mu0"] = npy(mu)
+                out[f"{task}_sigma0"] = npy(S)
+                gn, gs = [], []
+                for m, pre in zip(mods, ("model.", "skew_block.")):
+                    for name, p in m.named_parameters():
+                        if p.grad is not None:
+                            gn.append(pre + name)
+                            gs.append(stats(p.grad))
+                out[f"{task}_grad_names"] = np.array(gn)
+                out[f"{task}_grad_stats"] = np.stack(gs)
+            opt.step()
+            logs_all.append([float(v) for v in logs])
+        out[f"{task}_logs"] = np.array(logs_all)
+        # a few post-update weights
+        out[f"{task}_w_out"] = npy(net.output_block.conv.weight)
+        out[f"{task}_w_in"] = npy(net.input_block.conv1.conv.weight)
+        out[f"{task}_b_bott"] = npy(net.bottleneck.conv2.conv.bias)
+    np.savez_compressed(OUT / "train_step.npz", **out)
+
+
+# ----------------------------------------------------------------------------------------------- (iv) PSM math
+def gen_psm():
+    from contour_uncertainty.sampler.posterior_shape_model.posteriorshapemodel import pca, posterior_shape_model
+    from contour_uncertainty.sampler.posterior_shape_model.utils import index_to_flat
+    from contour_uncertainty.sampler.sampler import Sampler
+    psm = np.load(REF / "camus-cont_psm_11_no_std.npy", allow_pickle=True).item()
+    seq = np.load(REF / "camus-cont_sequence_psm_11_no_std.npy", allow_pickle=True).item()
+    # plain arrays of the shipped PSM files (data, not code) so the product can load them without pickle
+    np.savez_compressed(OUT / "camus-cont_psm_11_no_std.npz", **{k: np.asarray(v) for k, v in psm.items()})
+    np.savez_compressed(OUT / "camus-cont_sequence_psm_11_no_std.npz", **{k: np.asarray(v) for k, v in seq.items()})
+
+    X = torch.tensor(np.asarray(psm["X_train"])).float()
+    sm = np.asarray(psm["scaler_mean"])
+    mu_pred = torch.tensor((np.asarray(psm["X_val"])[3] + 0.0)).float().reshape(-1, 1)     # a val shape as "prediction"
+    mu_p, Q = pca(X, mu_pred)
+    out = {"pca_mu": npy(mu_p), "pca_QQt": npy(Q @ Q.T), "pca_Qabs_colnorm": npy(Q.norm(dim=0)),
+           "scaler_mean": sm, "mu_pred": npy(mu_pred)}
+    init, order = Sampler.get_points_order(21, levels=3)
+    out["order_init"] = np.array(init)
+    for i, lv in enumerate(order):
+        out[f"order_l{i}"] = np.array(lv)
+    g = torch.Generator().manual_seed(5)
+    s = mu_pred + torch.randn(42, 1, generator=g) * 2.0
+    known = list(init)
+    for i, lv in enumerate(order):
+        idx = index_to_flat(sorted(known))
+        mu_c, cov_c = posterior_shape_model(s, idx, mu_pred, Q, sigma2=1)
+        out[f"psm_l{i}_idx"] = np.array(idx)
+        out[f"psm_l{i}_mu"] = npy(mu_c)
+        out[f"psm_l{i}_cov"] = npy(cov_c)
+        known += lv
+    idx = index_to_flat(sorted(known))
+    mu_c, cov_c = posterior_shape_model(s, idx, mu_pred, Q, sigma2=0.001)
+    out["psm_final_idx"] = np.array(idx)
+    out["psm_final_mu"] = npy(mu_c)
+    out["psm_final_cov"] = npy(cov_c)
+    out["psm_s"] = npy(s)
+    np.savez_compressed(OUT / "psm_math.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["dsnt", "nll", "unet_small", "unet_full", "step", "psm"]
+    for w in which:
+        print("generating", w, flush=True)
+        {"dsnt": gen_dsnt, "nll": gen_nll, "unet_small": gen_unet_small, "unet_full": gen_unet_full,
+         "step": gen_step, "psm": gen_psm}[w]()
+    for f in sorted(OUT.glob("*.npz")):
+        print(f.name, f.stat().st_size)

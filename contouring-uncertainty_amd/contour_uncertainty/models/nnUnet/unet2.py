@@ -1,0 +1,289 @@
+"""``contour_uncertainty.models.nnUnet.unet2`` -- drop-in ``UNet`` / ``ConfidenceNet`` running on the HIP kernels.
+
+Mirrors the constructor, attribute names, parameter names/shapes and return values of the reference classes
+(reference contour_uncertainty/models/nnUnet/unet2.py:14-34 ``ConfidenceNet``, :37-208 ``UNet``) so that
+``config/task/model/unet2.yaml`` instantiates it unchanged and reference checkpoints load with ``strict=True``.
+The ``nn.Conv2d`` / ``nn.InstanceNorm2d`` / ``nn.ConvTranspose2d`` sub-modules are parameter holders only: ``forward``
+runs the kernel schedule of :mod:`cu_hip.engine` through one autograd node (hand-written backward), not PyTorch ops.
+"""
+from __future__ import annotations
+
+from typing import Sequence, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from cu_hip import lib as _lib
+from cu_hip.engine import ConfidenceEngine, UNetEngine
+
+
+def _dtype_of(name) -> torch.dtype:
+    if isinstance(name, torch.dtype):
+        return name
+    return {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32,
+            "float32": torch.float32}[str(name)]
+
+
+# ------------------------------------------------------------------------------------------------ parameter holders
+class ConvLayer(nn.Module):
+    """conv3x3 -> InstanceNorm2d(affine) -> LeakyReLU (reference layers.py:167-205); holder of the parameters."""
+
+    def __init__(self, in_channels: int, out_channels: int, stride: int, negative_slope: float):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, 3, stride, 1)
+        self.norm = nn.InstanceNorm2d(out_channels, affine=True)
+        self.lrelu = nn.LeakyReLU(negative_slope, inplace=True)
+        self.use_drop_block = False
+
+
+class ConvBlock(nn.Module):
+    """reference layers.py:208-238"""
+
+    def __init__(self, in_channels: int, out_channels: int, stride: int, negative_slope: float):
+        super().__init__()
+        self.conv1 = ConvLayer(in_channels, out_channels, stride, negative_slope)
+        self.conv2 = ConvLayer(out_channels, out_channels, 1, negative_slope)
+
+
+class UpsampleBlock(nn.Module):
+    """reference layers.py:389-438"""
+
+    def __init__(self, in_channels: int, out_channels: int, stride: int, negative_slope: float):
+        super().__init__()
+        self.transp_conv = nn.ConvTranspose2d(in_channels, out_channels, stride, stride, 0, 0, bias=False)
+        self.conv_block = ConvBlock(2 * out_channels, out_channels, 1, negative_slope)
+        self.attention = False
+
+
+class OutputBlock(nn.Module):
+    """reference layers.py:441-463"""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, 1, 1, 0, bias=False)
+
+
+def _flatten_params(module: nn.Module, names: Sequence[str]):
+    """Re-home the listed parameters in one flat float32 buffer (fused Adam / bucketed all-reduce work on slices)."""
+    params = dict(module.named_parameters())
+    plist = [params[n] for n in names]
+    total = sum(p.numel() for p in plist)
+    dev = plist[0].device
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    off = 0
+    for p in plist:
+        n = p.numel()
+        flat[off:off + n].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + n].view(p.shape)
+        off += n
+    return flat
+
+
+def _is_flat(plist) -> bool:
+    ptr = plist[0].data_ptr()
+    for p in plist:
+        if p.data_ptr() != ptr or not p.is_contiguous():
+            return False
+        ptr += p.numel() * 4
+    return True
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module: "UNet", x: Tensor, *params: Tensor):
+        P = dict(zip(module._pnames, params))
+        logits, feats, ectx = module.engine.forward(P, x, module.bottleneck_out)
+        ctx.module, ctx.ectx = module, ectx
+        ctx.save_for_backward(*params)
+        if module.bottleneck_out:
+            return logits, feats
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits, dfeats=None):
+        module: UNet = ctx.module
+        params = ctx.saved_tensors
+        P = dict(zip(module._pnames, params))
+        used = module._used_names
+        total = sum(P[n].numel() for n in used)
+        flat = torch.zeros(total, dtype=torch.float32, device=dlogits.device)
+        G, off = {}, 0
+        for n in used:
+            k = P[n].numel()
+            G[n] = flat[off:off + k].view(P[n].shape)
+            off += k
+        module.last_flat_grad = flat
+        module.engine.backward(P, G, ctx.ectx, dlogits, dfeats)
+        ctx.ectx = None
+        return (None, None) + tuple(G.get(n) for n in module._pnames)
+
+
+class UNet(nn.Module):
+    """A generic 2-D U-Net that can be instantiated dynamically (reference unet2.py:37-208), MI355X kernels inside.
+
+    Extra keyword (not in the reference): ``compute_dtype`` = "bf16" (default; production) | "f32" (parity mode).
+    """
+
+    def __init__(
+            self,
+            input_shape: Tuple[int],
+            output_shape: Tuple[int],
+            patch_size: list,
+            kernels: list,
+            strides: list,
+            normalization_layer: str = "instance",
+            negative_slope: float = 1e-2,
+            deep_supervision: bool = False,
+            attention: bool = False,
+            drop_block: bool = False,
+            residual: bool = False,
+            out_seg_bias: bool = False,
+            ssn_rank=0,
+            bottleneck_out: bool = False,
+            compute_dtype="bf16",
+    ) -> None:
+        super().__init__()
+        if len(patch_size) != 2:
+            raise NotImplementedError("Only 2D patches are on the MI355X dsnt path")
+        for flag, name in ((deep_supervision, "deep_supervision"), (attention, "attention"), (residual, "residual"),
+                           (out_seg_bias, "out_seg_bias"), (ssn_rank != 0, "ssn_rank"), (drop_block, "drop_block")):
+            if flag:
+                raise NotImplementedError(f"{name} is not enabled by any task=dsnt-* config and is out of scope "
+                                          "(SURVEY.md section 2 row 3)")
+        if normalization_layer != "instance":
+            raise NotImplementedError("only InstanceNorm is on the dsnt path (unet2.yaml)")
+        for k in kernels:
+            if tuple(k) != (3, 3):
+                raise NotImplementedError("only 3x3 kernels are on the dsnt path (unet2.yaml)")
+        self.patch_size = patch_size
+        self.dim = 2
+        self.in_channels = int(input_shape[0])
+        self.num_classes = int(output_shape[0])
+        self.attention, self.residual, self.out_seg_bias = attention, residual, out_seg_bias
+        self.negative_slope = negative_slope
+        self.deep_supervision = deep_supervision
+        self.norm = normalization_layer + "norm2d"
+        st = [int(s[0]) for s in strides]
+        self.filters = [min(2 ** (5 + i), 480) for i in range(len(st))]
+        f = self.filters
+        self.input_block = ConvBlock(self.in_channels, f[0], st[0], negative_slope)
+        self.downsamples = nn.ModuleList(
+            [ConvBlock(f[i], f[i + 1], st[i + 1], negative_slope) for i in range(len(st) - 2)])
+        self.bottleneck = ConvBlock(f[-2], f[-1], st[-1], negative_slope)
+        self.upsamples = nn.ModuleList(
+            [UpsampleBlock(ci, co, s, negative_slope)
+             for ci, co, s in zip(f[1:][::-1], f[:-1][::-1], st[1:][::-1])])
+        self.output_block = OutputBlock(f[0], self.num_classes)
+        self.ssn_rank = ssn_rank
+        self.bottleneck_out = bottleneck_out
+        self.confidence_net = ConfidenceNet  # reference unet2.py:172: handle used by DSNTSkew
+        # never used on the dsnt path but part of the reference state_dict (unet2.py:174, 262-273)
+        self.deep_supervision_heads = nn.ModuleList(
+            [OutputBlock(f[i + 1], self.num_classes) for i in range(len(self.upsamples) - 1)])
+        self.apply(self.initialize_weights)
+
+        self.engine = UNetEngine(self.in_channels, self.num_classes, st, f, negative_slope, 1e-5,
+                                 _dtype_of(compute_dtype))
+        self._pnames = [n for n, _ in self.named_parameters()]
+        self._used_names = [n for n in self._pnames if not n.startswith("deep_supervision_heads")]
+        self._flat = None
+        self.last_flat_grad = None
+
+    def initialize_weights(self, module: nn.Module) -> None:
+        """Kaiming-normal(a=negative_slope) weights, zero conv biases (reference unet2.py:309-314)."""
+        if isinstance(module, (nn.Conv2d, nn.ConvTranspose2d)):
+            module.weight = nn.init.kaiming_normal_(module.weight, a=self.negative_slope)
+            if module.bias is not None:
+                module.bias = nn.init.constant_(module.bias, 0)
+
+    def set_compute_dtype(self, dtype):
+        self.engine.dtype = _dtype_of(dtype)
+        self.engine._opcache.clear()
+
+    def _ensure_flat(self):
+        plist = [p for n, p in self.named_parameters() if n in set(self._used_names)]
+        if self._flat is None or not _is_flat(plist) or self._flat.device != plist[0].device:
+            self._flat = _flatten_params(self, self._used_names)
+
+    def flat_params(self):
+        """(flat parameter buffer, flat gradient buffer of the last backward) over the used parameters."""
+        self._ensure_flat()
+        return self._flat, self.last_flat_grad
+
+    def forward(self, input_data: Tensor):  # noqa: D102
+        _lib.require_gpu()
+        if not input_data.is_cuda:
+            raise _lib.ContourHipError("UNet.forward needs a device tensor: the HIP path has no CPU fallback")
+        self._ensure_flat()
+        params = [p for _, p in self.named_parameters()]
+        return _UNetFn.apply(self, input_data.float(), *params)
+
+
+class _ConfidenceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module: "ConfidenceNet", feats: Tensor, *params: Tensor):
+        P = dict(zip(module._pnames, params))
+        out, ectx = module.engine.forward(P, feats)
+        ctx.module, ctx.ectx = module, ectx
+        ctx.need_in = feats.requires_grad
+        ctx.save_for_backward(*params)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        module: ConfidenceNet = ctx.module
+        params = ctx.saved_tensors
+        P = dict(zip(module._pnames, params))
+        total = sum(p.numel() for p in params)
+        flat = torch.zeros(total, dtype=torch.float32, device=gout.device)
+        G, off = {}, 0
+        for n, p in zip(module._pnames, params):
+            G[n] = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        module.last_flat_grad = flat
+        gin = module.engine.backward(P, G, ctx.ectx, gout, ctx.need_in)
+        ctx.ectx = None
+        return (None, gin) + tuple(G[n] for n in module._pnames)
+
+
+class ConfidenceNet(nn.Module):
+    """Bottleneck (N, 480, 2, 2) -> (N, output_size)  (reference unet2.py:14-34; hard-codes 480 channels, 2x2)."""
+
+    def __init__(self, output_size, compute_dtype="bf16"):
+        super().__init__()
+        self.model = nn.Sequential(
+            nn.Conv2d(480, 128, kernel_size=3, stride=1, padding=1),
+            nn.ReLU(),
+            nn.Conv2d(128, 128, kernel_size=3, stride=1, padding=1),
+            nn.ReLU(),
+            nn.Conv2d(128, 128, kernel_size=3, stride=1, padding=1),
+            nn.ReLU(),
+            nn.Flatten(),
+            nn.Linear(128 * 2 * 2, output_size),
+        )
+        self.engine = ConfidenceEngine(_dtype_of(compute_dtype))
+        self._pnames = [n for n, _ in self.named_parameters()]
+        self._flat = None
+        self.last_flat_grad = None
+
+    def set_compute_dtype(self, dtype):
+        self.engine.dtype = _dtype_of(dtype)
+        self.engine._opcache.clear()
+
+    def _ensure_flat(self):
+        plist = [p for _, p in self.named_parameters()]
+        if self._flat is None or not _is_flat(plist) or self._flat.device != plist[0].device:
+            self._flat = _flatten_params(self, self._pnames)
+
+    def flat_params(self):
+        self._ensure_flat()
+        return self._flat, self.last_flat_grad
+
+    def forward(self, x):
+        _lib.require_gpu()
+        if x.shape[1] != 480 or x.shape[2] != 2 or x.shape[3] != 2:
+            raise ValueError(f"ConfidenceNet expects a (N, 480, 2, 2) bottleneck (reference unet2.py:22,29), got "
+                             f"{tuple(x.shape)}")
+        self._ensure_flat()
+        params = [p for _, p in self.named_parameters()]
+        return _ConfidenceFn.apply(self, x.float(), *params)

@@ -1,0 +1,305 @@
+// DSNT head and NLL losses (gfx950).  See include/contour_hip.h.
+//
+// cu_dsnt_head_fwd : flat_softmax + dsnt + pixel rescale + get_cov_matrix of the reference
+//                    (task/regression/dsnt/utils.py:7-47,71-77,95-105; dsnt_al.py:52-60; aleatoric.py:138-144).
+//   One workgroup per heat map.  Pass 1: max and arg-max (wave shuffles + LDS).  Pass 2: softmax-weighted moments taken
+//   about the arg-max cell so that the centred second moments do not cancel (the reference centres on the mean with 8
+//   full-size temporaries; here the map is read twice, 16 bytes per lane, and nothing is written but 13 floats).
+// cu_dsnt_head_bwd : analytic gradient, one streaming pass:  dlogit_i = p_i * (q_i - sum_j p_j q_j) with
+//   q_i = gx X_i + gy Y_i + gxx (X_i-xbar)^2 + gyy (Y_i-ybar)^2 + gxy (X_i-xbar)(Y_i-ybar); written NHWC for the MFMA
+//   gradient kernels of the 1x1 output conv.
+// cu_nll_fwd_bwd   : Gaussian NLL (dsnt_al.py:64-74) / skew-normal NLL (distributions/bivariateskewnormal.py:36-61)
+//   with closed-form 2x2 algebra and analytic gradients; one workgroup, deterministic reductions.
+#include "common.h"
+
+namespace {
+
+constexpr int HT = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* lds) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += lds[w];
+    return r;
+}
+
+__global__ __launch_bounds__(HT) void dsnt_fwd_kernel(const float* __restrict__ logits, int H, int W, int use_covar,
+                                                      float* __restrict__ mu, float* __restrict__ sigma,
+                                                      float* __restrict__ aux) {
+    __shared__ float lds[16];
+    __shared__ int lidx[4];
+    const int map = blockIdx.x;
+    const int HWn = H * W;
+    const float* lp = logits + (size_t)map * HWn;
+    const int tid = threadIdx.x;
+    const int nvec = HWn >> 2;
+
+    // ---- pass 1: max + arg-max (first occurrence)
+    float mx = -INFINITY;
+    int mi = 0;
+    for (int i = tid; i < nvec; i += HT) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lp + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (v[e] > mx) { mx = v[e]; mi = 4 * i + e; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+    }
+    if ((tid & 63) == 0) { lds[tid >> 6] = mx; lidx[tid >> 6] = mi; }
+    __syncthreads();
+    mx = lds[0]; mi = lidx[0];
+    for (int w = 1; w < HT / 64; ++w)
+        if (lds[w] > mx || (lds[w] == mx && lidx[w] < mi)) { mx = lds[w]; mi = lidx[w]; }
+    __syncthreads();
+
+    // normalised coordinates (utils.py:50-68): lin[j] = (2j + 1)/W - 1
+    const float invW = 1.f / (float)W;
+    const int cy = mi / W, cx = mi - cy * W;
+    const float x0 = (2.f * cx + 1.f) * invW - 1.f, y0 = (2.f * cy + 1.f) * invW - 1.f;
+
+    // ---- pass 2: moments about (x0, y0)
+    float s0 = 0.f, sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+    for (int i = tid; i < nvec; i += HT) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lp + 4 * i);
+        const int p = 4 * i;
+        const int yy = p / W, xx = p - yy * W;      // W % 4 == 0: the 4 elements share a row
+        const float dy = (2.f * yy + 1.f) * invW - 1.f - y0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float w = expf(v[e] - mx);
+            const float dx = (2.f * (xx + e) + 1.f) * invW - 1.f - x0;
+            s0 += w; sx += w * dx; sy += w * dy;
+            sxx += w * dx * dx; syy += w * dy * dy; sxy += w * dx * dy;
+        }
+    }
+    s0 = block_sum(s0, lds); sx = block_sum(sx, lds); sy = block_sum(sy, lds);
+    sxx = block_sum(sxx, lds); syy = block_sum(syy, lds); sxy = block_sum(sxy, lds);
+    if (tid == 0) {
+        const float inv = 1.f / s0;
+        const float mxr = sx * inv, myr = sy * inv;            // mean relative to (x0, y0)
+        const float xbar = x0 + mxr, ybar = y0 + myr;
+        const float vx = sxx * inv - mxr * mxr, vy = syy * inv - myr * myr;
+        const float cv = sxy * inv - mxr * myr;
+        const float half = 0.5f * (float)W;                    // image_size / 2
+        // normalized_to_pixel_coordinates: 0.5*((c + 1)*size - 1)
+        mu[2 * map] = 0.5f * ((xbar + 1.f) * (float)W - 1.f);
+        mu[2 * map + 1] = 0.5f * ((ybar + 1.f) * (float)H - 1.f);
+        sigma[3 * map] = vx * half * half;
+        sigma[3 * map + 1] = vy * half * half;
+        sigma[3 * map + 2] = use_covar ? cv * half * half : 0.f;
+        float* a = aux + 8 * (size_t)map;
+        a[0] = mx; a[1] = inv; a[2] = xbar; a[3] = ybar; a[4] = vx; a[5] = vy; a[6] = cv; a[7] = 0.f;
+    }
+}
+
+// One workgroup per heat map, one streaming pass: dlogit_i = p_i * (q_i - sum_j p_j q_j).
+__global__ __launch_bounds__(HT) void dsnt_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ aux,
+                                                      const float* __restrict__ gmu, const float* __restrict__ gsigma,
+                                                      int use_covar, float* __restrict__ dl, int H, int W) {
+    const int map = blockIdx.x;
+    const int HWn = H * W;
+    const float* a = aux + 8 * (size_t)map;
+    const float half = 0.5f * (float)W;
+    // chain rule from pixel units back to normalised units
+    const float gx = gmu[2 * map] * 0.5f * (float)W, gy = gmu[2 * map + 1] * 0.5f * (float)H;
+    const float gxx = gsigma[3 * map] * half * half, gyy = gsigma[3 * map + 1] * half * half;
+    const float gxy = use_covar ? gsigma[3 * map + 2] * half * half : 0.f;
+    const float mx = a[0], inv = a[1], xbar = a[2], ybar = a[3];
+    const float pq = gx * xbar + gy * ybar + gxx * a[4] + gyy * a[5] + gxy * a[6];   // sum_j p_j q_j in closed form
+    const float invW = 1.f / (float)W;
+    const float* lp = logits + (size_t)map * HWn;
+    float* op = dl + (size_t)map * HWn;
+    const int nvec = HWn >> 2;
+    for (int i = blockIdx.y * HT + threadIdx.x; i < nvec; i += HT * gridDim.y) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lp + 4 * i);
+        const int p = 4 * i;
+        const int yy = p / W, xx = p - yy * W;
+        const float Y = (2.f * yy + 1.f) * invW - 1.f, dy = Y - ybar;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float X = (2.f * (xx + e) + 1.f) * invW - 1.f, dx = X - xbar;
+            const float pr = expf(v[e] - mx) * inv;
+            const float q = gx * X + gy * Y + gxx * dx * dx + gyy * dy * dy + gxy * dx * dy;
+            o[e] = pr * (q - pq);
+        }
+        *reinterpret_cast<f32x4*>(op + 4 * i) = o;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------- NLL
+__global__ __launch_bounds__(HT) void nll_kernel(int M, int skew, float w_mse, float w_log, const float* __restrict__ mu,
+                                                 const float* __restrict__ sigma, const float* __restrict__ y,
+                                                 const float* __restrict__ alpha, float* __restrict__ logs,
+                                                 float* __restrict__ gmu, float* __restrict__ gsigma,
+                                                 float* __restrict__ galpha) {
+    __shared__ float lds[16];
+    const float invM = 1.f / (float)M;
+    float l_loss = 0.f, l_dist = 0.f, l_t1 = 0.f, l_t2 = 0.f, l_t3 = 0.f, l_an = 0.f;
+    for (int i = threadIdx.x; i < M; i += HT) {
+        const float a = sigma[3 * i], b = sigma[3 * i + 1], c = sigma[3 * i + 2];
+        // d = mu - y for the quadratic form (dsnt_al.py:68-69); the skew affine uses (y - mu) (bivariateskewnormal.py:57)
+        const float d1 = mu[2 * i] - y[2 * i], d2 = mu[2 * i + 1] - y[2 * i + 1];
+        const float det = a * b - c * c;
+        const float idet = 1.f / det;
+        const float logdet = logf(det);
+        const float quad = (b * d1 * d1 - 2.f * c * d1 * d2 + a * d2 * d2) * idet;
+        // d quad / d(a,b,c):  quad = num/det
+        const float num = quad * det;
+        const float dq_da = (d2 * d2 - num * b * idet) * idet;
+        const float dq_db = (d1 * d1 - num * a * idet) * idet;
+        const float dq_dc = (-2.f * d1 * d2 + num * 2.f * c * idet) * idet;
+        const float dq_d1 = 2.f * (b * d1 - c * d2) * idet, dq_d2 = 2.f * (a * d2 - c * d1) * idet;
+        const float dl_da = b * idet, dl_db = a * idet, dl_dc = -2.f * c * idet;
+        l_dist += sqrtf(d1 * d1 + d2 * d2);
+        float g1, g2, ga, gb, gc;
+        if (!skew) {
+            const float t1 = w_log * logdet, t2 = w_mse * quad;
+            l_t1 += t1; l_t2 += t2; l_loss += t1 + t2;
+            g1 = w_mse * dq_d1; g2 = w_mse * dq_d2;
+            ga = w_log * dl_da + w_mse * dq_da; gb = w_log * dl_db + w_mse * dq_db; gc = w_log * dl_dc + w_mse * dq_dc;
+        } else {
+            const float al1 = alpha[2 * i], al2 = alpha[2 * i + 1];
+            const float e1 = -d1, e2 = -d2;                        // y - mu
+            const float s = sqrtf(det), t = sqrtf(a + b + 2.f * s);
+            // Sigma^-1/2 = 1/(s t) [[b+s, -c], [-c, a+s]]
+            const float u = al1 * ((b + s) * e1 - c * e2) + al2 * ((a + s) * e2 - c * e1);
+            const float ist = 1.f / (s * t);
+            const float zz = u * ist;
+            const float cdf = 0.5f * (1.f + erff(zz * 0.70710678118654752f));
+            const float t3 = logf(cdf + 1e-7f);
+            const float nll = 0.5f * logdet + 0.5f * quad - t3;
+            l_t1 += logdet; l_t2 += quad; l_t3 += t3; l_loss += nll;
+            l_an += fabsf(al1) + fabsf(al2);                       // torch.norm(alpha_flat, dim=-1) over a size-1 dim
+            // d(-t3)/dz = -phi(z)/(cdf + 1e-7)
+            const float phi = 0.3989422804014327f * expf(-0.5f * zz * zz);
+            const float gz = -phi / (cdf + 1e-7f);
+            const float ae = al1 * e1 + al2 * e2;
+            const float ds_da = 0.5f * b / s, ds_db = 0.5f * a / s, ds_dc = -c / s;
+            const float dt_da = (1.f + 2.f * ds_da) / (2.f * t), dt_db = (1.f + 2.f * ds_db) / (2.f * t),
+                        dt_dc = ds_dc / t;
+            const float du_da = al2 * e2 + ae * ds_da, du_db = al1 * e1 + ae * ds_db,
+                        du_dc = -al1 * e2 - al2 * e1 + ae * ds_dc;
+            const float k2 = u * ist * ist;
+            const float dz_da = du_da * ist - k2 * (t * ds_da + s * dt_da);
+            const float dz_db = du_db * ist - k2 * (t * ds_db + s * dt_db);
+            const float dz_dc = du_dc * ist - k2 * (t * ds_dc + s * dt_dc);
+            // dz/d(mu) = -dz/d(e)
+            const float dz_de1 = (al1 * (b + s) - al2 * c) * ist, dz_de2 = (al2 * (a + s) - al1 * c) * ist;
+            g1 = 0.5f * dq_d1 - gz * dz_de1; g2 = 0.5f * dq_d2 - gz * dz_de2;
+            ga = 0.5f * dl_da + 0.5f * dq_da + gz * dz_da;
+            gb = 0.5f * dl_db + 0.5f * dq_db + gz * dz_db;
+            gc = 0.5f * dl_dc + 0.5f * dq_dc + gz * dz_dc;
+            if (galpha) {
+                galpha[2 * i] = gz * ((b + s) * e1 - c * e2) * ist * invM;
+                galpha[2 * i + 1] = gz * ((a + s) * e2 - c * e1) * ist * invM;
+            }
+        }
+        if (gmu) { gmu[2 * i] = g1 * invM; gmu[2 * i + 1] = g2 * invM; }
+        if (gsigma) { gsigma[3 * i] = ga * invM; gsigma[3 * i + 1] = gb * invM; gsigma[3 * i + 2] = gc * invM; }
+    }
+    l_loss = block_sum(l_loss, lds); l_dist = block_sum(l_dist, lds); l_t1 = block_sum(l_t1, lds);
+    l_t2 = block_sum(l_t2, lds); l_t3 = block_sum(l_t3, lds); l_an = block_sum(l_an, lds);
+    if (threadIdx.x == 0) {
+        logs[0] = l_loss * invM; logs[1] = l_dist * invM; logs[2] = l_t1 * invM; logs[3] = l_t2 * invM;
+        logs[4] = l_t3 * invM; logs[5] = l_an * invM * 0.5f; logs[6] = 0.f; logs[7] = 0.f;
+    }
+}
+
+// ConfidenceNet Linear(512, 2K*) (unet2.py:28-29): tiny, one thread per output.
+__global__ void linear_fwd_kernel(int N, int IN, int OUT, const float* __restrict__ x, const float* __restrict__ w,
+                                  const float* __restrict__ b, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * OUT) return;
+    const int n = i / OUT, o = i - n * OUT;
+    float acc = b ? b[o] : 0.f;
+    for (int k = 0; k < IN; ++k) acc += x[(size_t)n * IN + k] * w[(size_t)o * IN + k];
+    out[i] = acc;
+}
+__global__ void linear_bwd_x_kernel(int N, int IN, int OUT, const float* __restrict__ w, const float* __restrict__ go,
+                                    float* __restrict__ gx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * IN) return;
+    const int n = i / IN, k = i - n * IN;
+    float acc = 0.f;
+    for (int o = 0; o < OUT; ++o) acc += go[(size_t)n * OUT + o] * w[(size_t)o * IN + k];
+    gx[i] = acc;
+}
+__global__ void linear_bwd_w_kernel(int N, int IN, int OUT, const float* __restrict__ x, const float* __restrict__ go,
+                                    float* __restrict__ gw, float* __restrict__ gb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= OUT * IN) return;
+    const int o = i / IN, k = i - o * IN;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc += go[(size_t)n * OUT + o] * x[(size_t)n * IN + k];
+    gw[i] += acc;
+    if (k == 0 && gb) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += go[(size_t)n * OUT + o];
+        gb[o] += s;
+    }
+}
+
+}  // namespace
+
+extern "C" int cu_dsnt_head_fwd(int NK, int H, int W, const float* logits, int use_covar, float* mu, float* sigma,
+                                float* aux, void* stream) {
+    CU_CHECK_ARG(NK > 0 && H > 0 && W > 0 && H == W, "cu_dsnt_head_fwd: maps must be square (reference utils.py:9), got %dx%d",
+                 H, W);
+    CU_CHECK_ARG(W % 4 == 0, "cu_dsnt_head_fwd: W=%d must be a multiple of 4", W);
+    CU_CHECK_ARG(logits && mu && sigma && aux, "cu_dsnt_head_fwd: null pointer");
+    hipLaunchKernelGGL(dsnt_fwd_kernel, dim3(NK), dim3(HT), 0, reinterpret_cast<hipStream_t>(stream), logits, H, W,
+                       use_covar, mu, sigma, aux);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_dsnt_head_bwd(int NK, int H, int W, const float* logits, const float* aux, const float* gmu,
+                                const float* gsigma, int use_covar, float* dlogits, void* stream) {
+    CU_CHECK_ARG(NK > 0 && H == W && W % 4 == 0, "cu_dsnt_head_bwd: bad shape %dx%d", H, W);
+    CU_CHECK_ARG(logits && aux && gmu && gsigma && dlogits, "cu_dsnt_head_bwd: null pointer");
+    int split = 1;                      // several workgroups per map when there are few maps
+    while (NK * split < 1024 && (H * W) / (4 * HT * split) > 4) split *= 2;
+    hipLaunchKernelGGL(dsnt_bwd_kernel, dim3(NK, split), dim3(HT), 0, reinterpret_cast<hipStream_t>(stream), logits, aux,
+                       gmu, gsigma, use_covar, dlogits, H, W);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_nll_fwd_bwd(int M, int skew, float w_mse, float w_log, const float* mu, const float* sigma,
+                              const float* y, const float* alpha, float* logs, float* gmu, float* gsigma,
+                              float* galpha, void* stream) {
+    CU_CHECK_ARG(M > 0 && mu && sigma && y && logs, "cu_nll_fwd_bwd: bad argument");
+    CU_CHECK_ARG(!skew || alpha, "cu_nll_fwd_bwd: skew NLL needs alpha");
+    hipLaunchKernelGGL(nll_kernel, dim3(1), dim3(HT), 0, reinterpret_cast<hipStream_t>(stream), M, skew, w_mse, w_log, mu,
+                       sigma, y, alpha, logs, gmu, gsigma, galpha);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_linear_fwd(int N, int IN, int OUT, const float* x, const float* w, const float* b, float* out,
+                             void* stream) {
+    CU_CHECK_ARG(N > 0 && IN > 0 && OUT > 0 && x && w && out, "cu_linear_fwd: bad argument");
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(N * OUT, 128)), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), N,
+                       IN, OUT, x, w, b, out);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_linear_bwd(int N, int IN, int OUT, const float* x, const float* w, const float* gout, float* gx,
+                             float* gw, float* gb, void* stream) {
+    CU_CHECK_ARG(N > 0 && IN > 0 && OUT > 0 && x && w && gout, "cu_linear_bwd: bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (gx) hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(cdiv(N * IN, 128)), dim3(128), 0, st, N, IN, OUT, w, gout, gx);
+    if (gw) hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(cdiv(OUT * IN, 128)), dim3(128), 0, st, N, IN, OUT, x, gout, gw, gb);
+    CU_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,304 @@
+// Weight gradient of the gather convolution on MFMA (gfx950).  See include/contour_hip.h : cu_conv_wgrad.
+//
+//   dW[t][n][c] += sum_p Z[p*ZS + zoff_t, n] * act(S[p*IS + off_t, c])
+//
+// Replaces autograd's weight gradient of nn.Conv2d / nn.ConvTranspose2d (reference models/nnUnet/layers.py:55-109) with
+// the InstanceNorm+LeakyReLU / concat of the forward operand recomputed in the load (never materialised).
+//
+// The reduction index is the pixel, which is the slow index of NHWC: both operands are staged row-major
+// ([pixel][channel]) in LDS and read k-major with the hardware transpose read ds_read_b64_tr_b16 (bf16) so that tap
+// shifts are plain row offsets; f32 parity mode uses v_mfma_f32_32x32x2_f32 with scalar LDS reads.
+// One workgroup owns a (32*NBLK) x (32*CBLK) block of dW for all taps (<= 9 accumulators of 32x32 per wave) and walks
+// pixel tiles split over grid.y; partial sums are added with f32 atomics in 128-byte rows.
+#include "common.h"
+
+namespace {
+
+struct WgKArgs {
+    const void* src0; const void* src1;
+    const float* sc0; const float* sh0; const float* sc1; const float* sh1;
+    const void* z; float* dw;
+    int N, PH, PW, SH, SW, C0, C1, IS, ZH, ZW, ZC, ZS, CO, ntaps;
+    int s_off[CU_MAX_TAPS], z_off[CU_MAX_TAPS], tap_w[CU_MAX_TAPS];
+    int sdymin, sdxmin, SHH, SHW, s_halo;      // source halo
+    int zdymin, zdxmin, ZHH, ZHW, z_halo;      // Z halo
+    int twl, thl, iml, tiles_x, tiles_y, igroups, ntiles, splits;
+    int ctiles;                                // number of channel tiles (grid.x = ntile_n * ctiles)
+    int tile_px;                               // loop pixels per tile (128, or 64 for stride-2 gathers)
+    unsigned mg_shpi, mg_shw, mg_zhpi, mg_zhw; // ceil(2^32/d) magics for the halo index decode
+    float slope0, slope1;
+    int zsame;                                 // all taps read the same Z pixel
+};
+
+template <typename T> struct WCfg;
+template <> struct WCfg<bf16_t> { static constexpr int PIECE = 8; static constexpr int KPIX = 16; };
+template <> struct WCfg<float> { static constexpr int PIECE = 4; static constexpr int KPIX = 2; };
+
+__device__ __forceinline__ bf16x4 tr_read(const void* lds_ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (__attribute__((address_space(3))) bf16x4*)(const_cast<void*>(lds_ptr)));
+}
+
+
+template <typename T, int NBLK, int CBLK>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
+    using C = WCfg<T>;
+    constexpr int PIECE = C::PIECE, KPIX = C::KPIX;
+    constexpr int TN = 32 * NBLK, TC = 32 * CBLK;
+    constexpr int NWB = NBLK * CBLK;            // wave blocks
+    constexpr int KSPLIT = 4 / NWB;             // waves sharing one block split the k-steps
+    constexpr int SPP = TC / PIECE;             // source pieces per pixel
+    constexpr int ZPP = TN / PIECE;
+    // row pitch in bytes: bf16 rows of 64 B are contiguous per 4-pixel transpose block; 128-B rows get +64 B so that the
+    // 4 rows of a transpose block fall on distinct bank quarters
+    constexpr int ROWS_B = (sizeof(T) == 2) ? (TC == 32 ? 64 : 192) : TC * 4 + 16;
+    constexpr int ROWZ_B = (sizeof(T) == 2) ? (TN == 32 ? 64 : 192) : TN * 4 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ss = smem;
+    unsigned char* Zs = smem + (size_t)p.s_halo * ROWS_B;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int blk = wave % NWB, kpart = wave / NWB;
+    const int nblk = blk / CBLK, cblk = blk % CBLK;
+    const int TW = 1 << p.twl, TH = 1 << p.thl;
+    const int CI = p.C0 + p.C1;
+    const int ct = blockIdx.x % p.ctiles, nt = blockIdx.x / p.ctiles;
+    const int c_base = ct * TC, n_base = nt * TN;
+    const int s_hpi = p.SHH * p.SHW, z_hpi = p.ZHH * p.ZHW;
+    const bool wave_active = (n_base + nblk * 32 < p.CO) && (c_base + cblk * 32 < CI);
+
+    f32x16 acc[CU_MAX_TAPS];
+#pragma unroll
+    for (int t = 0; t < CU_MAX_TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    for (int tile = blockIdx.y; tile < p.ntiles; tile += p.splits) {
+        int bx = tile;
+        const int tile_x = bx % p.tiles_x; bx /= p.tiles_x;
+        const int tile_y = bx % p.tiles_y;
+        const int ig = bx / p.tiles_y;
+        const int py0 = tile_y << p.thl, px0 = tile_x << p.twl, img0 = ig << p.iml;
+        const int sy0 = py0 * p.IS + p.sdymin, sx0 = px0 * p.IS + p.sdxmin;
+        const int zy0 = py0 * p.ZS + p.zdymin, zx0 = px0 * p.ZS + p.zdxmin;
+
+        __syncthreads();   // previous tile's fragment reads are done
+        // ---- stage the source halo (with the producing layer's affine + LeakyReLU) and the Z patch
+#pragma unroll 4
+        for (int i = tid; i < p.s_halo * SPP; i += 256) {
+            const int piece = i % SPP, hp = i / SPP;
+            const int im = __umulhi((unsigned)hp, p.mg_shpi), rem = hp - im * s_hpi;
+            const int hy = __umulhi((unsigned)rem, p.mg_shw), hx = rem - hy * p.SHW;
+            const int n = img0 + im, sy = sy0 + hy, sx = sx0 + hx;
+            const int c = c_base + piece * PIECE;
+            float v[PIECE];
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) v[e] = 0.f;
+            if (n < p.N && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW && c < CI) {
+                const bool s1 = c >= p.C0;
+                const T* src = reinterpret_cast<const T*>(s1 ? p.src1 : p.src0);
+                const int Cs = s1 ? p.C1 : p.C0, cc = s1 ? c - p.C0 : c;
+                const float* sc = s1 ? p.sc1 : p.sc0;
+                const float* sh = s1 ? p.sh1 : p.sh0;
+                const float slope = s1 ? p.slope1 : p.slope0;
+                load_piece<T>(src + ((size_t)(n * p.SH + sy) * p.SW + sx) * Cs + cc, v);
+                if (sc != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < PIECE; ++e) v[e] = v[e] * sc[(size_t)n * Cs + cc + e] + sh[(size_t)n * Cs + cc + e];
+                }
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+            }
+            store_piece<T>(reinterpret_cast<T*>(Ss + hp * ROWS_B + piece * 16), v);
+        }
+#pragma unroll 4
+        for (int i = tid; i < p.z_halo * ZPP; i += 256) {
+            const int piece = i % ZPP, hp = i / ZPP;
+            const int im = __umulhi((unsigned)hp, p.mg_zhpi), rem = hp - im * z_hpi;
+            const int hy = __umulhi((unsigned)rem, p.mg_zhw), hx = rem - hy * p.ZHW;
+            const int n = img0 + im, zy = zy0 + hy, zx = zx0 + hx;
+            const int col = n_base + piece * PIECE;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (n < p.N && zy >= 0 && zy < p.ZH && zx >= 0 && zx < p.ZW && col < p.CO)
+                v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.z) +
+                                                    ((size_t)(n * p.ZH + zy) * p.ZW + zx) * p.ZC + col);
+            *reinterpret_cast<u32x4*>(Zs + hp * ROWZ_B + piece * 16) = v;
+        }
+        __syncthreads();
+        if (!wave_active) continue;
+
+        const int NK = p.tile_px / KPIX;
+        for (int ks = kpart; ks < NK; ks += KSPLIT) {
+            if constexpr (sizeof(T) == 2) {
+                // lane l = 16g + 4q + pp supplies row q of its group's 4x16 transpose block
+                const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+                const int hh = g >> 1, chalf = g & 1;
+                int sbase[2], zbase[2];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int m = ks * 16 + 8 * hh + 4 * half + q;
+                    const int tx = m & (TW - 1), ty = (m >> p.twl) & (TH - 1), im = m >> (p.twl + p.thl);
+                    sbase[half] = (im * s_hpi + ty * p.IS * p.SHW + tx * p.IS) * ROWS_B + (cblk * 32 + 16 * chalf + 4 * pp) * 2;
+                    zbase[half] = (im * z_hpi + ty * p.ZS * p.ZHW + tx * p.ZS) * ROWZ_B + (nblk * 32 + 16 * chalf + 4 * pp) * 2;
+                }
+                bf16x8 af;
+                if (p.zsame) {
+                    const bf16x4 a0 = tr_read(Zs + zbase[0] + p.z_off[0] * ROWZ_B);
+                    const bf16x4 a1 = tr_read(Zs + zbase[1] + p.z_off[0] * ROWZ_B);
+                    af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int t = 0; t < CU_MAX_TAPS; ++t) {
+                    if (t < p.ntaps) {
+                        if (!p.zsame) {
+                            const bf16x4 a0 = tr_read(Zs + zbase[0] + p.z_off[t] * ROWZ_B);
+                            const bf16x4 a1 = tr_read(Zs + zbase[1] + p.z_off[t] * ROWZ_B);
+                            af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                        const bf16x4 b0 = tr_read(Ss + sbase[0] + p.s_off[t] * ROWS_B);
+                        const bf16x4 b1 = tr_read(Ss + sbase[1] + p.s_off[t] * ROWS_B);
+                        const bf16x8 bfr = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+                    }
+                }
+            } else {
+                const int r = lane & 31, hh = lane >> 5;
+                const int m = ks * 2 + hh;
+                const int tx = m & (TW - 1), ty = (m >> p.twl) & (TH - 1), im = m >> (p.twl + p.thl);
+                const int sbase = (im * s_hpi + ty * p.IS * p.SHW + tx * p.IS) * ROWS_B + (cblk * 32 + r) * 4;
+                const int zbase = (im * z_hpi + ty * p.ZS * p.ZHW + tx * p.ZS) * ROWZ_B + (nblk * 32 + r) * 4;
+#pragma unroll
+                for (int t = 0; t < CU_MAX_TAPS; ++t) {
+                    if (t < p.ntaps) {
+                        const float a = *reinterpret_cast<const float*>(Zs + zbase + p.z_off[t] * ROWZ_B);
+                        const float b = *reinterpret_cast<const float*>(Ss + sbase + p.s_off[t] * ROWS_B);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    if (!wave_active) return;
+    // ---- atomics: col (lane&31) = c, rows = n
+    const int r = lane & 31, hh = lane >> 5;
+    const int c = c_base + cblk * 32 + r;
+    if (c >= CI) return;
+#pragma unroll
+    for (int t = 0; t < CU_MAX_TAPS; ++t) {
+        if (t < p.ntaps) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = n_base + nblk * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                if (n < p.CO) unsafeAtomicAdd(p.dw + ((size_t)p.tap_w[t] * p.CO + n) * CI + c, acc[t][i]);
+            }
+        }
+    }
+}
+
+template <typename T, int NBLK, int CBLK>
+int launch(WgKArgs& a, hipStream_t st) {
+    constexpr int TN = 32 * NBLK, TC = 32 * CBLK;
+    constexpr int ROWS_B = (sizeof(T) == 2) ? (TC == 32 ? 64 : 192) : TC * 4 + 16;
+    constexpr int ROWZ_B = (sizeof(T) == 2) ? (TN == 32 ? 64 : 192) : TN * 4 + 16;
+    const size_t lds = (size_t)a.s_halo * ROWS_B + (size_t)a.z_halo * ROWZ_B;
+    CU_CHECK_ARG(lds <= 160 * 1024, "cu_conv_wgrad: LDS %zu bytes exceeds 160 KiB", lds);
+    auto k = igemm_wgrad_kernel<T, NBLK, CBLK>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        CU_CHECK_ARG(e == hipSuccess, "cu_conv_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    }
+    const int CI = a.C0 + a.C1;
+    a.ctiles = cdiv(CI, TC);
+    const int ntn = cdiv(a.CO, TN);
+    if (a.splits <= 0) {
+        // enough workgroups to fill 256 CUs a few times over, but never more splits than tiles
+        int want = cdiv(1024, a.ctiles * ntn);
+        a.splits = want < 1 ? 1 : want;
+    }
+    if (a.splits > a.ntiles) a.splits = a.ntiles;
+    dim3 grid(a.ctiles * ntn, a.splits);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const float* scale0, const float* shift0,
+                             const void* src1, const float* scale1, const float* shift1, const void* z, float* dw,
+                             void* stream) {
+    CU_CHECK_ARG(d != nullptr, "cu_conv_wgrad: null descriptor");
+    CU_CHECK_ARG(d->dtype == CU_F32 || d->dtype == CU_BF16, "cu_conv_wgrad: bad dtype %d", d->dtype);
+    CU_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= CU_MAX_TAPS, "cu_conv_wgrad: ntaps %d", d->ntaps);
+    const int PIECE = d->dtype == CU_BF16 ? 8 : 4;
+    CU_CHECK_ARG(d->C0 > 0 && d->C0 % PIECE == 0 && d->C1 >= 0 && d->C1 % PIECE == 0 && d->ZC % PIECE == 0 &&
+                     d->CO % PIECE == 0 && d->CO <= d->ZC,
+                 "cu_conv_wgrad: channel counts must be multiples of %d", PIECE);
+    CU_CHECK_ARG(src0 && z && dw && (d->C1 == 0 || src1), "cu_conv_wgrad: null pointer");
+    CU_CHECK_ARG((scale0 == nullptr) == (shift0 == nullptr) && (scale1 == nullptr) == (shift1 == nullptr),
+                 "cu_conv_wgrad: scale/shift must come in pairs");
+
+    WgKArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src0 = src0; a.src1 = src1; a.sc0 = scale0; a.sh0 = shift0; a.sc1 = scale1; a.sh1 = shift1; a.z = z; a.dw = dw;
+    a.N = d->N; a.PH = d->PH; a.PW = d->PW; a.SH = d->SH; a.SW = d->SW; a.C0 = d->C0; a.C1 = d->C1; a.IS = d->IS;
+    a.ZH = d->ZH; a.ZW = d->ZW; a.ZC = d->ZC; a.ZS = d->ZS; a.CO = d->CO; a.ntaps = d->ntaps;
+    a.slope0 = d->slope0; a.slope1 = d->slope1; a.splits = d->splits;
+
+    const int BM = (d->IS > 1 || d->ZS > 1) ? 64 : 128;   // stride-2 gathers have 4x the halo: halve the tile
+    a.tile_px = BM;
+    int tw = d->PW < 32 ? d->PW : 32;
+    if (tw > BM) tw = BM;
+    int th = BM / tw;
+    if (th > d->PH) th = d->PH;
+    int imgs = BM / (tw * th);
+    a.twl = ilog2_exact(tw); a.thl = ilog2_exact(th); a.iml = ilog2_exact(imgs);
+    CU_CHECK_ARG(a.twl >= 0 && a.thl >= 0 && a.iml >= 0 && d->PW % tw == 0 && d->PH % th == 0,
+                 "cu_conv_wgrad: loop grid %dx%d must be powers of two", d->PH, d->PW);
+    a.tiles_x = d->PW / tw; a.tiles_y = d->PH / th; a.igroups = cdiv(d->N, imgs);
+    a.ntiles = a.tiles_x * a.tiles_y * a.igroups;
+
+    int ymin = 1 << 20, xmin = 1 << 20, ymax = -(1 << 20), xmax = -(1 << 20);
+    int zymin = 1 << 20, zxmin = 1 << 20, zymax = -(1 << 20), zxmax = -(1 << 20);
+    for (int t = 0; t < d->ntaps; ++t) {
+        ymin = d->tap_dy[t] < ymin ? d->tap_dy[t] : ymin; ymax = d->tap_dy[t] > ymax ? d->tap_dy[t] : ymax;
+        xmin = d->tap_dx[t] < xmin ? d->tap_dx[t] : xmin; xmax = d->tap_dx[t] > xmax ? d->tap_dx[t] : xmax;
+        zymin = d->tap_zy[t] < zymin ? d->tap_zy[t] : zymin; zymax = d->tap_zy[t] > zymax ? d->tap_zy[t] : zymax;
+        zxmin = d->tap_zx[t] < zxmin ? d->tap_zx[t] : zxmin; zxmax = d->tap_zx[t] > zxmax ? d->tap_zx[t] : zxmax;
+    }
+    a.sdymin = ymin; a.sdxmin = xmin;
+    a.SHH = (th - 1) * d->IS + (ymax - ymin) + 1; a.SHW = (tw - 1) * d->IS + (xmax - xmin) + 1;
+    a.s_halo = imgs * a.SHH * a.SHW;
+    a.zdymin = zymin; a.zdxmin = zxmin;
+    a.ZHH = (th - 1) * d->ZS + (zymax - zymin) + 1; a.ZHW = (tw - 1) * d->ZS + (zxmax - zxmin) + 1;
+    a.z_halo = imgs * a.ZHH * a.ZHW;
+    a.mg_shpi = (unsigned)((0x100000000ull + (unsigned)(a.SHH * a.SHW) - 1) / (unsigned)(a.SHH * a.SHW));
+    a.mg_shw = (unsigned)((0x100000000ull + (unsigned)a.SHW - 1) / (unsigned)a.SHW);
+    a.mg_zhpi = (unsigned)((0x100000000ull + (unsigned)(a.ZHH * a.ZHW) - 1) / (unsigned)(a.ZHH * a.ZHW));
+    a.mg_zhw = (unsigned)((0x100000000ull + (unsigned)a.ZHW - 1) / (unsigned)a.ZHW);
+    a.zsame = 1;
+    for (int t = 0; t < d->ntaps; ++t) {
+        a.s_off[t] = (d->tap_dy[t] - ymin) * a.SHW + (d->tap_dx[t] - xmin);
+        a.z_off[t] = (d->tap_zy[t] - zymin) * a.ZHW + (d->tap_zx[t] - zxmin);
+        a.tap_w[t] = d->tap_w[t];
+        if (a.z_off[t] != a.z_off[0]) a.zsame = 0;
+    }
+
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int CI = d->C0 + d->C1;
+    const bool wide_n = d->CO > 32, wide_c = CI > 32;
+    if (d->dtype == CU_BF16) {
+        if (wide_n && wide_c) return launch<bf16_t, 2, 2>(a, st);
+        if (wide_n) return launch<bf16_t, 2, 1>(a, st);
+        if (wide_c) return launch<bf16_t, 1, 2>(a, st);
+        return launch<bf16_t, 1, 1>(a, st);
+    } else {
+        if (wide_n && wide_c) return launch<float, 2, 2>(a, st);
+        if (wide_n) return launch<float, 2, 1>(a, st);
+        if (wide_c) return launch<float, 1, 2>(a, st);
+        return launch<float, 1, 1>(a, st);
+    }
+}

@@ -1,0 +1,242 @@
+// Small kernels of libcontour_hip.so: first-layer direct conv (Cin = 1), operand-copy preparation, fused Adam.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------- first conv, Cin = 1
+// reference: input_block.conv1.conv = nn.Conv2d(1, 32, 3, 1, 1) (models/nnUnet/unet2.py:113-119, layers.py:192).
+// 0.13 % of the network's MACs and HBM-bound on its 64-byte/pixel store, so plain VALU FMAs.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, T* __restrict__ dst, int N,
+                                                          int H, int W, int CO) {
+    constexpr int PIECE = Elem<T>::PIECE;
+    const int ppp = CO / PIECE;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)N * H * W * ppp;
+    if (i >= total) return;
+    const int piece = i % ppp;
+    const size_t pix = i / ppp;
+    const int x = pix % W;
+    const int y = (pix / W) % H;
+    const int n = pix / ((size_t)W * H);
+    float acc[PIECE];
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) acc[e] = bias ? bias[piece * PIECE + e] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int sy = y + t / 3 - 1, sx = x + t % 3 - 1;
+        if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
+        const float v = img[((size_t)n * H + sy) * W + sx];
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) acc[e] += v * w[t * CO + piece * PIECE + e];
+    }
+    store_piece<T>(dst + pix * CO + piece * PIECE, acc);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ dz,
+                                                            float* __restrict__ dw, int N, int H, int W, int CO,
+                                                            int chunk) {
+    constexpr int PIECE = Elem<T>::PIECE;
+    extern __shared__ float lds[];
+    const int ppp = CO / PIECE;
+    const int rows = 256 / ppp;
+    const int piece = threadIdx.x % ppp, prow = threadIdx.x / ppp;
+    const int n = blockIdx.y;
+    const int HWn = H * W;
+    const int p0 = blockIdx.x * chunk, p1 = min(HWn, p0 + chunk);
+    float acc[9][PIECE];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) acc[t][e] = 0.f;
+    if (prow < rows) {
+        for (int p = p0 + prow; p < p1; p += rows) {
+            const int y = p / W, x = p - y * W;
+            float g[PIECE];
+            load_piece<T>(dz + ((size_t)n * HWn + p) * CO + piece * PIECE, g);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int sy = y + t / 3 - 1, sx = x + t % 3 - 1;
+                const float v = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? img[((size_t)n * H + sy) * W + sx] : 0.f;
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) acc[t][e] += v * g[e];
+            }
+        }
+        float* d = lds + ((size_t)prow * ppp + piece) * 9 * PIECE;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) d[t * PIECE + e] = acc[t][e];
+    }
+    __syncthreads();
+    // 9*CO outputs per block, summed over the rows by the first 9*CO threads (strided if more outputs than threads)
+    for (int o = threadIdx.x; o < 9 * CO; o += 256) {
+        const int t = o / CO, c = o - t * CO;
+        const int pc = c / PIECE, e = c - pc * PIECE;
+        float s = 0.f;
+        for (int rr = 0; rr < rows; ++rr) s += lds[((size_t)rr * ppp + pc) * 9 * PIECE + t * PIECE + e];
+        unsafeAtomicAdd(dw + o, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- operand copies
+// The nn.Parameters keep the reference's logical layouts (Conv2d: [CO][CI][kh][kw]; ConvTranspose2d: [CI][CO][kh][kw]) so
+// that reference checkpoints load with strict=True.  The MFMA kernels want tap-major operands:
+//   fwd operand   [T][CO][CI]   (rows = GEMM columns, K contiguous)
+//   dgrad operand [T][CI][CO]
+// element (t, co, ci) of the master sits at  co*s_co + ci*s_ci + t  (s_co, s_ci in elements).  32x32 LDS-tiled per tap.
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ m, T* __restrict__ wf,
+                                                          T* __restrict__ wd, int CO, int CI, int COP, long s_co,
+                                                          long s_ci) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int co = co0 + ty + 8 * k, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < CO && ci < CI) v = m[(size_t)co * s_co + (size_t)ci * s_ci + t];
+        if (co < COP && ci < CI && wf) Elem<T>::st(wf + ((size_t)t * COP + co) * CI + ci, v);
+        tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+    if (wd) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ci = ci0 + ty + 8 * k, co = co0 + tx;
+            if (co < COP && ci < CI) Elem<T>::st(wd + ((size_t)t * CI + ci) * COP + co, tile[tx][ty + 8 * k]);
+        }
+    }
+}
+
+// kernel-layout f32 gradient dWk[T][COP][CI] -> logical gradient (same strides as above), rows >= CO dropped
+__global__ __launch_bounds__(256) void grad_unprep_kernel(const float* __restrict__ dwk, float* __restrict__ g, int CO,
+                                                          int CI, int COP, long s_co, long s_ci, int accumulate) {
+    const int t = blockIdx.z;
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int co = co0 + ty + 8 * k, ci = ci0 + tx;
+        if (co < CO && ci < CI) {
+            const float v = dwk[((size_t)t * COP + co) * CI + ci];
+            float* o = g + (size_t)co * s_co + (size_t)ci * s_ci + t;
+            *o = accumulate ? *o + v : v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- Adam
+// torch.optim.Adam (no amsgrad, weight_decay folded into the gradient) -- reference vital/vital/system.py:82-115 with
+// vital/vital/config/task/optim/adam.yaml:1-4.  One 16-byte-per-lane streaming pass over the flat parameter buffer.
+__global__ __launch_bounds__(256) void adam_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, float lr, float b1,
+                                                   float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                   float gscale) {
+    const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    const float step = lr / bc1;
+    if (i4 + 4 <= n) {
+        f32x4 pv = *reinterpret_cast<f32x4*>(p + i4);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i4);
+        f32x4 mv = *reinterpret_cast<f32x4*>(m + i4), vv = *reinterpret_cast<f32x4*>(v + i4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = gv[e] * gscale + wd * pv[e];
+            mv[e] = b1 * mv[e] + (1.f - b1) * gg;
+            vv[e] = b2 * vv[e] + (1.f - b2) * gg * gg;
+            pv[e] -= step * mv[e] / (sqrtf(vv[e]) / bc2_sqrt + eps);
+        }
+        *reinterpret_cast<f32x4*>(p + i4) = pv;
+        *reinterpret_cast<f32x4*>(m + i4) = mv;
+        *reinterpret_cast<f32x4*>(v + i4) = vv;
+    } else {
+        for (size_t i = i4; i < n; ++i) {
+            const float gg = g[i] * gscale + wd * p[i];
+            m[i] = b1 * m[i] + (1.f - b1) * gg;
+            v[i] = b2 * v[i] + (1.f - b2) * gg * gg;
+            p[i] -= step * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cu_conv_c1_fwd(int dtype, int N, int H, int W, int CO, const float* img, const float* w, const float* bias,
+                              void* dst, void* stream) {
+    CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_conv_c1_fwd: bad dtype");
+    const int PIECE = dtype == CU_BF16 ? 8 : 4;
+    CU_CHECK_ARG(N > 0 && H > 0 && W > 0 && CO > 0 && CO % PIECE == 0 && img && w && dst, "cu_conv_c1_fwd: bad argument");
+    const size_t total = (size_t)N * H * W * (CO / PIECE);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL(conv_c1_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, img, w, bias, (bf16_t*)dst, N, H, W, CO);
+    else
+        hipLaunchKernelGGL(conv_c1_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, img, w, bias, (float*)dst, N, H, W, CO);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_conv_c1_wgrad(int dtype, int N, int H, int W, int CO, const float* img, const void* dz, float* dw,
+                                void* stream) {
+    CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_conv_c1_wgrad: bad dtype");
+    const int PIECE = dtype == CU_BF16 ? 8 : 4;
+    CU_CHECK_ARG(N > 0 && H > 0 && W > 0 && CO > 0 && CO % PIECE == 0 && CO / PIECE <= 256 && img && dz && dw,
+                 "cu_conv_c1_wgrad: bad argument");
+    const int ppp = CO / PIECE, rows = 256 / ppp;
+    int want = cdiv(1024, N);
+    int chunk = cdiv(cdiv(H * W, want), rows) * rows;
+    if (chunk < rows) chunk = rows;
+    dim3 grid(cdiv(H * W, chunk), N);
+    const size_t lds = sizeof(float) * (size_t)rows * ppp * 9 * PIECE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL(conv_c1_wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, img, (const bf16_t*)dz, dw, N, H, W, CO, chunk);
+    else
+        hipLaunchKernelGGL(conv_c1_wgrad_kernel<float>, grid, dim3(256), lds, st, img, (const float*)dz, dw, N, H, W, CO, chunk);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_weight_prep(int dtype, int T, int CO, int CI, int COP, long s_co, long s_ci, const float* master,
+                              void* w_fwd, void* w_dgrad, void* stream) {
+    CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_weight_prep: bad dtype");
+    CU_CHECK_ARG(T > 0 && CO > 0 && CI > 0 && COP >= CO && master && (w_fwd || w_dgrad), "cu_weight_prep: bad argument");
+    dim3 grid(cdiv(CI, 32), cdiv(COP, 32), T);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL(weight_prep_kernel<bf16_t>, grid, dim3(256), 0, st, master, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, CO,
+                           CI, COP, s_co, s_ci);
+    else
+        hipLaunchKernelGGL(weight_prep_kernel<float>, grid, dim3(256), 0, st, master, (float*)w_fwd, (float*)w_dgrad, CO, CI,
+                           COP, s_co, s_ci);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_ci, const float* dwk, float* grad,
+                              int accumulate, void* stream) {
+    CU_CHECK_ARG(T > 0 && CO > 0 && CI > 0 && COP >= CO && dwk && grad, "cu_grad_unprep: bad argument");
+    dim3 grid(cdiv(CI, 32), cdiv(CO, 32), T);
+    hipLaunchKernelGGL(grad_unprep_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dwk, grad, CO, CI,
+                       COP, s_co, s_ci, accumulate);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_adam_step(size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    CU_CHECK_ARG(n > 0 && p && g && m && v && step >= 1, "cu_adam_step: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    const size_t blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, p, g, m,
+                       v, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+    CU_LAUNCH_CHECK();
+    return 0;
+}

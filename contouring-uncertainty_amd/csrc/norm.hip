@@ -1,0 +1,450 @@
+// InstanceNorm2d(affine) + LeakyReLU in fused form (reference models/nnUnet/layers.py:193-194,203-204), NHWC.
+//
+// Forward: only the per-(image,channel) statistics are computed here (one streaming read of the raw conv output);
+// the normalise + affine + LeakyReLU is applied by the consumer while it loads its operand (igemm_conv.hip /
+// igemm_wgrad.hip), so the activated tensor never exists in HBM.
+// Backward: one reduction pass (A1 = sum g*l', A2 = sum g*l'*xhat) and one in-place pass that turns dL/d(activated)
+// into dL/dz; d(gamma), d(beta) and d(conv bias) fall out of the same passes.
+// All kernels are HBM-bound streaming reductions: 16-byte loads, one channel piece per thread, LDS tree, few atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// thread -> (channel piece, pixel row) mapping shared by the streaming kernels
+struct RowMap {
+    int tpp;     // threads (pieces) per pixel
+    int rows;    // pixel rows handled per iteration
+};
+static inline RowMap row_map(int C, int piece) {
+    RowMap m;
+    m.tpp = C / piece;
+    m.rows = NT / m.tpp;
+    if (m.rows < 1) m.rows = 1;
+    return m;
+}
+
+// Block-level reduction over pixel rows of per-thread partials v[NV][PIECE]; result lands in thread (prow == 0).
+template <int NV, int PIECE>
+__device__ __forceinline__ void reduce_rows(float (&v)[NV][PIECE], float* lds, int piece, int prow, int rows, int tpp,
+                                            bool active) {
+    // lds: [rows][tpp][NV*PIECE]
+    const int stride = NV * PIECE;
+    if (active) {
+        float* d = lds + ((size_t)prow * tpp + piece) * stride;
+#pragma unroll
+        for (int a = 0; a < NV; ++a)
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) d[a * PIECE + e] = v[a][e];
+    }
+    __syncthreads();
+    if (active && prow == 0) {
+        for (int rr = 1; rr < rows; ++rr) {
+            const float* s = lds + ((size_t)rr * tpp + piece) * stride;
+#pragma unroll
+            for (int a = 0; a < NV; ++a)
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) v[a][e] += s[a * PIECE + e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward statistics
+template <typename T>
+__global__ __launch_bounds__(NT) void stats_partial_kernel(const T* __restrict__ z, float* __restrict__ ws, int HW, int C,
+                                                           int tpp, int rows, int chunk) {
+    constexpr int PIECE = Elem<T>::PIECE;
+    extern __shared__ float lds[];
+    const int n = blockIdx.x;
+    const int p0 = blockIdx.y * chunk;
+    const int p1 = min(HW, p0 + chunk);
+    const int piece = threadIdx.x % tpp, prow = threadIdx.x / tpp;
+    const bool active = prow < rows && piece < tpp;
+    float acc[2][PIECE];
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) acc[0][e] = acc[1][e] = 0.f;
+    if (active) {
+        const T* base = z + (size_t)n * HW * C + piece * PIECE;
+        float k[PIECE];
+        load_piece<T>(base, k);   // shift by the image's first pixel: avoids E[x^2]-E[x]^2 cancellation
+        for (int p = p0 + prow; p < p1; p += rows) {
+            float v[PIECE];
+            load_piece<T>(base + (size_t)p * C, v);
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) {
+                const float d = v[e] - k[e];
+                acc[0][e] += d;
+                acc[1][e] += d * d;
+            }
+        }
+    }
+    reduce_rows<2, PIECE>(acc, lds, piece, prow, rows, tpp, active);
+    if (active && prow == 0) {
+        float* o = ws + ((size_t)n * C + piece * PIECE) * 2;
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+            unsafeAtomicAdd(o + 2 * e, acc[0][e]);
+            unsafeAtomicAdd(o + 2 * e + 1, acc[1][e]);
+        }
+    }
+}
+
+template <typename T>
+__global__ void stats_finalize_kernel(const T* __restrict__ z, const float* __restrict__ ws,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                      float* __restrict__ stats, int N, int HW, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    const float k = Elem<T>::ld(z + (size_t)n * HW * C + c);
+    const float inv = 1.f / (float)HW;
+    const float m1 = ws[2 * i] * inv, m2 = ws[2 * i + 1] * inv;
+    const float mean = k + m1;
+    const float var = fmaxf(m2 - m1 * m1, 0.f);
+    const float rstd = 1.f / sqrtf(var + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const size_t NC = (size_t)N * C;
+    stats[i] = mean;
+    stats[NC + i] = rstd;
+    stats[2 * NC + i] = g * rstd;
+    stats[3 * NC + i] = b - mean * g * rstd;
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+template <typename T>
+__global__ __launch_bounds__(NT) void bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ z,
+                                                        const float* __restrict__ stats, float slope,
+                                                        float* __restrict__ ws, int N, int HW, int C, int tpp, int rows,
+                                                        int chunk) {
+    constexpr int PIECE = Elem<T>::PIECE;
+    extern __shared__ float lds[];
+    const int n = blockIdx.x;
+    const int p0 = blockIdx.y * chunk, p1 = min(HW, p0 + chunk);
+    const int piece = threadIdx.x % tpp, prow = threadIdx.x / tpp;
+    const bool active = prow < rows;
+    const size_t NC = (size_t)N * C;
+    float acc[2][PIECE];
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) acc[0][e] = acc[1][e] = 0.f;
+    if (active) {
+        const size_t sidx = (size_t)n * C + piece * PIECE;
+        float mean[PIECE], rstd[PIECE], sc[PIECE], sh[PIECE];
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+            mean[e] = stats[sidx + e]; rstd[e] = stats[NC + sidx + e];
+            sc[e] = stats[2 * NC + sidx + e]; sh[e] = stats[3 * NC + sidx + e];
+        }
+        const size_t base = (size_t)n * HW * C + piece * PIECE;
+        for (int p = p0 + prow; p < p1; p += rows) {
+            float zv[PIECE], gv[PIECE];
+            load_piece<T>(z + base + (size_t)p * C, zv);
+            load_piece<T>(g + base + (size_t)p * C, gv);
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) {
+                const float y = zv[e] * sc[e] + sh[e];
+                const float gl = y > 0.f ? gv[e] : gv[e] * slope;
+                acc[0][e] += gl;
+                acc[1][e] += gl * (zv[e] - mean[e]) * rstd[e];
+            }
+        }
+    }
+    reduce_rows<2, PIECE>(acc, lds, piece, prow, rows, tpp, active);
+    if (active && prow == 0) {
+        float* o = ws + ((size_t)n * C + piece * PIECE) * 2;
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+            unsafeAtomicAdd(o + 2 * e, acc[0][e]);
+            unsafeAtomicAdd(o + 2 * e + 1, acc[1][e]);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void bwd_apply_kernel(T* __restrict__ g, const T* __restrict__ z,
+                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       float slope, const float* __restrict__ ws,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                       float* __restrict__ dbias, int N, int HW, int C, int tpp, int rows,
+                                                       int chunk) {
+    constexpr int PIECE = Elem<T>::PIECE;
+    extern __shared__ float lds[];
+    const int n = blockIdx.x;
+    const int p0 = blockIdx.y * chunk, p1 = min(HW, p0 + chunk);
+    const int piece = threadIdx.x % tpp, prow = threadIdx.x / tpp;
+    const bool active = prow < rows;
+    const size_t NC = (size_t)N * C;
+    float acc[1][PIECE];
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) acc[0][e] = 0.f;
+    if (active) {
+        const size_t sidx = (size_t)n * C + piece * PIECE;
+        float mean[PIECE], rstd[PIECE], sc[PIECE], sh[PIECE], a1[PIECE], a2[PIECE], gr[PIECE];
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+            mean[e] = stats[sidx + e]; rstd[e] = stats[NC + sidx + e];
+            sc[e] = stats[2 * NC + sidx + e]; sh[e] = stats[3 * NC + sidx + e];
+            a1[e] = ws[(sidx + e) * 2] * inv; a2[e] = ws[(sidx + e) * 2 + 1] * inv;
+            gr[e] = (gamma ? gamma[piece * PIECE + e] : 1.f) * rstd[e];
+        }
+        if (blockIdx.y == 0 && prow == 0) {   // one contribution per (image, channel)
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) {
+                if (dbeta) unsafeAtomicAdd(dbeta + piece * PIECE + e, ws[(sidx + e) * 2]);
+                if (dgamma) unsafeAtomicAdd(dgamma + piece * PIECE + e, ws[(sidx + e) * 2 + 1]);
+            }
+        }
+        const size_t base = (size_t)n * HW * C + piece * PIECE;
+        for (int p = p0 + prow; p < p1; p += rows) {
+            float zv[PIECE], gv[PIECE];
+            load_piece<T>(z + base + (size_t)p * C, zv);
+            load_piece<T>(g + base + (size_t)p * C, gv);
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) {
+                const float y = zv[e] * sc[e] + sh[e];
+                const float gl = y > 0.f ? gv[e] : gv[e] * slope;
+                const float xh = (zv[e] - mean[e]) * rstd[e];
+                gv[e] = gr[e] * (gl - a1[e] - xh * a2[e]);
+                acc[0][e] += gv[e];
+            }
+            store_piece<T>(g + base + (size_t)p * C, gv);
+        }
+    }
+    if (dbias) {
+        reduce_rows<1, PIECE>(acc, lds, piece, prow, rows, tpp, active);
+        if (active && prow == 0) {
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) unsafeAtomicAdd(dbias + piece * PIECE + e, acc[0][e]);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void act_bwd_kernel(T* __restrict__ g, const T* __restrict__ z, float slope,
+                                                     float* __restrict__ dbias, int HW, int C, int tpp, int rows,
+                                                     int chunk) {
+    constexpr int PIECE = Elem<T>::PIECE;
+    extern __shared__ float lds[];
+    const int n = blockIdx.x;
+    const int p0 = blockIdx.y * chunk, p1 = min(HW, p0 + chunk);
+    const int piece = threadIdx.x % tpp, prow = threadIdx.x / tpp;
+    const bool active = prow < rows;
+    float acc[1][PIECE];
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) acc[0][e] = 0.f;
+    if (active) {
+        const size_t base = (size_t)n * HW * C + piece * PIECE;
+        for (int p = p0 + prow; p < p1; p += rows) {
+            float zv[PIECE], gv[PIECE];
+            load_piece<T>(z + base + (size_t)p * C, zv);
+            load_piece<T>(g + base + (size_t)p * C, gv);
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) {
+                gv[e] = zv[e] > 0.f ? gv[e] : gv[e] * slope;
+                acc[0][e] += gv[e];
+            }
+            store_piece<T>(g + base + (size_t)p * C, gv);
+        }
+    }
+    if (dbias) {
+        reduce_rows<1, PIECE>(acc, lds, piece, prow, rows, tpp, active);
+        if (active && prow == 0) {
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) unsafeAtomicAdd(dbias + piece * PIECE + e, acc[0][e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ layout helpers (tiny tensors)
+template <typename T>
+__global__ void act_to_nchw_kernel(const T* __restrict__ z, const float* __restrict__ stats, float slope,
+                                   float* __restrict__ out, int N, int HW, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)N * HW * C;
+    if (i >= total) return;
+    const int c = i % C;
+    const size_t np = i / C;
+    const int p = np % HW, n = np / HW;
+    float v = Elem<T>::ld(z + i);
+    if (stats) {
+        const size_t NC = (size_t)N * C;
+        v = v * stats[2 * NC + (size_t)n * C + c] + stats[3 * NC + (size_t)n * C + c];
+    }
+    v = v > 0.f ? v : v * slope;
+    out[((size_t)n * C + c) * HW + p] = v;
+}
+// NCHW f32 [N][C][HW] -> NHWC [N][HW][CP] (channels >= C written as 0).  thread = (pixel, 8-channel group): a wave reads
+// 64-byte runs of CP/8 planes and writes whole 16-byte pieces.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int HW,
+                                                           int C, int CP) {
+    const int groups = CP / 8;
+    const int n = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int grp = i % groups;
+    const size_t p = i / groups;
+    if (p >= (size_t)HW) return;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = grp * 8 + e;
+        v[e] = c < C ? in[((size_t)n * C + c) * HW + p] : 0.f;
+    }
+    T* o = out + ((size_t)n * HW + p) * CP + grp * 8;
+    if constexpr (sizeof(T) == 2) {
+        store_piece<bf16_t>(reinterpret_cast<bf16_t*>(o), v);
+    } else {
+        float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+        store_piece<float>(reinterpret_cast<float*>(o), lo);
+        store_piece<float>(reinterpret_cast<float*>(o) + 4, hi);
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int N, int HW, int C, int accum) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)N * HW * C;
+    if (i >= total) return;
+    const int c = i % C;
+    const size_t np = i / C;
+    const int p = np % HW, n = np / HW;
+    float* o = out + ((size_t)n * C + c) * HW + p;
+    const float v = Elem<T>::ld(in + i);
+    *o = accum ? *o + v : v;
+}
+
+static int pick_chunk(int N, int HW, int rows, int* nchunks) {
+    // aim for ~2048 workgroups in total; every chunk a multiple of the rows handled per iteration
+    int want = cdiv(2048, N);
+    if (want < 1) want = 1;
+    int chunk = cdiv(HW, want);
+    chunk = cdiv(chunk, rows) * rows;
+    if (chunk < rows) chunk = rows;
+    *nchunks = cdiv(HW, chunk);
+    return chunk;
+}
+
+}  // namespace
+
+#define NORM_COMMON_CHECKS(name)                                                                              \
+    CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, name ": bad dtype %d", dtype);                          \
+    const int PIECE = dtype == CU_BF16 ? 8 : 4;                                                               \
+    CU_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % PIECE == 0, name ": bad shape N=%d HW=%d C=%d", N, HW, C);   \
+    CU_CHECK_ARG(C / PIECE <= NT, name ": C=%d too wide", C);                                                 \
+    const RowMap rm = row_map(C, PIECE);                                                                      \
+    int nchunks = 1;                                                                                          \
+    const int chunk = pick_chunk(N, HW, rm.rows, &nchunks);                                                   \
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);                                                   \
+    (void)chunk; (void)nchunks; (void)st;
+
+extern "C" int cu_instnorm_stats(int dtype, int N, int HW, int C, const void* z, const float* gamma, const float* beta,
+                                 float eps, float* stats, float* ws, void* stream) {
+    NORM_COMMON_CHECKS("cu_instnorm_stats");
+    CU_CHECK_ARG(z && stats && ws, "cu_instnorm_stats: null pointer");
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)N * C, st);
+    CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_stats: memset failed: %s", hipGetErrorString(e));
+    const size_t lds = sizeof(float) * (size_t)rm.rows * rm.tpp * 2 * PIECE;
+    dim3 grid(N, nchunks);
+    const int fin_blocks = cdiv(N * C, 256);
+    if (dtype == CU_BF16) {
+        hipLaunchKernelGGL(stats_partial_kernel<bf16_t>, grid, dim3(NT), lds, st, (const bf16_t*)z, ws, HW, C, rm.tpp,
+                           rm.rows, chunk);
+        hipLaunchKernelGGL(stats_finalize_kernel<bf16_t>, dim3(fin_blocks), dim3(256), 0, st, (const bf16_t*)z, ws, gamma,
+                           beta, eps, stats, N, HW, C);
+    } else {
+        hipLaunchKernelGGL(stats_partial_kernel<float>, grid, dim3(NT), lds, st, (const float*)z, ws, HW, C, rm.tpp,
+                           rm.rows, chunk);
+        hipLaunchKernelGGL(stats_finalize_kernel<float>, dim3(fin_blocks), dim3(256), 0, st, (const float*)z, ws, gamma,
+                           beta, eps, stats, N, HW, C);
+    }
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, const void* z, const float* stats,
+                                     const float* gamma, float slope, float* dgamma, float* dbeta, float* dbias,
+                                     float* ws, void* stream) {
+    NORM_COMMON_CHECKS("cu_instnorm_lrelu_bwd");
+    CU_CHECK_ARG(g && z && stats && ws, "cu_instnorm_lrelu_bwd: null pointer");
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)N * C, st);
+    CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_lrelu_bwd: memset failed: %s", hipGetErrorString(e));
+    const size_t lds = sizeof(float) * (size_t)rm.rows * rm.tpp * 2 * PIECE;
+    dim3 grid(N, nchunks);
+    if (dtype == CU_BF16) {
+        hipLaunchKernelGGL(bwd_reduce_kernel<bf16_t>, grid, dim3(NT), lds, st, (const bf16_t*)g, (const bf16_t*)z, stats,
+                           slope, ws, N, HW, C, rm.tpp, rm.rows, chunk);
+        hipLaunchKernelGGL(bwd_apply_kernel<bf16_t>, grid, dim3(NT), lds, st, (bf16_t*)g, (const bf16_t*)z, stats, gamma,
+                           slope, ws, dgamma, dbeta, dbias, N, HW, C, rm.tpp, rm.rows, chunk);
+    } else {
+        hipLaunchKernelGGL(bwd_reduce_kernel<float>, grid, dim3(NT), lds, st, (const float*)g, (const float*)z, stats,
+                           slope, ws, N, HW, C, rm.tpp, rm.rows, chunk);
+        hipLaunchKernelGGL(bwd_apply_kernel<float>, grid, dim3(NT), lds, st, (float*)g, (const float*)z, stats, gamma,
+                           slope, ws, dgamma, dbeta, dbias, N, HW, C, rm.tpp, rm.rows, chunk);
+    }
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_act_bwd(int dtype, int N, int HW, int C, void* g, const void* z, float slope, float* dbias,
+                          void* stream) {
+    NORM_COMMON_CHECKS("cu_act_bwd");
+    CU_CHECK_ARG(g && z, "cu_act_bwd: null pointer");
+    const size_t lds = sizeof(float) * (size_t)rm.rows * rm.tpp * PIECE;
+    dim3 grid(N, nchunks);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, grid, dim3(NT), lds, st, (bf16_t*)g, (const bf16_t*)z, slope, dbias, HW,
+                           C, rm.tpp, rm.rows, chunk);
+    else
+        hipLaunchKernelGGL(act_bwd_kernel<float>, grid, dim3(NT), lds, st, (float*)g, (const float*)z, slope, dbias, HW, C,
+                           rm.tpp, rm.rows, chunk);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_act_to_nchw_f32(int dtype, int N, int HW, int C, const void* z, const float* stats, float slope,
+                                  float* out, void* stream) {
+    CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_act_to_nchw_f32: bad dtype");
+    CU_CHECK_ARG(z && out && N > 0 && HW > 0 && C > 0, "cu_act_to_nchw_f32: bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t total = (size_t)N * HW * C;
+    const int blocks = (int)((total + 255) / 256);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL(act_to_nchw_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, stats, slope, out,
+                           N, HW, C);
+    else
+        hipLaunchKernelGGL(act_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, stats, slope, out, N,
+                           HW, C);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_nchw_f32_to_nhwc(int dtype, int N, int HW, int C, int CP, const float* in, void* out, void* stream) {
+    CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_nchw_f32_to_nhwc: bad dtype");
+    CU_CHECK_ARG(in && out && N > 0 && HW > 0 && C > 0 && CP >= C && CP % 8 == 0, "cu_nchw_f32_to_nhwc: bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t total = (size_t)HW * (CP / 8);
+    dim3 grid((unsigned)((total + 255) / 256), N);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, st, in, (bf16_t*)out, HW, C, CP);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, st, in, (float*)out, HW, C, CP);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_nhwc_to_nchw_f32(int dtype, int N, int HW, int C, const void* in, float* out, int accumulate,
+                                   void* stream) {
+    CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_nhwc_to_nchw_f32: bad dtype");
+    CU_CHECK_ARG(in && out && N > 0 && HW > 0 && C > 0, "cu_nhwc_to_nchw_f32: bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t total = (size_t)N * HW * C;
+    const int blocks = (int)((total + 255) / 256);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)in, out, N, HW, C,
+                           accumulate);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)in, out, N, HW, C,
+                           accumulate);
+    CU_LAUNCH_CHECK();
+    return 0;
+}

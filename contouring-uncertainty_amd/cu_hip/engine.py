@@ -1,0 +1,338 @@
+"""Kernel schedule of the dynamic nnU-Net-style U-Net (forward + hand-written backward) on the HIP C ABI.
+
+This is the MI355X replacement of ``UNet.forward`` (reference contour_uncertainty/models/nnUnet/unet2.py:177-208) and of
+PyTorch autograd's backward through it.  Every ``ConvLayer`` (conv -> InstanceNorm -> LeakyReLU, layers.py:167-205)
+becomes: one implicit-GEMM launch that writes the *raw* conv output once, one streaming statistics pass, and the
+normalise+activate folded into whichever kernels consume the tensor (next conv, skip concat, transposed conv, weight
+gradient).  ``torch.cat`` (layers.py:436) is a two-pointer operand load.  No tensor other than raw conv outputs and
+their gradients touches HBM.
+
+Data layout: activations NHWC (N, H, W, C) in ``dtype`` (bfloat16 production / float32 parity); logits NCHW float32.
+Parameters stay float32 in the reference's layouts and names; tap-major operand copies are refreshed when a parameter's
+version counter changes.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .ops import Act
+
+Tensor = torch.Tensor
+
+TAPS3 = [(kh - 1, kw - 1, kh * 3 + kw) for kh in range(3) for kw in range(3)]
+TAPS3_W = [(kh - 1, kw - 1, 0, 0, kh * 3 + kw) for kh in range(3) for kw in range(3)]
+# input gradient of a stride-1 3x3 conv: da[y] = sum dz[y + dy] w[kh = 1 - dy]
+TAPS3_D = [(dy, dx, (1 - dy) * 3 + (1 - dx)) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+
+
+def _parity_taps(par: int):
+    """stride-2 input gradient, one axis: (offset into dz, kernel index) pairs for input parity ``par``."""
+    return [(0, 1)] if par == 0 else [(1, 0), (0, 2)]
+
+
+@dataclass
+class _ConvRec:
+    prefix: str
+    srcs: List[Act]
+    out: Act
+    stride: int
+    first: bool = False          # Cin == 1 direct conv
+
+
+@dataclass
+class _UpRec:
+    prefix: str
+    src: Act
+    u: Act
+
+
+@dataclass
+class UNetCtx:
+    img: Tensor
+    convs: Dict[str, _ConvRec] = field(default_factory=dict)
+    ups: List[_UpRec] = field(default_factory=list)
+    enc: List[Act] = field(default_factory=list)
+    bott: Optional[Act] = None
+    last: Optional[Act] = None
+    n_up: int = 0
+
+
+class UNetEngine:
+    def __init__(self, in_channels: int, num_classes: int, strides: Sequence[int], filters: Sequence[int],
+                 negative_slope: float = 1e-2, eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16):
+        assert in_channels == 1, "the DSNT path feeds single-channel echo images (SURVEY.md 8b)"
+        assert num_classes <= 32
+        self.in_channels, self.num_classes = in_channels, num_classes
+        self.strides, self.filters = list(strides), list(filters)
+        self.slope, self.eps, self.dtype = negative_slope, eps, dtype
+        self._opcache: Dict[str, Tuple[int, int, Tensor, Tensor]] = {}
+        # called with a parameter-name prefix each time that layer's gradients are final (DDP bucket trigger)
+        self.grad_ready_hook: Optional[Callable[[str], None]] = None
+
+    # ------------------------------------------------------------------------------------------ operand copies
+    def _operands(self, name: str, w: Tensor, kind: str, cop: Optional[int] = None):
+        key = (w.data_ptr(), w._version, ops.PARAM_EPOCH[0])
+        hit = self._opcache.get(name)
+        if hit is not None and hit[0] == key and hit[1].dtype == self.dtype:
+            return hit[1], hit[2]
+        wf, wd = ops.weight_prep(w.detach(), kind, self.dtype, cop)
+        self._opcache[name] = (key, wf, wd)
+        return wf, wd
+
+    # ------------------------------------------------------------------------------------------ forward pieces
+    def _conv_layer_fwd(self, P, ctx: UNetCtx, prefix: str, srcs: List[Act], stride: int) -> Act:
+        w = P[f"{prefix}.conv.weight"]
+        wf, _ = self._operands(f"{prefix}.conv.weight", w, "conv")
+        n, sh, sw, _ = srcs[0].z.shape
+        oh, ow = sh // stride, sw // stride
+        co = w.shape[0]
+        z = torch.empty((n, oh, ow, co), dtype=self.dtype, device=w.device)
+        ops.conv_gemm(srcs, wf, P[f"{prefix}.conv.bias"], grid=(oh, ow), in_stride=stride, taps=TAPS3, dsts=[z],
+                      dst_cols=[co])
+        stats = ops.instnorm_stats(z, P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"], self.eps)
+        out = Act(z, stats, self.slope)
+        ctx.convs[prefix] = _ConvRec(prefix, srcs, out, stride)
+        return out
+
+    def _first_layer_fwd(self, P, ctx: UNetCtx, prefix: str, img: Tensor) -> Act:
+        w = P[f"{prefix}.conv.weight"]                       # (CO, 1, 3, 3)
+        co = w.shape[0]
+        key = (w.data_ptr(), w._version, ops.PARAM_EPOCH[0])
+        hit = self._opcache.get(prefix)
+        if hit is None or hit[0] != key:
+            w9, _ = ops.weight_prep(w.detach(), "conv", torch.float32, want_dgrad=False)   # [9][CO][1] f32
+            self._opcache[prefix] = (key, w9, None)
+        w9 = self._opcache[prefix][1]
+        n, _, h, w_ = img.shape
+        z = torch.empty((n, h, w_, co), dtype=self.dtype, device=img.device)
+        ops.conv_c1_fwd(img, w9, P[f"{prefix}.conv.bias"], z)
+        stats = ops.instnorm_stats(z, P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"], self.eps)
+        out = Act(z, stats, self.slope)
+        ctx.convs[prefix] = _ConvRec(prefix, [], out, 1, first=True)
+        return out
+
+    def _block_fwd(self, P, ctx, prefix: str, srcs: List[Act], stride: int) -> Act:
+        a = self._conv_layer_fwd(P, ctx, f"{prefix}.conv1", srcs, stride)
+        return self._conv_layer_fwd(P, ctx, f"{prefix}.conv2", [a], 1)
+
+    def _convT_fwd(self, P, ctx: UNetCtx, prefix: str, src: Act) -> Act:
+        w = P[f"{prefix}.weight"]                             # (CI, CO, 2, 2)
+        wf, _ = self._operands(f"{prefix}.weight", w, "convT")
+        n, h, w_, _ = src.z.shape
+        co = w.shape[1]
+        u = torch.empty((n, 2 * h, 2 * w_, co), dtype=self.dtype, device=w.device)
+        for dy in range(2):
+            for dx in range(2):
+                ops.conv_gemm([src], wf, None, grid=(h, w_), in_stride=1, taps=[(0, 0, dy * 2 + dx)], dsts=[u],
+                              dst_cols=[co], out_stride=2, out_off=(dy, dx))
+        out = Act(u, None, 1.0)
+        ctx.ups.append(_UpRec(prefix, src, out))
+        return out
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, P: Dict[str, Tensor], img: Tensor, want_bottleneck: bool):
+        """P: parameter name -> float32 device tensor (reference names).  img: (N, 1, H, W) float32."""
+        assert img.dtype == torch.float32 and img.is_cuda and img.shape[1] == 1
+        img = img.contiguous()
+        ctx = UNetCtx(img=img)
+        st = self.strides
+        assert st[0] == 1
+        a = self._first_layer_fwd(P, ctx, "input_block.conv1", img)
+        a = self._conv_layer_fwd(P, ctx, "input_block.conv2", [a], 1)
+        ctx.enc = [a]
+        nd = len(st) - 2
+        for i in range(nd):
+            a = self._block_fwd(P, ctx, f"downsamples.{i}", [a], st[i + 1])
+            ctx.enc.append(a)
+        a = self._block_fwd(P, ctx, "bottleneck", [a], st[-1])
+        ctx.bott = a
+        feats = ops.act_to_nchw_f32(a) if want_bottleneck else None
+        up_strides = st[1:][::-1]
+        for i, skip in enumerate(reversed(ctx.enc)):
+            assert up_strides[i] == 2, "transposed conv kernel = stride = 2 on the dsnt path"
+            u = self._convT_fwd(P, ctx, f"upsamples.{i}.transp_conv", a)
+            a = self._block_fwd(P, ctx, f"upsamples.{i}.conv_block", [u, skip], 1)
+        ctx.n_up = len(ctx.enc)
+        ctx.last = a
+        # 1x1 output conv -> NCHW f32 logits (K planes; GEMM columns padded to 32)
+        w = P["output_block.conv.weight"]
+        wf, _ = self._operands("output_block.conv.weight", w, "conv", cop=32)
+        n, h, w_, _ = a.z.shape
+        logits = torch.empty((n, self.num_classes, h, w_), dtype=torch.float32, device=img.device)
+        ops.conv_gemm([a], wf, None, grid=(h, w_), in_stride=1, taps=[(0, 0, 0)], dsts=[logits], dst_cols=[32],
+                      out_nchw=True, n_cols=32)
+        return logits, feats, ctx
+
+    # ------------------------------------------------------------------------------------------ backward pieces
+    def _ready(self, prefix: str):
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(prefix)
+
+    def _conv_layer_bwd(self, P, G, ctx: UNetCtx, prefix: str, g: Tensor,
+                        dsrc: Optional[List[Tuple[Tensor, int]]]):
+        """g: dL/d(activated output), overwritten with dL/dz.  dsrc: [(tensor, accumulate)] per source or None."""
+        rec = ctx.convs[prefix]
+        ops.instnorm_lrelu_bwd(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
+                               G[f"{prefix}.norm.bias"], G[f"{prefix}.conv.bias"])
+        w = P[f"{prefix}.conv.weight"]
+        n, oh, ow, co = g.shape
+        if rec.first:
+            dw9 = torch.zeros((9, co), dtype=torch.float32, device=g.device)
+            ops.conv_c1_wgrad(ctx.img, g, dw9)
+            ops.grad_unprep(dw9.view(9, co, 1), G[f"{prefix}.conv.weight"], "conv", accumulate=True)
+            self._ready(prefix)
+            return
+        ci = w.shape[1]
+        dwk = torch.zeros((9, co, ci), dtype=torch.float32, device=g.device)
+        ops.conv_wgrad(rec.srcs, g, dwk, grid=(oh, ow), in_stride=rec.stride, z_stride=1, taps=TAPS3_W, n_cols=co)
+        ops.grad_unprep(dwk, G[f"{prefix}.conv.weight"], "conv", accumulate=True)
+        self._ready(prefix)
+        if dsrc is None:
+            return
+        _, wd = self._operands(f"{prefix}.conv.weight", w, "conv")
+        dsts = [d[0] for d in dsrc]
+        acc = [d[1] for d in dsrc] + [0]
+        cols = [s.z.shape[3] for s in rec.srcs]
+        gz = Act(g, None, 1.0)
+        sh, sw = rec.srcs[0].z.shape[1:3]
+        if rec.stride == 1:
+            ops.conv_gemm([gz], wd, None, grid=(sh, sw), in_stride=1, taps=TAPS3_D, dsts=dsts, dst_cols=cols,
+                          accum=acc)
+        else:
+            for py in range(2):
+                for px in range(2):
+                    taps = [(dy, dx, kh * 3 + kw) for dy, kh in _parity_taps(py) for dx, kw in _parity_taps(px)]
+                    ops.conv_gemm([gz], wd, None, grid=(sh // 2, sw // 2), in_stride=1, taps=taps, dsts=dsts,
+                                  dst_cols=cols, out_stride=2, out_off=(py, px), accum=acc)
+
+    def _convT_bwd(self, P, G, rec: _UpRec, du: Tensor, d_in: Tensor, accum: int):
+        w = P[f"{rec.prefix}.weight"]
+        ci, co = w.shape[0], w.shape[1]
+        n, h, w_, _ = rec.src.z.shape
+        dwk = torch.zeros((4, co, ci), dtype=torch.float32, device=du.device)
+        taps = [(0, 0, dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)]
+        ops.conv_wgrad([rec.src], du, dwk, grid=(h, w_), in_stride=1, z_stride=2, taps=taps, n_cols=co)
+        ops.grad_unprep(dwk, G[f"{rec.prefix}.weight"], "convT", accumulate=True)
+        self._ready(rec.prefix)
+        _, wd = self._operands(f"{rec.prefix}.weight", w, "convT")
+        ops.conv_gemm([Act(du, None, 1.0)], wd, None, grid=(h, w_), in_stride=2,
+                      taps=[(dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)], dsts=[d_in], dst_cols=[ci],
+                      accum=[accum])
+
+    # ------------------------------------------------------------------------------------------ backward
+    def backward(self, P: Dict[str, Tensor], G: Dict[str, Tensor], ctx: UNetCtx, dlogits: Tensor,
+                 dfeats: Optional[Tensor]):
+        """Accumulates parameter gradients into G (float32, reference layouts; every touched tensor is ``+=``)."""
+        dt = self.dtype
+        last = ctx.last
+        n, h, w_, c_last = last.z.shape
+        # ---- 1x1 output conv
+        dl = ops.nchw_f32_to_nhwc(dlogits.contiguous(), dt, cp=32)
+        w = P["output_block.conv.weight"]
+        dwk = torch.zeros((1, 32, c_last), dtype=torch.float32, device=dl.device)
+        ops.conv_wgrad([last], dl, dwk, grid=(h, w_), in_stride=1, z_stride=1, taps=[(0, 0, 0, 0, 0)], n_cols=32)
+        ops.grad_unprep(dwk, G["output_block.conv.weight"], "conv", accumulate=True)
+        self._ready("output_block")
+        _, wd = self._operands("output_block.conv.weight", w, "conv", cop=32)
+        g = torch.empty_like(last.z)
+        ops.conv_gemm([Act(dl, None, 1.0)], wd, None, grid=(h, w_), in_stride=1, taps=[(0, 0, 0)], dsts=[g],
+                      dst_cols=[c_last])
+        del dl
+        # ---- decoder
+        d_enc: List[Optional[Tensor]] = [None] * len(ctx.enc)
+        n_up = ctx.n_up
+        d_bott = None
+        if dfeats is not None:
+            d_bott = ops.nchw_f32_to_nhwc(dfeats.contiguous(), dt)
+        for i in reversed(range(n_up)):
+            up = ctx.ups[i]
+            pre = f"upsamples.{i}.conv_block"
+            c1 = ctx.convs[f"{pre}.conv1"]
+            g_c1 = torch.empty_like(c1.out.z)
+            self._conv_layer_bwd(P, G, ctx, f"{pre}.conv2", g, [(g_c1, 0)])
+            k = n_up - 1 - i                      # encoder level of this skip
+            du = torch.empty_like(up.u.z)
+            d_enc[k] = torch.empty_like(ctx.enc[k].z)
+            self._conv_layer_bwd(P, G, ctx, f"{pre}.conv1", g_c1, [(du, 0), (d_enc[k], 0)])
+            del g_c1
+            if i == 0:
+                accum = 1 if d_bott is not None else 0
+                d_in = d_bott if d_bott is not None else torch.empty_like(up.src.z)
+            else:
+                accum = 0
+                d_in = torch.empty_like(up.src.z)
+            self._convT_bwd(P, G, up, du, d_in, accum)
+            del du
+            g = d_in
+        # ---- bottleneck + encoder
+        st = self.strides
+        blocks = [("bottleneck", len(ctx.enc) - 1)] + [(f"downsamples.{i}", i) for i in reversed(range(len(st) - 2))]
+        for prefix, k_in in blocks:
+            c1 = ctx.convs[f"{prefix}.conv1"]
+            g_c1 = torch.empty_like(c1.out.z)
+            self._conv_layer_bwd(P, G, ctx, f"{prefix}.conv2", g, [(g_c1, 0)])
+            self._conv_layer_bwd(P, G, ctx, f"{prefix}.conv1", g_c1, [(d_enc[k_in], 1)])
+            g = d_enc[k_in]
+        c1 = ctx.convs["input_block.conv1"]
+        g_c1 = torch.empty_like(c1.out.z)
+        self._conv_layer_bwd(P, G, ctx, "input_block.conv2", g, [(g_c1, 0)])
+        self._conv_layer_bwd(P, G, ctx, "input_block.conv1", g_c1, None)
+
+
+class ConfidenceEngine:
+    """ConfidenceNet (reference models/nnUnet/unet2.py:14-34): 3 x (conv3x3 + ReLU) -> flatten -> Linear."""
+
+    def __init__(self, dtype: torch.dtype = torch.bfloat16):
+        self.dtype = dtype
+        self._opcache: Dict[str, Tuple] = {}
+
+    def _operands(self, name, w):
+        key = (w.data_ptr(), w._version, ops.PARAM_EPOCH[0])
+        hit = self._opcache.get(name)
+        if hit is not None and hit[0] == key and hit[1].dtype == self.dtype:
+            return hit[1], hit[2]
+        wf, wd = ops.weight_prep(w.detach(), "conv", self.dtype)
+        self._opcache[name] = (key, wf, wd)
+        return wf, wd
+
+    def forward(self, P: Dict[str, Tensor], feats: Tensor):
+        """feats (N, 480, h, w) float32 NCHW -> (N, out) float32; returns (out, ctx)."""
+        n, c, h, w_ = feats.shape
+        x = Act(ops.nchw_f32_to_nhwc(feats.contiguous(), self.dtype), None, 1.0)
+        acts = [x]
+        for i in (0, 2, 4):
+            w = P[f"model.{i}.weight"]
+            wf, _ = self._operands(f"model.{i}.weight", w)
+            z = torch.empty((n, h, w_, w.shape[0]), dtype=self.dtype, device=feats.device)
+            ops.conv_gemm([acts[-1]], wf, P[f"model.{i}.bias"], grid=(h, w_), in_stride=1, taps=TAPS3, dsts=[z],
+                          dst_cols=[w.shape[0]])
+            acts.append(Act(z, None, 0.0))          # ReLU applied by the consumer
+        flat = ops.act_to_nchw_f32(acts[-1]).view(n, -1)      # nn.Flatten of the NCHW tensor
+        out = ops.linear_fwd(flat, P["model.7.weight"], P["model.7.bias"])
+        return out, (acts, flat)
+
+    def backward(self, P, G, ctx, gout: Tensor, need_input_grad: bool = True):
+        acts, flat = ctx
+        n, h, w_, c3 = acts[-1].z.shape
+        gflat = ops.linear_bwd(flat, P["model.7.weight"], gout.contiguous(), G["model.7.weight"], G["model.7.bias"])
+        g = ops.nchw_f32_to_nhwc(gflat.view(n, c3, h, w_), self.dtype)
+        for li, i in reversed(list(enumerate((0, 2, 4)))):
+            src, out = acts[li], acts[li + 1]
+            w = P[f"model.{i}.weight"]
+            co, ci = w.shape[0], w.shape[1]
+            ops.act_bwd(g, out.z, 0.0, G[f"model.{i}.bias"])
+            dwk = torch.zeros((9, co, ci), dtype=torch.float32, device=g.device)
+            ops.conv_wgrad([src], g, dwk, grid=(h, w_), in_stride=1, z_stride=1, taps=TAPS3_W, n_cols=co)
+            ops.grad_unprep(dwk, G[f"model.{i}.weight"], "conv", accumulate=True)
+            if li == 0 and not need_input_grad:
+                return None
+            _, wd = self._operands(f"model.{i}.weight", w)
+            gin = torch.empty_like(src.z)
+            ops.conv_gemm([Act(g, None, 1.0)], wd, None, grid=(h, w_), in_stride=1, taps=TAPS3_D, dsts=[gin],
+                          dst_cols=[ci])
+            g = gin
+        return ops.nhwc_to_nchw_f32(g)

@@ -1,0 +1,68 @@
+"""DSNT head + NLL as one autograd node on the HIP kernels.
+
+Replaces, for the tasks' ``_shared_step`` (reference task/regression/dsnt/dsnt_al.py:52-74, dsnt_skew.py:73-104):
+``flat_softmax`` -> ``dsnt`` -> ``normalized_to_pixel_coordinates`` -> ``get_cov_matrix`` -> Gaussian / skew-normal NLL
+and the logged means.  Forward runs ``cu_dsnt_head_fwd`` + ``cu_nll_fwd_bwd`` (which also yields the analytic
+gradients w.r.t. mu / Sigma / alpha); backward is one ``cu_dsnt_head_bwd`` streaming pass.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+
+Tensor = torch.Tensor
+
+LOG_KEYS = ("loss", "distance_loss", "loss_term1", "loss_term2", "loss_term3", "alpha_norm")
+
+
+class _DsntNllFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits: Tensor, y: Tensor, alpha: Optional[Tensor], covar: bool, w_mse: float, w_log: float):
+        logits = logits.contiguous()
+        need_grad = logits.requires_grad or (alpha is not None and alpha.requires_grad)
+        mu, sigma, aux = ops.dsnt_head_fwd(logits, covar)
+        al = alpha.contiguous().float() if alpha is not None else None
+        logs, gmu, gsigma, galpha = ops.nll_fwd_bwd(mu, sigma, y.contiguous().float(), al, w_mse, w_log, need_grad)
+        ctx.covar = covar
+        ctx.has_alpha = alpha is not None
+        if need_grad:
+            ctx.save_for_backward(logits, aux, gmu, gsigma, galpha if galpha is not None else torch.empty(0))
+        ctx.mark_non_differentiable(logs, mu, sigma)
+        return logs[0].clone(), logs, mu, sigma
+
+    @staticmethod
+    def backward(ctx, gloss, _glogs, _gmu, _gsigma):
+        logits, aux, gmu, gsigma, galpha = ctx.saved_tensors
+        scale = gloss.reshape(1)
+        dl = ops.dsnt_head_bwd(logits, aux, (gmu * scale).contiguous(), (gsigma * scale).contiguous(), ctx.covar)
+        dalpha = (galpha * scale) if ctx.has_alpha else None
+        return dl, None, dalpha, None, None, None
+
+
+def dsnt_nll(logits: Tensor, y: Tensor, alpha: Optional[Tensor] = None, covar: bool = True, mse_weight: float = 1.0,
+             log_penalty_weight: float = 1.0):
+    """logits (N,K,H,W) f32, y (N,K,2) pixel (x,y), alpha (N,K,2) or None ->
+    (logs dict of 0-dim tensors with a differentiable ``loss``, mu (N,K,2), Sigma (N,K,2,2))."""
+    loss, logs, mu, sigma3 = _DsntNllFn.apply(logits, y, alpha, bool(covar), float(mse_weight),
+                                              float(log_penalty_weight))
+    out: Dict[str, Tensor] = {"loss": loss, "distance_loss": logs[1], "loss_term1": logs[2], "loss_term2": logs[3]}
+    if alpha is not None:
+        out["loss_term3"] = logs[4]
+        out["alpha_norm"] = logs[5]
+    return out, mu, sigma_matrix(sigma3)
+
+
+def sigma_matrix(sigma3: Tensor) -> Tensor:
+    """{xx, yy, xy} -> (..., 2, 2) exactly as get_cov_matrix (reference aleatoric.py:138-144)."""
+    xx, yy, xy = sigma3[..., 0], sigma3[..., 1], sigma3[..., 2]
+    return torch.stack([torch.stack([xx, xy], -1), torch.stack([xy, yy], -1)], -2)
+
+
+@torch.no_grad()
+def dsnt_moments(logits: Tensor, covar: bool = True):
+    """predict-time head: pixel mu (N,K,2), Sigma (N,K,2,2)  (reference dsnt_al.py:118-131)."""
+    mu, sigma3, _ = ops.dsnt_head_fwd(logits.contiguous(), covar)
+    return mu, sigma_matrix(sigma3)

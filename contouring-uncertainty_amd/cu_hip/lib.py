@@ -1,0 +1,131 @@
+"""ctypes binding of libcontour_hip.so (the C ABI declared in include/contour_hip.h).
+
+The product path has NO fallback: if the shared library is missing, or a kernel is asked to run without a GPU,
+an exception is raised.  PyTorch is used only for device memory and streams (tensors' ``data_ptr()``, the current
+HIP stream handle).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+PKG_DIR = Path(__file__).resolve().parents[1]
+LIB_PATH = PKG_DIR / "libcontour_hip.so"
+
+CU_F32, CU_BF16 = 0, 1
+MAX_TAPS = 9
+
+_INT9 = C.c_int * MAX_TAPS
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("N", C.c_int), ("PH", C.c_int), ("PW", C.c_int), ("SH", C.c_int), ("SW", C.c_int),
+        ("C0", C.c_int), ("C1", C.c_int), ("IS", C.c_int), ("OH", C.c_int), ("OW", C.c_int), ("OS", C.c_int),
+        ("OY0", C.c_int), ("OX0", C.c_int), ("CO", C.c_int), ("D0", C.c_int), ("DC0", C.c_int), ("DC1", C.c_int),
+        ("ntaps", C.c_int), ("tap_dy", _INT9), ("tap_dx", _INT9), ("tap_w", _INT9),
+        ("slope0", C.c_float), ("slope1", C.c_float), ("accum0", C.c_int), ("accum1", C.c_int),
+        ("out_nchw_f32", C.c_int),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("N", C.c_int), ("PH", C.c_int), ("PW", C.c_int), ("SH", C.c_int), ("SW", C.c_int),
+        ("C0", C.c_int), ("C1", C.c_int), ("IS", C.c_int), ("ZH", C.c_int), ("ZW", C.c_int), ("ZC", C.c_int),
+        ("ZS", C.c_int), ("CO", C.c_int), ("ntaps", C.c_int), ("tap_dy", _INT9), ("tap_dx", _INT9),
+        ("tap_zy", _INT9), ("tap_zx", _INT9), ("tap_w", _INT9), ("slope0", C.c_float), ("slope1", C.c_float),
+        ("splits", C.c_int),
+    ]
+
+
+_P = C.c_void_p
+_SIGS = {
+    "cu_last_error": (C.c_char_p, []),
+    "cu_version": (C.c_int, []),
+    "cu_arch": (C.c_char_p, []),
+    "cu_conv_gemm": (C.c_int, [C.POINTER(ConvDesc)] + [_P] * 11),
+    "cu_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc)] + [_P] * 9),
+    "cu_conv_c1_fwd": (C.c_int, [C.c_int] * 5 + [_P] * 5),
+    "cu_conv_c1_wgrad": (C.c_int, [C.c_int] * 5 + [_P] * 4),
+    "cu_instnorm_stats": (C.c_int, [C.c_int] * 4 + [_P] * 3 + [C.c_float] + [_P] * 3),
+    "cu_instnorm_lrelu_bwd": (C.c_int, [C.c_int] * 4 + [_P] * 4 + [C.c_float] + [_P] * 5),
+    "cu_act_bwd": (C.c_int, [C.c_int] * 4 + [_P] * 2 + [C.c_float] + [_P] * 2),
+    "cu_act_to_nchw_f32": (C.c_int, [C.c_int] * 4 + [_P] * 2 + [C.c_float] + [_P] * 2),
+    "cu_nchw_f32_to_nhwc": (C.c_int, [C.c_int] * 5 + [_P] * 3),
+    "cu_nhwc_to_nchw_f32": (C.c_int, [C.c_int] * 4 + [_P] * 2 + [C.c_int, _P]),
+    "cu_dsnt_head_fwd": (C.c_int, [C.c_int] * 3 + [_P, C.c_int] + [_P] * 4),
+    "cu_dsnt_head_bwd": (C.c_int, [C.c_int] * 3 + [_P] * 4 + [C.c_int] + [_P] * 2),
+    "cu_nll_fwd_bwd": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float] + [_P] * 9),
+    "cu_linear_fwd": (C.c_int, [C.c_int] * 3 + [_P] * 5),
+    "cu_linear_bwd": (C.c_int, [C.c_int] * 3 + [_P] * 7),
+    "cu_weight_prep": (C.c_int, [C.c_int] * 5 + [C.c_long, C.c_long] + [_P] * 4),
+    "cu_grad_unprep": (C.c_int, [C.c_int] * 4 + [C.c_long, C.c_long] + [_P] * 2 + [C.c_int, _P]),
+    "cu_adam_step": (C.c_int, [C.c_size_t] + [_P] * 4 + [C.c_float] * 5 + [C.c_int, C.c_float, _P]),
+}
+
+_lib = None
+
+
+class ContourHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (no GPU needed for loading); raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("CONTOUR_HIP_LIB", LIB_PATH))
+    if not path.exists():
+        raise ContourHipError(
+            f"{path} not found: build it with `make -C {PKG_DIR / 'csrc'}` (or __graft_entry__.build()). "
+            "There is no CPU/PyTorch fallback for the HIP kernels.")
+    lib = C.CDLL(str(path))
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return list(_SIGS.keys())
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().cu_last_error().decode()
+        raise ContourHipError(f"{what} failed ({rc}): {msg}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """data_ptr of a CUDA tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ContourHipError("HIP kernels need device tensors (no CPU fallback)")
+    if not t.is_contiguous():
+        raise ContourHipError("HIP kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return CU_F32
+    if dt == torch.bfloat16:
+        return CU_BF16
+    raise ContourHipError(f"unsupported element type {dt}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise ContourHipError("no MI355X visible: the contour HIP path has no CPU fallback")

@@ -1,0 +1,267 @@
+"""Tensor-level wrappers over the C ABI (one Python function per kernel entry point).
+
+Geometry conventions (see include/contour_hip.h): activations are NHWC tensors (N, H, W, C) of dtype float32
+("parity mode") or bfloat16 ("production mode"); an :class:`Act` couples such a raw tensor with the pending
+InstanceNorm+LeakyReLU of the layer that produced it (applied by the consumer while loading).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as L
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class Act:
+    """Raw conv output + the normalisation/activation its consumers must apply on load."""
+    z: Tensor                          # (N, H, W, C) raw
+    stats: Optional[Tensor] = None     # (4, N, C) f32: mean, rstd, scale, shift   (None = no affine)
+    slope: float = 1.0                 # LeakyReLU slope (1.0 = identity, 0.0 = ReLU)
+
+    @property
+    def scale(self):
+        return None if self.stats is None else self.stats[2]
+
+    @property
+    def shift(self):
+        return None if self.stats is None else self.stats[3]
+
+
+def _taps(desc, dys, dxs, ws, zys=None, zxs=None):
+    desc.ntaps = len(dys)
+    for i, (a, b, c) in enumerate(zip(dys, dxs, ws)):
+        desc.tap_dy[i], desc.tap_dx[i], desc.tap_w[i] = a, b, c
+    if zys is not None:
+        for i, (a, b) in enumerate(zip(zys, zxs)):
+            desc.tap_zy[i], desc.tap_zx[i] = a, b
+
+
+def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: Tuple[int, int], in_stride: int,
+              taps: Sequence[Tuple[int, int, int]], dsts: Sequence[Tensor], dst_cols: Sequence[int],
+              out_stride: int = 1, out_off: Tuple[int, int] = (0, 0), accum: Sequence[int] = (0, 0),
+              out_nchw: bool = False, n_cols: Optional[int] = None):
+    """D[p, n] = bias[n] + sum_t sum_c act(S[p*IS + off_t, c]) W[tap_w[t]][n][c]  (cu_conv_gemm)."""
+    lib = L.load()
+    s0 = srcs[0]
+    s1 = srcs[1] if len(srcs) > 1 else None
+    d = L.ConvDesc()
+    d.dtype = L.dtype_code(s0.z.dtype)
+    d.N, d.SH, d.SW, d.C0 = s0.z.shape
+    d.C1 = s1.z.shape[3] if s1 is not None else 0
+    d.PH, d.PW = grid
+    d.IS = in_stride
+    dst0 = dsts[0]
+    if out_nchw:
+        d.OH, d.OW = dst0.shape[2], dst0.shape[3]
+        d.DC0 = dst0.shape[1]
+    else:
+        d.OH, d.OW = dst0.shape[1], dst0.shape[2]
+        d.DC0 = dst0.shape[3]
+    d.DC1 = dsts[1].shape[3] if len(dsts) > 1 else 0
+    d.OS = out_stride
+    d.OY0, d.OX0 = out_off
+    d.CO = n_cols if n_cols is not None else sum(dst_cols)
+    d.D0 = dst_cols[0]
+    _taps(d, [t[0] for t in taps], [t[1] for t in taps], [t[2] for t in taps])
+    d.slope0 = s0.slope
+    d.slope1 = s1.slope if s1 is not None else 1.0
+    d.accum0, d.accum1 = int(accum[0]), int(accum[1]) if len(accum) > 1 else 0
+    d.out_nchw_f32 = int(out_nchw)
+    assert w.dtype == s0.z.dtype and w.shape[-1] == d.C0 + d.C1 and w.shape[-2] == d.CO, (w.shape, d.CO, d.C0, d.C1)
+    rc = lib.cu_conv_gemm(d, L.ptr(s0.z), L.ptr(s0.scale), L.ptr(s0.shift),
+                          L.ptr(s1.z) if s1 is not None else None, L.ptr(s1.scale) if s1 is not None else None,
+                          L.ptr(s1.shift) if s1 is not None else None, L.ptr(w), L.ptr(bias), L.ptr(dst0),
+                          L.ptr(dsts[1]) if len(dsts) > 1 else None, L.stream_ptr())
+    L.check(rc, "cu_conv_gemm")
+
+
+def conv_wgrad(srcs: Sequence[Act], z: Tensor, dwk: Tensor, *, grid: Tuple[int, int], in_stride: int, z_stride: int,
+               taps: Sequence[Tuple[int, int, int, int, int]], n_cols: int, splits: int = 0):
+    """dWk[tap_w][n][c] += sum_p Z[p*ZS + zoff, n] * act(S[p*IS + off, c])  (cu_conv_wgrad); taps = (dy,dx,zy,zx,w)."""
+    lib = L.load()
+    s0 = srcs[0]
+    s1 = srcs[1] if len(srcs) > 1 else None
+    d = L.WgradDesc()
+    d.dtype = L.dtype_code(s0.z.dtype)
+    d.N, d.SH, d.SW, d.C0 = s0.z.shape
+    d.C1 = s1.z.shape[3] if s1 is not None else 0
+    d.PH, d.PW = grid
+    d.IS = in_stride
+    _, d.ZH, d.ZW, d.ZC = z.shape
+    d.ZS = z_stride
+    d.CO = n_cols
+    _taps(d, [t[0] for t in taps], [t[1] for t in taps], [t[4] for t in taps], [t[2] for t in taps],
+          [t[3] for t in taps])
+    d.slope0 = s0.slope
+    d.slope1 = s1.slope if s1 is not None else 1.0
+    d.splits = splits
+    assert dwk.dtype == torch.float32 and z.dtype == s0.z.dtype
+    rc = lib.cu_conv_wgrad(d, L.ptr(s0.z), L.ptr(s0.scale), L.ptr(s0.shift),
+                           L.ptr(s1.z) if s1 is not None else None, L.ptr(s1.scale) if s1 is not None else None,
+                           L.ptr(s1.shift) if s1 is not None else None, L.ptr(z), L.ptr(dwk), L.stream_ptr())
+    L.check(rc, "cu_conv_wgrad")
+
+
+def conv_c1_fwd(img: Tensor, w9: Tensor, bias: Optional[Tensor], dst: Tensor):
+    n, h, w_, co = dst.shape
+    L.check(L.load().cu_conv_c1_fwd(L.dtype_code(dst.dtype), n, h, w_, co, L.ptr(img), L.ptr(w9), L.ptr(bias),
+                                    L.ptr(dst), L.stream_ptr()), "cu_conv_c1_fwd")
+
+
+def conv_c1_wgrad(img: Tensor, dz: Tensor, dw9: Tensor):
+    n, h, w_, co = dz.shape
+    L.check(L.load().cu_conv_c1_wgrad(L.dtype_code(dz.dtype), n, h, w_, co, L.ptr(img), L.ptr(dz), L.ptr(dw9),
+                                      L.stream_ptr()), "cu_conv_c1_wgrad")
+
+
+def instnorm_stats(z: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float = 1e-5) -> Tensor:
+    n, h, w_, c = z.shape
+    stats = torch.empty((4, n, c), dtype=torch.float32, device=z.device)
+    ws = torch.empty((n, c, 2), dtype=torch.float32, device=z.device)
+    L.check(L.load().cu_instnorm_stats(L.dtype_code(z.dtype), n, h * w_, c, L.ptr(z), L.ptr(gamma), L.ptr(beta), eps,
+                                       L.ptr(stats), L.ptr(ws), L.stream_ptr()), "cu_instnorm_stats")
+    return stats
+
+
+def instnorm_lrelu_bwd(g: Tensor, act: Act, gamma: Optional[Tensor], dgamma, dbeta, dbias):
+    """In place: g (dL/d activated) -> dL/dz."""
+    n, h, w_, c = g.shape
+    ws = torch.empty((n, c, 2), dtype=torch.float32, device=g.device)
+    L.check(L.load().cu_instnorm_lrelu_bwd(L.dtype_code(g.dtype), n, h * w_, c, L.ptr(g), L.ptr(act.z),
+                                           L.ptr(act.stats), L.ptr(gamma), act.slope, L.ptr(dgamma), L.ptr(dbeta),
+                                           L.ptr(dbias), L.ptr(ws), L.stream_ptr()), "cu_instnorm_lrelu_bwd")
+
+
+def act_bwd(g: Tensor, z: Tensor, slope: float, dbias):
+    n, h, w_, c = g.shape
+    L.check(L.load().cu_act_bwd(L.dtype_code(g.dtype), n, h * w_, c, L.ptr(g), L.ptr(z), slope, L.ptr(dbias),
+                                L.stream_ptr()), "cu_act_bwd")
+
+
+def act_to_nchw_f32(act: Act) -> Tensor:
+    n, h, w_, c = act.z.shape
+    out = torch.empty((n, c, h, w_), dtype=torch.float32, device=act.z.device)
+    L.check(L.load().cu_act_to_nchw_f32(L.dtype_code(act.z.dtype), n, h * w_, c, L.ptr(act.z), L.ptr(act.stats),
+                                        act.slope, L.ptr(out), L.stream_ptr()), "cu_act_to_nchw_f32")
+    return out
+
+
+def nchw_f32_to_nhwc(x: Tensor, dtype: torch.dtype, cp: Optional[int] = None) -> Tensor:
+    n, c, h, w_ = x.shape
+    cp = cp or c
+    out = torch.empty((n, h, w_, cp), dtype=dtype, device=x.device)
+    L.check(L.load().cu_nchw_f32_to_nhwc(L.dtype_code(dtype), n, h * w_, c, cp, L.ptr(x), L.ptr(out), L.stream_ptr()),
+            "cu_nchw_f32_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw_f32(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    n, h, w_, c = x.shape
+    if out is None:
+        out = torch.empty((n, c, h, w_), dtype=torch.float32, device=x.device)
+    L.check(L.load().cu_nhwc_to_nchw_f32(L.dtype_code(x.dtype), n, h * w_, c, L.ptr(x), L.ptr(out), int(accumulate),
+                                         L.stream_ptr()), "cu_nhwc_to_nchw_f32")
+    return out
+
+
+def dsnt_head_fwd(logits: Tensor, use_covar: bool = True):
+    n, k, h, w_ = logits.shape
+    dev = logits.device
+    mu = torch.empty((n, k, 2), dtype=torch.float32, device=dev)
+    sigma = torch.empty((n, k, 3), dtype=torch.float32, device=dev)
+    aux = torch.empty((n, k, 8), dtype=torch.float32, device=dev)
+    L.check(L.load().cu_dsnt_head_fwd(n * k, h, w_, L.ptr(logits), int(use_covar), L.ptr(mu), L.ptr(sigma),
+                                      L.ptr(aux), L.stream_ptr()), "cu_dsnt_head_fwd")
+    return mu, sigma, aux
+
+
+def dsnt_head_bwd(logits: Tensor, aux: Tensor, gmu: Tensor, gsigma: Tensor, use_covar: bool = True) -> Tensor:
+    n, k, h, w_ = logits.shape
+    dl = torch.empty_like(logits)
+    L.check(L.load().cu_dsnt_head_bwd(n * k, h, w_, L.ptr(logits), L.ptr(aux), L.ptr(gmu), L.ptr(gsigma),
+                                      int(use_covar), L.ptr(dl), L.stream_ptr()), "cu_dsnt_head_bwd")
+    return dl
+
+
+def nll_fwd_bwd(mu: Tensor, sigma: Tensor, y: Tensor, alpha: Optional[Tensor], w_mse: float = 1.0,
+                w_log: float = 1.0, need_grad: bool = True):
+    m = mu.numel() // 2
+    dev = mu.device
+    logs = torch.empty(8, dtype=torch.float32, device=dev)
+    gmu = torch.empty_like(mu) if need_grad else None
+    gsigma = torch.empty_like(sigma) if need_grad else None
+    galpha = torch.empty_like(alpha) if (need_grad and alpha is not None) else None
+    L.check(L.load().cu_nll_fwd_bwd(m, int(alpha is not None), w_mse, w_log, L.ptr(mu), L.ptr(sigma), L.ptr(y),
+                                    L.ptr(alpha), L.ptr(logs), L.ptr(gmu), L.ptr(gsigma), L.ptr(galpha),
+                                    L.stream_ptr()), "cu_nll_fwd_bwd")
+    return logs, gmu, gsigma, galpha
+
+
+def linear_fwd(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    n, i = x.shape
+    o = w.shape[0]
+    out = torch.empty((n, o), dtype=torch.float32, device=x.device)
+    L.check(L.load().cu_linear_fwd(n, i, o, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(out), L.stream_ptr()), "cu_linear_fwd")
+    return out
+
+
+def linear_bwd(x: Tensor, w: Tensor, gout: Tensor, gw: Optional[Tensor], gb: Optional[Tensor], need_gx: bool = True):
+    n, i = x.shape
+    o = w.shape[0]
+    gx = torch.empty_like(x) if need_gx else None
+    L.check(L.load().cu_linear_bwd(n, i, o, L.ptr(x), L.ptr(w), L.ptr(gout), L.ptr(gx), L.ptr(gw), L.ptr(gb),
+                                   L.stream_ptr()), "cu_linear_bwd")
+    return gx
+
+
+def weight_prep(master: Tensor, kind: str, dtype: torch.dtype, cop: Optional[int] = None, want_fwd=True,
+                want_dgrad=True):
+    """master: the nn.Parameter in the reference's layout; kind: 'conv' (CO,CI,kh,kw) | 'convT' (CI,CO,kh,kw).
+    Returns (w_fwd [T][COP][CI], w_dgrad [T][CI][COP])."""
+    if kind == "conv":
+        co, ci, kh, kw = master.shape
+        t = kh * kw
+        s_co, s_ci = ci * t, t
+    elif kind == "convT":
+        ci, co, kh, kw = master.shape
+        t = kh * kw
+        s_co, s_ci = t, co * t
+    else:
+        raise ValueError(kind)
+    cop = cop or co
+    dev = master.device
+    wf = torch.empty((t, cop, ci), dtype=dtype, device=dev) if want_fwd else None
+    wd = torch.empty((t, ci, cop), dtype=dtype, device=dev) if want_dgrad else None
+    L.check(L.load().cu_weight_prep(L.dtype_code(dtype), t, co, ci, cop, s_co, s_ci, L.ptr(master), L.ptr(wf),
+                                    L.ptr(wd), L.stream_ptr()), "cu_weight_prep")
+    return wf, wd
+
+
+def grad_unprep(dwk: Tensor, grad: Tensor, kind: str, accumulate: bool = False):
+    if kind == "conv":
+        co, ci, kh, kw = grad.shape
+        t = kh * kw
+        s_co, s_ci = ci * t, t
+    else:
+        ci, co, kh, kw = grad.shape
+        t = kh * kw
+        s_co, s_ci = t, co * t
+    cop = dwk.shape[1]
+    L.check(L.load().cu_grad_unprep(t, co, ci, cop, s_co, s_ci, L.ptr(dwk), L.ptr(grad), int(accumulate),
+                                    L.stream_ptr()), "cu_grad_unprep")
+
+
+# Raw-pointer kernels do not bump tensor._version: operand caches key on this epoch as well.
+PARAM_EPOCH = [0]
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, beta2: float, eps: float,
+              weight_decay: float, step: int, grad_scale: float = 1.0):
+    PARAM_EPOCH[0] += 1
+    L.check(L.load().cu_adam_step(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), lr, beta1, beta2, eps,
+                                  weight_decay, step, grad_scale, L.stream_ptr()), "cu_adam_step")

@@ -1,0 +1,162 @@
+/*
+ * contour_hip.h -- C ABI of libcontour_hip.so: the MI355X (gfx950) kernels of the DSNT contour-regression hot path.
+ *
+ * Boundary rules:
+ *   - plain pointers and sizes only; every buffer is caller-owned device memory (PyTorch tensors' data_ptr()).
+ *   - no allocation, no ownership transfer, no global mutable state (except the thread-local last-error string).
+ *   - every call is asynchronous on the hipStream_t passed in (void* here so that C callers need no HIP headers).
+ *   - return 0 on success, a negative errno-style code otherwise; cu_last_error() gives the text.
+ *
+ * Each entry point names the reference (ThierryJudge/contouring-uncertainty) call site it replaces.
+ * dtype: 0 = f32 (parity mode, exact-f32 MFMA), 1 = bf16 (production mode, bf16 MFMA, f32 accumulate).
+ * Activations are NHWC ("pixel-major, channel-contiguous"); logits are NCHW f32.
+ */
+#ifndef CONTOUR_HIP_H
+#define CONTOUR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CU_F32 0
+#define CU_BF16 1
+#define CU_MAX_TAPS 9
+
+const char* cu_last_error(void);
+int cu_version(void);
+const char* cu_arch(void); /* "gfx950" */
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Generic implicit-GEMM "gather convolution":   D[p, n] = bias[n] + sum_t sum_c  act(S[p*IS + off_t, c]) * W[t][n][c]
+ * One kernel serves nn.Conv2d 3x3 s1/s2 forward (reference layers.py:55-80,192), its input gradient (autograd of the
+ * same), nn.ConvTranspose2d k2 s2 forward/input-gradient (layers.py:83-109,415-417), the 1x1 output conv
+ * (layers.py:456-463) and the ConfidenceNet convs (unet2.py:21-27).
+ *   - up to two channel-concatenated sources (torch.cat((out, skip), 1), layers.py:436, fused into the load),
+ *   - per-(image,channel) affine + LeakyReLU applied while loading (InstanceNorm2d + LeakyReLU of the producing layer,
+ *     layers.py:193-194,203-204, fused so the normalised tensor is never materialised),
+ *   - up to two channel-split destinations (gradient of the concat), optional accumulate.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int dtype;          /* CU_F32 | CU_BF16: element type of sources, weights and NHWC destinations */
+    int N;              /* images */
+    int PH, PW;         /* loop ("p") grid per image */
+    int SH, SW;         /* source image size */
+    int C0, C1;         /* channels of source 0 and source 1 (0 = absent); multiples of 32 (bf16) / 16 (f32) */
+    int IS;             /* source pixel = p*IS + (dy,dx) */
+    int OH, OW;         /* destination image size */
+    int OS, OY0, OX0;   /* destination pixel = p*OS + (OY0,OX0) */
+    int CO;             /* GEMM columns (rows of W per tap); W is [wtaps][CO][C0+C1] */
+    int D0;             /* columns [0,D0) -> dst0, [D0,CO) -> dst1 */
+    int DC0, DC1;       /* channel counts (pixel strides) of dst0 / dst1 */
+    int ntaps;
+    int tap_dy[CU_MAX_TAPS], tap_dx[CU_MAX_TAPS], tap_w[CU_MAX_TAPS];
+    float slope0, slope1;   /* LeakyReLU slope applied to source 0/1 after the affine; 1.0f = none */
+    int accum0, accum1;     /* 1: dst += result */
+    int out_nchw_f32;       /* 1: dst0 is NCHW f32 with DC0 planes (the logits); columns >= DC0 are dropped */
+} cu_conv_desc;
+
+int cu_conv_gemm(const cu_conv_desc* d,
+                 const void* src0, const float* scale0, const float* shift0,   /* scale/shift: [N][C0] or NULL */
+                 const void* src1, const float* scale1, const float* shift1,
+                 const void* w, const float* bias /* [CO] or NULL */,
+                 void* dst0, void* dst1, void* stream);
+
+/* Weight gradient of the same gather convolution:  dW[t][n][c] += sum_p Z[p*ZS + zoff_t, n] * act(S[p*IS + off_t, c])
+ * (autograd of nn.Conv2d / nn.ConvTranspose2d weights).  dW is f32, accumulated with atomics. */
+typedef struct {
+    int dtype;
+    int N;
+    int PH, PW;
+    int SH, SW, C0, C1, IS;        /* activation source(s), as above */
+    int ZH, ZW, ZC, ZS;            /* Z = gradient tensor [N][ZH][ZW][ZC] */
+    int CO;                        /* columns used (<= ZC) */
+    int ntaps;
+    int tap_dy[CU_MAX_TAPS], tap_dx[CU_MAX_TAPS];     /* source offsets */
+    int tap_zy[CU_MAX_TAPS], tap_zx[CU_MAX_TAPS];     /* Z offsets */
+    int tap_w[CU_MAX_TAPS];
+    float slope0, slope1;
+    int splits;                    /* pixel-range splits (grid.z); 0 = auto */
+} cu_wgrad_desc;
+
+int cu_conv_wgrad(const cu_wgrad_desc* d,
+                  const void* src0, const float* scale0, const float* shift0,
+                  const void* src1, const float* scale1, const float* shift1,
+                  const void* z, float* dw /* [wtaps][CO][C0+C1] f32 */, void* stream);
+
+/* First layer, Cin = 1 (input_block.conv1.conv, unet2.py:113-119): direct 3x3 conv of the f32 image. */
+int cu_conv_c1_fwd(int dtype, int N, int H, int W, int CO, const float* img /* [N][H][W] */,
+                   const float* w /* [9][CO] f32 */, const float* bias, void* dst /* NHWC */, void* stream);
+int cu_conv_c1_wgrad(int dtype, int N, int H, int W, int CO, const float* img, const void* dz /* NHWC */,
+                     float* dw /* [9][CO] f32, += */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * InstanceNorm2d(affine) + LeakyReLU (layers.py:193-194) in its fused form.
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* statistics of z [N][HW][C] -> stats[4][N][C] = planes {mean, rstd, scale = gamma*rstd, shift = beta - mean*gamma*rstd}
+ * (planes 2 and 3 are what cu_conv_gemm / cu_conv_wgrad take as scale / shift).
+ * ws: f32 workspace [N][C][2], zero-filled by the call. */
+int cu_instnorm_stats(int dtype, int N, int HW, int C, const void* z, const float* gamma, const float* beta,
+                      float eps, float* stats, float* ws, void* stream);
+/* backward: g = dL/d(activated output) [N][HW][C] is overwritten in place with dL/dz.
+ * dgamma/dbeta/dbias: f32 [C], accumulated (+=), any may be NULL.
+ * ws: f32 workspace [N][C][2], zero-filled by the call. */
+int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, const void* z, const float* stats,
+                          const float* gamma, float slope, float* dgamma, float* dbeta, float* dbias,
+                          float* ws, void* stream);
+/* plain activation backward for layers without norm (ConfidenceNet ReLU): g *= (z > 0 ? 1 : slope); dbias[c] += sum g */
+int cu_act_bwd(int dtype, int N, int HW, int C, void* g, const void* z, float slope, float* dbias, void* stream);
+/* materialise act(z*scale+shift) as NCHW f32 (the bottleneck clone handed to the skew head, unet2.py:186) and back */
+int cu_act_to_nchw_f32(int dtype, int N, int HW, int C, const void* z, const float* stats, float slope,
+                       float* out, void* stream);
+/* NCHW f32 [N][C][HW] -> NHWC (dtype) [N][HW][CP], channels >= C zero-filled (CP % 8 == 0) */
+int cu_nchw_f32_to_nhwc(int dtype, int N, int HW, int C, int CP, const float* in, void* out, void* stream);
+int cu_nhwc_to_nchw_f32(int dtype, int N, int HW, int C, const void* in, float* out, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * DSNT head: flat_softmax + dsnt + pixel rescale + get_cov_matrix
+ * (dsnt/utils.py:7-47,71-77,95-105; dsnt_al.py:52-60; aleatoric.py:138-144)
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* logits [N*K][H][W] f32 (H == W) -> mu [N*K][2] (pixel x,y), sigma [N*K][3] = {xx, yy, xy} (pixel^2),
+ * aux [N*K][8] = {max, 1/sumexp, xbar, ybar, varx, vary, covar (normalised units), 0} kept for backward. */
+int cu_dsnt_head_fwd(int NK, int H, int W, const float* logits, int use_covar, float* mu, float* sigma, float* aux,
+                     void* stream);
+/* gmu [N*K][2], gsigma [N*K][3] = dL/d(mu), dL/d{xx,yy,xy} (xy = the single covariance scalar feeding both
+ * off-diagonal entries) -> dlogits [N*K][H][W] f32. */
+int cu_dsnt_head_bwd(int NK, int H, int W, const float* logits, const float* aux, const float* gmu,
+                     const float* gsigma, int use_covar, float* dlogits, void* stream);
+
+/* Gaussian NLL of dsnt_al.py:64-74 and skew-normal NLL of bivariateskewnormal.py:36-61 (closed-form 2x2 algebra,
+ * Sigma^-1/2 = ((Sigma + sqrt(det) I)/sqrt(tr + 2 sqrt(det)))^-1 instead of distributions/utils.py:100-129's eig).
+ * y [M][2]; alpha [M][2] or NULL (gauss).  logs[8] = {loss, distance_loss, term1, term2, term3, alpha_norm, 0, 0}
+ * (means over M).  Gradients of `loss` (already divided by M): gmu [M][2], gsigma [M][3], galpha [M][2]. */
+int cu_nll_fwd_bwd(int M, int skew, float w_mse, float w_log, const float* mu, const float* sigma, const float* y,
+                   const float* alpha, float* logs, float* gmu, float* gsigma, float* galpha, void* stream);
+
+/* ConfidenceNet Linear (unet2.py:28-29): x [N][IN] f32, w [OUT][IN], out [N][OUT]; and its backward. */
+int cu_linear_fwd(int N, int IN, int OUT, const float* x, const float* w, const float* b, float* out, void* stream);
+int cu_linear_bwd(int N, int IN, int OUT, const float* x, const float* w, const float* gout, float* gx, float* gw,
+                  float* gb, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Parameters: f32 master weights live in one flat buffer; kernels read per-step bf16/f32 "operand copies".
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* master weight in the reference's logical layout, element (t, co, ci) at co*s_co + ci*s_ci + t (Conv2d OIHW: s_co =
+ * CI*T, s_ci = T; ConvTranspose2d IOHW: s_co = T, s_ci = CO*T) -> fwd operand [T][COP][CI] and dgrad operand
+ * [T][CI][COP] (dtype), rows co >= CO zero-filled; either output may be NULL. */
+int cu_weight_prep(int dtype, int T, int CO, int CI, int COP, long s_co, long s_ci, const float* master, void* w_fwd,
+                   void* w_dgrad, void* stream);
+/* kernel-layout gradient dWk [T][COP][CI] f32 (what cu_conv_wgrad accumulates) -> logical-layout gradient */
+int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_ci, const float* dwk, float* grad, int accumulate,
+                   void* stream);
+/* torch.optim.Adam(lr, betas, eps, weight_decay) semantics (vital/vital/config/task/optim/adam.yaml:1-4):
+ * g += wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps). */
+int cu_adam_step(size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONTOUR_HIP_H */

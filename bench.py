@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""Headline benchmark: train images/sec of task=dsnt-skew, 256x256x1 input, K=21, bf16 compute, fused Adam, on N GPUs.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one full training step of the hot path (U-Net forward, skew head, DSNT head + skew-normal NLL, hand-written
+backward, RCCL gradient all-reduce for N > 1, fused Adam) on one synthetic minibatch already resident in HBM.
+Per-GPU batch is fixed (64, BASELINE.json configs[2] / configs[3] = 512 over 8 GPUs), so scaling is "weak".
+
+Prints ONE JSON line on rank 0 with the driver's contract plus:
+  roofline     : the dominant kernel family (MFMA implicit-GEMM convolution), algorithmic FLOPs / measured launch time
+                 (HIP events on the launch stream, in a separate profiled pass after the timed region) vs 2.5 PFLOP/s.
+  cpu_baseline : the CPU oracle (PyTorch-CPU restatement of the reference step, kind "port") timed on this box's host
+                 cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "contouring-uncertainty_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_DENSE = 2.5e15     # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
+PEAK_HBM = 8.0e12
+
+
+def build_task(size: int, dtype: str, task_name: str):
+    from contour_uncertainty._compat import DataParameters
+    from contour_uncertainty.task.regression.dsnt.dsnt_al import DSNTAleatoric
+    from contour_uncertainty.task.regression.dsnt.dsnt_skew import DSNTSkew
+    n_stages = 8 if size >= 256 else 6
+    model_cfg = {"_target_": "contour_uncertainty.models.nnUnet.unet2.UNet", "kernels": [[3, 3]] * n_stages,
+                 "strides": [[1, 1]] + [[2, 2]] * (n_stages - 1), "patch_size": [256, 256], "drop_block": False,
+                 "deep_supervision": False, "compute_dtype": dtype}
+    cls = DSNTSkew if task_name == "dsnt-skew" else DSNTAleatoric
+    torch.manual_seed(0)
+    task = cls(model=model_cfg, optim={"_target_": "torch.optim.Adam", "lr": 1e-3, "weight_decay": 1e-3}, choices={},
+               data_params=DataParameters((1, size, size), (21, 2), [0, 1]), psm_path="camus-cont_psm_11_no_std.npy",
+               seq_psm_path="camus-cont_sequence_psm_11_no_std.npy", t_a=25, t_e=1, covar=True)
+    return task, n_stages
+
+
+def conv_flops_per_image(n_stages: int, size: int):
+    """Algorithmic conv FLOPs of one training step per image: fwd + dgrad + wgrad,
+    no dgrad for the first conv."""
+    from oracle.unet import UNetSpec, conv_macs_per_image
+    spec = UNetSpec(strides=tuple([1] + [2] * (n_stages - 1)))
+    m = conv_macs_per_image(spec, size)
+    return 2.0 * (3.0 * m["fwd"] - m["first_conv"]), 2.0 * m["fwd"]
+
+
+def cpu_baseline(size: int, n_stages: int, task_name: str, batch: int, steps: int):
+    """The oracle's training step (op-for-op the reference on PyTorch-CPU) on the host cores."""
+    from oracle.step import OracleTask, synthetic_batch
+    from oracle.unet import UNetSpec
+    # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() would report the whole host
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("BENCH_CPU_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    spec = UNetSpec(strides=tuple([1] + [2] * (n_stages - 1)))
+    ot = OracleTask(spec, task=task_name, seed=0)
+    img, contour = synthetic_batch(batch, size, 21, seed=1234)
+    ot.train_step(img, contour)                      # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ot.train_step(img, contour)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{steps} steps of batch {batch} at {size}x{size}, fp32, oracle/step.py"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU minibatch")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--task", default="dsnt-skew", choices=["dsnt-skew", "dsnt-al", "dsnt-al2"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"launched {world} ranks for --gpus {args.gpus}"
+
+    from cu_hip import ops
+    from cu_hip.ddp import GradSync
+    from oracle.step import synthetic_batch   # input generator only (SURVEY 8d synthetic inputs)
+
+    task_name = "dsnt-al" if args.task == "dsnt-al2" else args.task
+    task, n_stages = build_task(args.size, args.dtype, task_name)
+    task = task.to(dev)
+    sync = GradSync(task)
+    sync.broadcast_parameters()
+    opt = task.configure_optimizers()["optimizer"]
+    img, contour = synthetic_batch(args.batch, args.size, 21, seed=1234 + rank)
+    batch = {"img": img.to(dev), "contour": contour.to(dev)}
+
+    def step(i):
+        opt.zero_grad(set_to_none=True)
+        out = task.training_step(batch, i)
+        out["loss"].backward()
+        sync.finish()
+        opt.step(grad_scale=sync.grad_scale)
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = step(i)
+    fence()
+    if rank == 0:
+        print(f"[bench] warm-up done, timing {args.steps} steps ...", file=sys.stderr, flush=True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    loss = float(out["loss"])
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+
+    result = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = args.batch * world * args.steps / dt
+        flops_step_img, _ = conv_flops_per_image(n_stages, args.size)
+        result = {
+            "metric": "train images/sec, dsnt-skew 256x256 bf16" if (args.task == "dsnt-skew" and args.size == 256)
+            else f"train images/sec, {args.task} {args.size}x{args.size} {args.dtype}",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"task={args.task} {args.size}x{args.size}x1, K=21, {n_stages}-stage unet2, "
+                                   f"batch {args.batch}/GPU, Adam(lr=1e-3, wd=1e-3)",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}", "final_loss": round(loss, 4),
+                       "mfma_roofline_frac_whole_step": round(value / world * flops_step_img / PEAK_BF16_DENSE, 4)},
+        }
+
+    # ---- roofline of the dominant kernel family: separate profiled pass (events around every launch)
+    if rank == 0 and not args.no_roofline:
+        ops.PROFILE.clear()
+        ops.PROFILE_ON[0] = True
+        for i in range(2):
+            step(i)
+        torch.cuda.synchronize()
+        ops.PROFILE_ON[0] = False
+        fam = {}
+        for name, flops, e0, e1 in ops.PROFILE:
+            ms_k = e0.elapsed_time(e1)
+            f = fam.setdefault(name, [0.0, 0.0, 0])
+            f[0] += flops
+            f[1] += ms_k
+            f[2] += 1
+        total_ms = sum(v[1] for v in fam.values())
+        dom = max(fam.items(), key=lambda kv: kv[1][1])
+        name, (fl, ms_k, cnt) = dom
+        achieved = fl / (ms_k * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
+                              "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
+                              "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": None,
+                              "launches_per_step": cnt // 2, "avg_launch_ms": round(ms_k / cnt, 4),
+                              "flops_per_launch": fl / cnt,
+                              "family_ms_per_step": {k: round(v[1] / 2, 3) for k, v in fam.items()},
+                              "family_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 2) for k, v in fam.items()
+                                                if v[1] > 0},
+                              "profiled_ms_per_step": round(total_ms / 2, 3)}
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        print("[bench] timing the CPU oracle baseline ...", file=sys.stderr, flush=True)
+        result["cpu_baseline"] = cpu_baseline(args.size, n_stages, task_name, 4 if args.size >= 256 else 8, 2)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,6 +113,8 @@ class _UNetFn(torch.autograd.Function):
             G[n] = flat[off:off + k].view(P[n].shape)
             off += k
         module.last_flat_grad = flat
+        if module.flat_grad_hook is not None:
+            module.flat_grad_hook(flat)
         module.engine.backward(P, G, ctx.ectx, dlogits, dfeats)
         ctx.ectx = None
         return (None, None) + tuple(G.get(n) for n in module._pnames)
@@ -188,6 +190,7 @@ class UNet(nn.Module):
         self._used_names = [n for n in self._pnames if not n.startswith("deep_supervision_heads")]
         self._flat = None
         self.last_flat_grad = None
+        self.flat_grad_hook = None     # called with the flat gradient buffer at the start of every backward (DDP)
 
     def initialize_weights(self, module: nn.Module) -> None:
         """Kaiming-normal(a=negative_slope) weights, zero conv biases (reference unet2.py:309-314)."""

@@ -1,0 +1,61 @@
+"""``contour_uncertainty.task.uncertainty.UncertaintyTask`` (reference task/uncertainty.py:27-150): boilerplate common
+to all uncertainty methods.  Only what the DSNT train/val/predict path uses is kept; MC-dropout patching, ensembling
+checkpoints and figure upload are host-side features outside the accelerated path."""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Union
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from contour_uncertainty._compat import SharedStepsTask, prefix
+from contour_uncertainty.utils.metrics import Dice
+
+
+class UncertaintyTask(SharedStepsTask):
+    def __init__(self, t_a: int = 1, t_e: int = 1, train_ensemble: bool = False, ensemble_ckpt=None, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.save_hyperparameters()
+        labels = getattr(self.hparams.data_params, "labels", None)
+        self.dice = Dice(labels=labels)
+        self.model = self.configure_model()
+        self.is_val_step = False
+        if ensemble_ckpt is not None:
+            raise NotImplementedError("checkpoint ensembling (reference uncertainty.py:55-70) is out of scope of the "
+                                      "accelerated path")
+        self.ensembling = False
+        if self.hparams.t_e > 1:
+            raise NotImplementedError("t_e > 1 keeps Dropout2d active at predict time (reference utils/mcdropout.py); "
+                                      "drop_block is not enabled on this path yet")
+
+    def forward(self, *args, **kwargs):  # noqa: D102
+        return self.model(*args, **kwargs)
+
+    def validation_step(self, *args, **kwargs) -> Dict[str, Tensor]:  # noqa: D102
+        self.is_val_step = True
+        result = prefix(self._shared_step(*args, **kwargs), "val/")
+        self.is_val_step = False
+        self.log_dict(result, **(self.hparams.get("val_log_kwargs") or {}))
+        self.log("val_loss", result["val/loss"], on_step=True, on_epoch=True, prog_bar=True, logger=False)
+        return result
+
+    def predict_step(self, batch: Any, batch_idx: int, dataloader_idx: int = 0):
+        raise NotImplementedError
+
+    @staticmethod
+    def sample_entropy(samples):
+        """reference uncertainty.py:107-133: entropy of the mean sample map (binary case when C == 1)."""
+        import scipy.stats
+        samples = torch.as_tensor(samples)
+        if samples.ndim == 5:
+            samples = samples.reshape(-1, *samples.shape[2:])
+        y_hat = samples.mean(0)
+        if samples.shape[1] == 1:
+            y_hat = torch.cat([y_hat, 1 - y_hat], dim=0)
+            base = 2
+        else:
+            base = samples.shape[1]
+        umap = scipy.stats.entropy(y_hat.cpu().numpy(), axis=0, base=base)
+        umap[~np.isfinite(umap)] = 0
+        return umap

@@ -248,43 +248,53 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
     a.ZH = d->ZH; a.ZW = d->ZW; a.ZC = d->ZC; a.ZS = d->ZS; a.CO = d->CO; a.ntaps = d->ntaps;
     a.slope0 = d->slope0; a.slope1 = d->slope1; a.splits = d->splits;
 
-    const int BM = (d->IS > 1 || d->ZS > 1) ? 64 : 128;   // stride-2 gathers have 4x the halo: halve the tile
-    a.tile_px = BM;
-    int tw = d->PW < 32 ? d->PW : 32;
-    if (tw > BM) tw = BM;
-    int th = BM / tw;
-    if (th > d->PH) th = d->PH;
-    int imgs = BM / (tw * th);
-    a.twl = ilog2_exact(tw); a.thl = ilog2_exact(th); a.iml = ilog2_exact(imgs);
-    CU_CHECK_ARG(a.twl >= 0 && a.thl >= 0 && a.iml >= 0 && d->PW % tw == 0 && d->PH % th == 0,
-                 "cu_conv_wgrad: loop grid %dx%d must be powers of two", d->PH, d->PW);
-    a.tiles_x = d->PW / tw; a.tiles_y = d->PH / th; a.igroups = cdiv(d->N, imgs);
-    a.ntiles = a.tiles_x * a.tiles_y * a.igroups;
+    const int CI_all = d->C0 + d->C1;
+    const bool wn = d->CO > 32, wc = CI_all > 32;
+    const int rows_b = d->dtype == CU_BF16 ? (wc ? 192 : 64) : (wc ? 64 : 32) * 4 + 16;
+    const int rowz_b = d->dtype == CU_BF16 ? (wn ? 192 : 64) : (wn ? 64 : 32) * 4 + 16;
+    const int kpix = d->dtype == CU_BF16 ? 16 : 2;
+    // loop-pixel tile: 128 pixels (64 for stride-2 gathers: 4x the halo), halved until both staged patches fit in LDS
+    int BM = (d->IS > 1 || d->ZS > 1) ? 64 : 128;
+    for (;; BM >>= 1) {
+        CU_CHECK_ARG(BM >= 16 && BM >= kpix, "cu_conv_wgrad: patches do not fit in LDS");
+        a.tile_px = BM;
+        int tw = d->PW < 32 ? d->PW : 32;
+        if (tw > BM) tw = BM;
+        int th = BM / tw;
+        if (th > d->PH) th = d->PH;
+        int imgs = BM / (tw * th);
+        a.twl = ilog2_exact(tw); a.thl = ilog2_exact(th); a.iml = ilog2_exact(imgs);
+        CU_CHECK_ARG(a.twl >= 0 && a.thl >= 0 && a.iml >= 0 && d->PW % tw == 0 && d->PH % th == 0,
+                     "cu_conv_wgrad: loop grid %dx%d must be powers of two", d->PH, d->PW);
+        a.tiles_x = d->PW / tw; a.tiles_y = d->PH / th; a.igroups = cdiv(d->N, imgs);
+        a.ntiles = a.tiles_x * a.tiles_y * a.igroups;
 
-    int ymin = 1 << 20, xmin = 1 << 20, ymax = -(1 << 20), xmax = -(1 << 20);
-    int zymin = 1 << 20, zxmin = 1 << 20, zymax = -(1 << 20), zxmax = -(1 << 20);
-    for (int t = 0; t < d->ntaps; ++t) {
-        ymin = d->tap_dy[t] < ymin ? d->tap_dy[t] : ymin; ymax = d->tap_dy[t] > ymax ? d->tap_dy[t] : ymax;
-        xmin = d->tap_dx[t] < xmin ? d->tap_dx[t] : xmin; xmax = d->tap_dx[t] > xmax ? d->tap_dx[t] : xmax;
-        zymin = d->tap_zy[t] < zymin ? d->tap_zy[t] : zymin; zymax = d->tap_zy[t] > zymax ? d->tap_zy[t] : zymax;
-        zxmin = d->tap_zx[t] < zxmin ? d->tap_zx[t] : zxmin; zxmax = d->tap_zx[t] > zxmax ? d->tap_zx[t] : zxmax;
-    }
-    a.sdymin = ymin; a.sdxmin = xmin;
-    a.SHH = (th - 1) * d->IS + (ymax - ymin) + 1; a.SHW = (tw - 1) * d->IS + (xmax - xmin) + 1;
-    a.s_halo = imgs * a.SHH * a.SHW;
-    a.zdymin = zymin; a.zdxmin = zxmin;
-    a.ZHH = (th - 1) * d->ZS + (zymax - zymin) + 1; a.ZHW = (tw - 1) * d->ZS + (zxmax - zxmin) + 1;
-    a.z_halo = imgs * a.ZHH * a.ZHW;
-    a.mg_shpi = (unsigned)((0x100000000ull + (unsigned)(a.SHH * a.SHW) - 1) / (unsigned)(a.SHH * a.SHW));
-    a.mg_shw = (unsigned)((0x100000000ull + (unsigned)a.SHW - 1) / (unsigned)a.SHW);
-    a.mg_zhpi = (unsigned)((0x100000000ull + (unsigned)(a.ZHH * a.ZHW) - 1) / (unsigned)(a.ZHH * a.ZHW));
-    a.mg_zhw = (unsigned)((0x100000000ull + (unsigned)a.ZHW - 1) / (unsigned)a.ZHW);
-    a.zsame = 1;
-    for (int t = 0; t < d->ntaps; ++t) {
-        a.s_off[t] = (d->tap_dy[t] - ymin) * a.SHW + (d->tap_dx[t] - xmin);
-        a.z_off[t] = (d->tap_zy[t] - zymin) * a.ZHW + (d->tap_zx[t] - zxmin);
-        a.tap_w[t] = d->tap_w[t];
-        if (a.z_off[t] != a.z_off[0]) a.zsame = 0;
+        int ymin = 1 << 20, xmin = 1 << 20, ymax = -(1 << 20), xmax = -(1 << 20);
+        int zymin = 1 << 20, zxmin = 1 << 20, zymax = -(1 << 20), zxmax = -(1 << 20);
+        for (int t = 0; t < d->ntaps; ++t) {
+            ymin = d->tap_dy[t] < ymin ? d->tap_dy[t] : ymin; ymax = d->tap_dy[t] > ymax ? d->tap_dy[t] : ymax;
+            xmin = d->tap_dx[t] < xmin ? d->tap_dx[t] : xmin; xmax = d->tap_dx[t] > xmax ? d->tap_dx[t] : xmax;
+            zymin = d->tap_zy[t] < zymin ? d->tap_zy[t] : zymin; zymax = d->tap_zy[t] > zymax ? d->tap_zy[t] : zymax;
+            zxmin = d->tap_zx[t] < zxmin ? d->tap_zx[t] : zxmin; zxmax = d->tap_zx[t] > zxmax ? d->tap_zx[t] : zxmax;
+        }
+        a.sdymin = ymin; a.sdxmin = xmin;
+        a.SHH = (th - 1) * d->IS + (ymax - ymin) + 1; a.SHW = (tw - 1) * d->IS + (xmax - xmin) + 1;
+        a.s_halo = imgs * a.SHH * a.SHW;
+        a.zdymin = zymin; a.zdxmin = zxmin;
+        a.ZHH = (th - 1) * d->ZS + (zymax - zymin) + 1; a.ZHW = (tw - 1) * d->ZS + (zxmax - zxmin) + 1;
+        a.z_halo = imgs * a.ZHH * a.ZHW;
+        a.mg_shpi = (unsigned)((0x100000000ull + (unsigned)(a.SHH * a.SHW) - 1) / (unsigned)(a.SHH * a.SHW));
+        a.mg_shw = (unsigned)((0x100000000ull + (unsigned)a.SHW - 1) / (unsigned)a.SHW);
+        a.mg_zhpi = (unsigned)((0x100000000ull + (unsigned)(a.ZHH * a.ZHW) - 1) / (unsigned)(a.ZHH * a.ZHW));
+        a.mg_zhw = (unsigned)((0x100000000ull + (unsigned)a.ZHW - 1) / (unsigned)a.ZHW);
+        a.zsame = 1;
+        for (int t = 0; t < d->ntaps; ++t) {
+            a.s_off[t] = (d->tap_dy[t] - ymin) * a.SHW + (d->tap_dx[t] - xmin);
+            a.z_off[t] = (d->tap_zy[t] - zymin) * a.ZHW + (d->tap_zx[t] - zxmin);
+            a.tap_w[t] = d->tap_w[t];
+            if (a.z_off[t] != a.z_off[0]) a.zsame = 0;
+        }
+        if ((size_t)a.s_halo * rows_b + (size_t)a.z_halo * rowz_b <= 150 * 1024) break;
     }
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -72,6 +72,7 @@ class UNetEngine:
         self._opcache: Dict[str, Tuple[int, int, Tensor, Tensor]] = {}
         # called with a parameter-name prefix each time that layer's gradients are final (DDP bucket trigger)
         self.grad_ready_hook: Optional[Callable[[str], None]] = None
+        self.debug: Optional[Dict[str, Tensor]] = None    # tests/tools: set to {} to capture per-layer gradients (NHWC)
 
     # ------------------------------------------------------------------------------------------ operand copies
     def _operands(self, name: str, w: Tensor, kind: str, cop: Optional[int] = None):
@@ -139,6 +140,8 @@ class UNetEngine:
         assert img.dtype == torch.float32 and img.is_cuda and img.shape[1] == 1
         img = img.contiguous()
         ctx = UNetCtx(img=img)
+        if self.debug is not None:
+            self._last_ctx = ctx
         st = self.strides
         assert st[0] == 1
         a = self._first_layer_fwd(P, ctx, "input_block.conv1", img)
@@ -176,8 +179,12 @@ class UNetEngine:
                         dsrc: Optional[List[Tuple[Tensor, int]]]):
         """g: dL/d(activated output), overwritten with dL/dz.  dsrc: [(tensor, accumulate)] per source or None."""
         rec = ctx.convs[prefix]
+        if self.debug is not None:
+            self.debug[f"{prefix}:da"] = g.float().clone()
         ops.instnorm_lrelu_bwd(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
                                G[f"{prefix}.norm.bias"], G[f"{prefix}.conv.bias"])
+        if self.debug is not None:
+            self.debug[f"{prefix}:dz"] = g.float().clone()
         w = P[f"{prefix}.conv.weight"]
         n, oh, ow, co = g.shape
         if rec.first:

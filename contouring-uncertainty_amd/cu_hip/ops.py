@@ -32,6 +32,35 @@ class Act:
         return None if self.stats is None else self.stats[3]
 
 
+# ---- optional per-launch timing (bench.py's roofline pass): HIP events on the launch stream around every kernel call
+import os as _os
+
+PROFILE_ON = [False]
+PROFILE: list = []          # (family, algorithmic flops, start event, end event)
+TRACE = bool(_os.environ.get("CU_TRACE"))    # debugging aid: synchronise and print after every kernel call
+
+
+class _Prof:
+    def __init__(self, family: str, flops: float = 0.0):
+        self.family, self.flops = family, flops
+
+    def __enter__(self):
+        if PROFILE_ON[0]:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE_ON[0]:
+            self.e1.record()
+            PROFILE.append((self.family, self.flops, self.e0, self.e1))
+        if TRACE:
+            torch.cuda.synchronize()
+            print(f"[cu_trace] {self.family} flops={self.flops:.3g}", flush=True)
+        return False
+
+
 def _taps(desc, dys, dxs, ws, zys=None, zxs=None):
     desc.ntaps = len(dys)
     for i, (a, b, c) in enumerate(zip(dys, dxs, ws)):
@@ -73,10 +102,12 @@ def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: T
     d.accum0, d.accum1 = int(accum[0]), int(accum[1]) if len(accum) > 1 else 0
     d.out_nchw_f32 = int(out_nchw)
     assert w.dtype == s0.z.dtype and w.shape[-1] == d.C0 + d.C1 and w.shape[-2] == d.CO, (w.shape, d.CO, d.C0, d.C1)
-    rc = lib.cu_conv_gemm(d, L.ptr(s0.z), L.ptr(s0.scale), L.ptr(s0.shift),
-                          L.ptr(s1.z) if s1 is not None else None, L.ptr(s1.scale) if s1 is not None else None,
-                          L.ptr(s1.shift) if s1 is not None else None, L.ptr(w), L.ptr(bias), L.ptr(dst0),
-                          L.ptr(dsts[1]) if len(dsts) > 1 else None, L.stream_ptr())
+    flops = 2.0 * d.N * d.PH * d.PW * d.ntaps * (d.C0 + d.C1) * (d.DC0 if out_nchw else d.CO)
+    with _Prof("igemm_conv", flops):
+        rc = lib.cu_conv_gemm(d, L.ptr(s0.z), L.ptr(s0.scale), L.ptr(s0.shift),
+                              L.ptr(s1.z) if s1 is not None else None, L.ptr(s1.scale) if s1 is not None else None,
+                              L.ptr(s1.shift) if s1 is not None else None, L.ptr(w), L.ptr(bias), L.ptr(dst0),
+                              L.ptr(dsts[1]) if len(dsts) > 1 else None, L.stream_ptr())
     L.check(rc, "cu_conv_gemm")
 
 
@@ -101,30 +132,35 @@ def conv_wgrad(srcs: Sequence[Act], z: Tensor, dwk: Tensor, *, grid: Tuple[int, 
     d.slope1 = s1.slope if s1 is not None else 1.0
     d.splits = splits
     assert dwk.dtype == torch.float32 and z.dtype == s0.z.dtype
-    rc = lib.cu_conv_wgrad(d, L.ptr(s0.z), L.ptr(s0.scale), L.ptr(s0.shift),
-                           L.ptr(s1.z) if s1 is not None else None, L.ptr(s1.scale) if s1 is not None else None,
-                           L.ptr(s1.shift) if s1 is not None else None, L.ptr(z), L.ptr(dwk), L.stream_ptr())
+    flops = 2.0 * d.N * d.PH * d.PW * d.ntaps * (d.C0 + d.C1) * d.CO
+    with _Prof("igemm_wgrad", flops):
+        rc = lib.cu_conv_wgrad(d, L.ptr(s0.z), L.ptr(s0.scale), L.ptr(s0.shift),
+                               L.ptr(s1.z) if s1 is not None else None, L.ptr(s1.scale) if s1 is not None else None,
+                               L.ptr(s1.shift) if s1 is not None else None, L.ptr(z), L.ptr(dwk), L.stream_ptr())
     L.check(rc, "cu_conv_wgrad")
 
 
 def conv_c1_fwd(img: Tensor, w9: Tensor, bias: Optional[Tensor], dst: Tensor):
     n, h, w_, co = dst.shape
-    L.check(L.load().cu_conv_c1_fwd(L.dtype_code(dst.dtype), n, h, w_, co, L.ptr(img), L.ptr(w9), L.ptr(bias),
-                                    L.ptr(dst), L.stream_ptr()), "cu_conv_c1_fwd")
+    with _Prof("conv_c1"):
+        L.check(L.load().cu_conv_c1_fwd(L.dtype_code(dst.dtype), n, h, w_, co, L.ptr(img), L.ptr(w9), L.ptr(bias),
+                                        L.ptr(dst), L.stream_ptr()), "cu_conv_c1_fwd")
 
 
 def conv_c1_wgrad(img: Tensor, dz: Tensor, dw9: Tensor):
     n, h, w_, co = dz.shape
-    L.check(L.load().cu_conv_c1_wgrad(L.dtype_code(dz.dtype), n, h, w_, co, L.ptr(img), L.ptr(dz), L.ptr(dw9),
-                                      L.stream_ptr()), "cu_conv_c1_wgrad")
+    with _Prof("conv_c1"):
+        L.check(L.load().cu_conv_c1_wgrad(L.dtype_code(dz.dtype), n, h, w_, co, L.ptr(img), L.ptr(dz), L.ptr(dw9),
+                                          L.stream_ptr()), "cu_conv_c1_wgrad")
 
 
 def instnorm_stats(z: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float = 1e-5) -> Tensor:
     n, h, w_, c = z.shape
     stats = torch.empty((4, n, c), dtype=torch.float32, device=z.device)
     ws = torch.empty((n, c, 2), dtype=torch.float32, device=z.device)
-    L.check(L.load().cu_instnorm_stats(L.dtype_code(z.dtype), n, h * w_, c, L.ptr(z), L.ptr(gamma), L.ptr(beta), eps,
-                                       L.ptr(stats), L.ptr(ws), L.stream_ptr()), "cu_instnorm_stats")
+    with _Prof("instnorm_stats"):
+        L.check(L.load().cu_instnorm_stats(L.dtype_code(z.dtype), n, h * w_, c, L.ptr(z), L.ptr(gamma), L.ptr(beta), eps,
+                                           L.ptr(stats), L.ptr(ws), L.stream_ptr()), "cu_instnorm_stats")
     return stats
 
 
@@ -132,22 +168,25 @@ def instnorm_lrelu_bwd(g: Tensor, act: Act, gamma: Optional[Tensor], dgamma, dbe
     """In place: g (dL/d activated) -> dL/dz."""
     n, h, w_, c = g.shape
     ws = torch.empty((n, c, 2), dtype=torch.float32, device=g.device)
-    L.check(L.load().cu_instnorm_lrelu_bwd(L.dtype_code(g.dtype), n, h * w_, c, L.ptr(g), L.ptr(act.z),
-                                           L.ptr(act.stats), L.ptr(gamma), act.slope, L.ptr(dgamma), L.ptr(dbeta),
-                                           L.ptr(dbias), L.ptr(ws), L.stream_ptr()), "cu_instnorm_lrelu_bwd")
+    with _Prof("instnorm_bwd"):
+        L.check(L.load().cu_instnorm_lrelu_bwd(L.dtype_code(g.dtype), n, h * w_, c, L.ptr(g), L.ptr(act.z),
+                                               L.ptr(act.stats), L.ptr(gamma), act.slope, L.ptr(dgamma), L.ptr(dbeta),
+                                               L.ptr(dbias), L.ptr(ws), L.stream_ptr()), "cu_instnorm_lrelu_bwd")
 
 
 def act_bwd(g: Tensor, z: Tensor, slope: float, dbias):
     n, h, w_, c = g.shape
-    L.check(L.load().cu_act_bwd(L.dtype_code(g.dtype), n, h * w_, c, L.ptr(g), L.ptr(z), slope, L.ptr(dbias),
-                                L.stream_ptr()), "cu_act_bwd")
+    with _Prof("small"):
+        L.check(L.load().cu_act_bwd(L.dtype_code(g.dtype), n, h * w_, c, L.ptr(g), L.ptr(z), slope, L.ptr(dbias),
+                                    L.stream_ptr()), "cu_act_bwd")
 
 
 def act_to_nchw_f32(act: Act) -> Tensor:
     n, h, w_, c = act.z.shape
     out = torch.empty((n, c, h, w_), dtype=torch.float32, device=act.z.device)
-    L.check(L.load().cu_act_to_nchw_f32(L.dtype_code(act.z.dtype), n, h * w_, c, L.ptr(act.z), L.ptr(act.stats),
-                                        act.slope, L.ptr(out), L.stream_ptr()), "cu_act_to_nchw_f32")
+    with _Prof("small"):
+        L.check(L.load().cu_act_to_nchw_f32(L.dtype_code(act.z.dtype), n, h * w_, c, L.ptr(act.z), L.ptr(act.stats),
+                                            act.slope, L.ptr(out), L.stream_ptr()), "cu_act_to_nchw_f32")
     return out
 
 
@@ -155,8 +194,9 @@ def nchw_f32_to_nhwc(x: Tensor, dtype: torch.dtype, cp: Optional[int] = None) ->
     n, c, h, w_ = x.shape
     cp = cp or c
     out = torch.empty((n, h, w_, cp), dtype=dtype, device=x.device)
-    L.check(L.load().cu_nchw_f32_to_nhwc(L.dtype_code(dtype), n, h * w_, c, cp, L.ptr(x), L.ptr(out), L.stream_ptr()),
-            "cu_nchw_f32_to_nhwc")
+    with _Prof("layout"):
+        L.check(L.load().cu_nchw_f32_to_nhwc(L.dtype_code(dtype), n, h * w_, c, cp, L.ptr(x), L.ptr(out), L.stream_ptr()),
+                "cu_nchw_f32_to_nhwc")
     return out
 
 
@@ -164,8 +204,9 @@ def nhwc_to_nchw_f32(x: Tensor, out: Optional[Tensor] = None, accumulate: bool =
     n, h, w_, c = x.shape
     if out is None:
         out = torch.empty((n, c, h, w_), dtype=torch.float32, device=x.device)
-    L.check(L.load().cu_nhwc_to_nchw_f32(L.dtype_code(x.dtype), n, h * w_, c, L.ptr(x), L.ptr(out), int(accumulate),
-                                         L.stream_ptr()), "cu_nhwc_to_nchw_f32")
+    with _Prof("small"):
+        L.check(L.load().cu_nhwc_to_nchw_f32(L.dtype_code(x.dtype), n, h * w_, c, L.ptr(x), L.ptr(out), int(accumulate),
+                                             L.stream_ptr()), "cu_nhwc_to_nchw_f32")
     return out
 
 
@@ -175,16 +216,18 @@ def dsnt_head_fwd(logits: Tensor, use_covar: bool = True):
     mu = torch.empty((n, k, 2), dtype=torch.float32, device=dev)
     sigma = torch.empty((n, k, 3), dtype=torch.float32, device=dev)
     aux = torch.empty((n, k, 8), dtype=torch.float32, device=dev)
-    L.check(L.load().cu_dsnt_head_fwd(n * k, h, w_, L.ptr(logits), int(use_covar), L.ptr(mu), L.ptr(sigma),
-                                      L.ptr(aux), L.stream_ptr()), "cu_dsnt_head_fwd")
+    with _Prof("dsnt_head"):
+        L.check(L.load().cu_dsnt_head_fwd(n * k, h, w_, L.ptr(logits), int(use_covar), L.ptr(mu), L.ptr(sigma),
+                                          L.ptr(aux), L.stream_ptr()), "cu_dsnt_head_fwd")
     return mu, sigma, aux
 
 
 def dsnt_head_bwd(logits: Tensor, aux: Tensor, gmu: Tensor, gsigma: Tensor, use_covar: bool = True) -> Tensor:
     n, k, h, w_ = logits.shape
     dl = torch.empty_like(logits)
-    L.check(L.load().cu_dsnt_head_bwd(n * k, h, w_, L.ptr(logits), L.ptr(aux), L.ptr(gmu), L.ptr(gsigma),
-                                      int(use_covar), L.ptr(dl), L.stream_ptr()), "cu_dsnt_head_bwd")
+    with _Prof("dsnt_head"):
+        L.check(L.load().cu_dsnt_head_bwd(n * k, h, w_, L.ptr(logits), L.ptr(aux), L.ptr(gmu), L.ptr(gsigma),
+                                          int(use_covar), L.ptr(dl), L.stream_ptr()), "cu_dsnt_head_bwd")
     return dl
 
 
@@ -196,9 +239,10 @@ def nll_fwd_bwd(mu: Tensor, sigma: Tensor, y: Tensor, alpha: Optional[Tensor], w
     gmu = torch.empty_like(mu) if need_grad else None
     gsigma = torch.empty_like(sigma) if need_grad else None
     galpha = torch.empty_like(alpha) if (need_grad and alpha is not None) else None
-    L.check(L.load().cu_nll_fwd_bwd(m, int(alpha is not None), w_mse, w_log, L.ptr(mu), L.ptr(sigma), L.ptr(y),
-                                    L.ptr(alpha), L.ptr(logs), L.ptr(gmu), L.ptr(gsigma), L.ptr(galpha),
-                                    L.stream_ptr()), "cu_nll_fwd_bwd")
+    with _Prof("small"):
+        L.check(L.load().cu_nll_fwd_bwd(m, int(alpha is not None), w_mse, w_log, L.ptr(mu), L.ptr(sigma), L.ptr(y),
+                                        L.ptr(alpha), L.ptr(logs), L.ptr(gmu), L.ptr(gsigma), L.ptr(galpha),
+                                        L.stream_ptr()), "cu_nll_fwd_bwd")
     return logs, gmu, gsigma, galpha
 
 
@@ -206,7 +250,8 @@ def linear_fwd(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
     n, i = x.shape
     o = w.shape[0]
     out = torch.empty((n, o), dtype=torch.float32, device=x.device)
-    L.check(L.load().cu_linear_fwd(n, i, o, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(out), L.stream_ptr()), "cu_linear_fwd")
+    with _Prof("small"):
+        L.check(L.load().cu_linear_fwd(n, i, o, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(out), L.stream_ptr()), "cu_linear_fwd")
     return out
 
 
@@ -214,8 +259,9 @@ def linear_bwd(x: Tensor, w: Tensor, gout: Tensor, gw: Optional[Tensor], gb: Opt
     n, i = x.shape
     o = w.shape[0]
     gx = torch.empty_like(x) if need_gx else None
-    L.check(L.load().cu_linear_bwd(n, i, o, L.ptr(x), L.ptr(w), L.ptr(gout), L.ptr(gx), L.ptr(gw), L.ptr(gb),
-                                   L.stream_ptr()), "cu_linear_bwd")
+    with _Prof("small"):
+        L.check(L.load().cu_linear_bwd(n, i, o, L.ptr(x), L.ptr(w), L.ptr(gout), L.ptr(gx), L.ptr(gw), L.ptr(gb),
+                                       L.stream_ptr()), "cu_linear_bwd")
     return gx
 
 
@@ -237,8 +283,9 @@ def weight_prep(master: Tensor, kind: str, dtype: torch.dtype, cop: Optional[int
     dev = master.device
     wf = torch.empty((t, cop, ci), dtype=dtype, device=dev) if want_fwd else None
     wd = torch.empty((t, ci, cop), dtype=dtype, device=dev) if want_dgrad else None
-    L.check(L.load().cu_weight_prep(L.dtype_code(dtype), t, co, ci, cop, s_co, s_ci, L.ptr(master), L.ptr(wf),
-                                    L.ptr(wd), L.stream_ptr()), "cu_weight_prep")
+    with _Prof("weight_prep"):
+        L.check(L.load().cu_weight_prep(L.dtype_code(dtype), t, co, ci, cop, s_co, s_ci, L.ptr(master), L.ptr(wf),
+                                        L.ptr(wd), L.stream_ptr()), "cu_weight_prep")
     return wf, wd
 
 
@@ -252,8 +299,9 @@ def grad_unprep(dwk: Tensor, grad: Tensor, kind: str, accumulate: bool = False):
         t = kh * kw
         s_co, s_ci = t, co * t
     cop = dwk.shape[1]
-    L.check(L.load().cu_grad_unprep(t, co, ci, cop, s_co, s_ci, L.ptr(dwk), L.ptr(grad), int(accumulate),
-                                    L.stream_ptr()), "cu_grad_unprep")
+    with _Prof("weight_prep"):
+        L.check(L.load().cu_grad_unprep(t, co, ci, cop, s_co, s_ci, L.ptr(dwk), L.ptr(grad), int(accumulate),
+                                        L.stream_ptr()), "cu_grad_unprep")
 
 
 # Raw-pointer kernels do not bump tensor._version: operand caches key on this epoch as well.
@@ -263,5 +311,6 @@ PARAM_EPOCH = [0]
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, beta2: float, eps: float,
               weight_decay: float, step: int, grad_scale: float = 1.0):
     PARAM_EPOCH[0] += 1
-    L.check(L.load().cu_adam_step(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), lr, beta1, beta2, eps,
-                                  weight_decay, step, grad_scale, L.stream_ptr()), "cu_adam_step")
+    with _Prof("adam"):
+        L.check(L.load().cu_adam_step(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), lr, beta1, beta2, eps,
+                                      weight_decay, step, grad_scale, L.stream_ptr()), "cu_adam_step")

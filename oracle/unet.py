@@ -131,31 +131,37 @@ def init_confidence_state(output_size: int, generator: Optional[torch.Generator]
 
 
 # --------------------------------------------------------------------------- forward
-def conv_layer(sd, prefix: str, x: Tensor, stride: int, spec: UNetSpec, drop_mask: Optional[Tensor] = None) -> Tensor:
+def conv_layer(sd, prefix: str, x: Tensor, stride: int, spec: UNetSpec, drop_mask: Optional[Tensor] = None,
+               taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """layers.py:199-205: conv(3x3, pad 1, bias) -> [dropout2d] -> InstanceNorm2d(affine) -> LeakyReLU."""
     y = F.conv2d(x, sd[f"{prefix}.conv.weight"], sd[f"{prefix}.conv.bias"], stride=stride, padding=1)
     if drop_mask is not None:          # Dropout2d(p=.5): whole channels zeroed, survivors x2 (layers.py:154-164)
         y = y * drop_mask
+    if taps is not None:
+        taps[f"{prefix}:z"] = y
     y = F.instance_norm(y, weight=sd[f"{prefix}.norm.weight"], bias=sd[f"{prefix}.norm.bias"], eps=spec.eps)
-    return F.leaky_relu(y, spec.negative_slope)
+    y = F.leaky_relu(y, spec.negative_slope)
+    if taps is not None:
+        taps[f"{prefix}:a"] = y
+    return y
 
 
-def conv_block(sd, prefix: str, x: Tensor, stride: int, spec: UNetSpec) -> Tensor:
+def conv_block(sd, prefix: str, x: Tensor, stride: int, spec: UNetSpec, taps=None) -> Tensor:
     """layers.py:208-238: two ConvLayers, the first carries the stage stride."""
-    y = conv_layer(sd, f"{prefix}.conv1", x, stride, spec)
-    return conv_layer(sd, f"{prefix}.conv2", y, 1, spec)
+    y = conv_layer(sd, f"{prefix}.conv1", x, stride, spec, taps=taps)
+    return conv_layer(sd, f"{prefix}.conv2", y, 1, spec, taps=taps)
 
 
 def unet_forward(sd: Dict[str, Tensor], x: Tensor, spec: UNetSpec, bottleneck_out: bool = False,
                  taps: Optional[Dict[str, Tensor]] = None):
     """unet2.py:177-208 (deep supervision / ssn branches are off for the dsnt tasks)."""
-    out = conv_block(sd, "input_block", x, spec.strides[0], spec)
+    out = conv_block(sd, "input_block", x, spec.strides[0], spec, taps)
     enc = [out]
     nd = spec.n_stages - 2
     for i in range(nd):
-        out = conv_block(sd, f"downsamples.{i}", out, spec.strides[i + 1], spec)
+        out = conv_block(sd, f"downsamples.{i}", out, spec.strides[i + 1], spec, taps)
         enc.append(out)
-    out = conv_block(sd, "bottleneck", out, spec.strides[-1], spec)
+    out = conv_block(sd, "bottleneck", out, spec.strides[-1], spec, taps)
     bott = out.clone()
     if taps is not None:
         taps["bottleneck"] = bott
@@ -164,7 +170,7 @@ def unet_forward(sd: Dict[str, Tensor], x: Tensor, spec: UNetSpec, bottleneck_ou
         s = up_strides[i]
         out = F.conv_transpose2d(out, sd[f"upsamples.{i}.transp_conv.weight"], None, stride=s)   # layers.py:415-417
         out = torch.cat((out, skip), dim=1)                                                        # layers.py:436
-        out = conv_block(sd, f"upsamples.{i}.conv_block", out, 1, spec)
+        out = conv_block(sd, f"upsamples.{i}.conv_block", out, 1, spec, taps)
         if taps is not None:
             taps[f"upsamples.{i}"] = out
     out = F.conv2d(out, sd["output_block.conv.weight"], None)                                      # layers.py:456-463

@@ -15,11 +15,13 @@
 //     im2col);
 //   - the next chunk's global loads are issued before the current chunk's MFMAs (register prefetch);
 //   - bf16: v_mfma_f32_32x32x16_bf16; f32 (parity mode): v_mfma_f32_32x32x2_f32 (exact f32 FMA chain).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
-constexpr int MAXI = 10;   // halo pieces per thread per chunk (host checks halo_px*4 <= 256*MAXI)
+constexpr int MAXI = 10;   // largest NX instantiated: halo pieces per thread per chunk (halo_px*4 <= 256*MAXI)
 
 struct ConvKArgs {
     const void* src0; const void* src1;
@@ -33,7 +35,10 @@ struct ConvKArgs {
     int tiles_x, tiles_y;
     float slope0, slope1;
     int accum0, accum1, out_nchw;
-    int imgs;                   // images per tile (TW*TH*imgs <= 128; rows beyond are idle)
+    int imgs;                   // images per tile (TW*TH*imgs <= 128*MA; rows beyond are idle)
+    int txl, tyl, ntiles;       // log2 of tiles per row / column, total pixel tiles
+    int tap_lds;                // byte offset of the tap table inside the dynamic LDS
+    int dbg;                    // CU_CONV_DBG bits (timing experiments only): 1 no stores, 2 no MFMA, 4 no commit, 8 no loads
 };
 
 template <typename T> struct Cfg;
@@ -52,98 +57,171 @@ template <> struct Cfg<float> {
     static constexpr int WPLANES = 16;
 };
 
-template <typename T, int MA, int NB>
+// Template parameters
+//   MA   : 32-pixel MFMA blocks per wave (tile = 128*MA loop pixels)
+//   NB   : 32-column MFMA blocks per workgroup (all waves share the columns)
+//   NX   : halo pieces per thread per chunk, NT : tap capacity.  Both compile-time so that every global load of the
+//          staging is UNCONDITIONAL (clamped address, value masked later): hipcc serialises predicated loads with a
+//          vmcnt(0) each (cdna_hip_programming.md, "three .s-level traps" (c)).
+//   WRES : the whole weight slice (all chunks, all taps) of this column tile stays resident in LDS; the workgroup is
+//          persistent over pixel tiles, so thin layers (C <= 64 at 256^2/128^2) stage their weights once per CU.
+// The MFMA is issued with the WEIGHTS as the A operand and the PIXELS as the B operand: D[row = column n][col = pixel],
+// so a lane owns one pixel and 4 consecutive output channels per register quad -> 8/16-byte epilogue stores.
+//   PLAIN: the sources need no affine / activation (materialised activations): staging is a pure 16-byte copy.
+template <typename T, int MA, int NB, int NX, int NT, bool WRES, bool PLAIN>
 __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvKArgs p) {
     using C = Cfg<T>;
-    constexpr int CK = C::CK, PIECE = C::PIECE, PPP = C::PPP;
+    constexpr int CK = C::CK, PIECE = C::PIECE, PPP = C::PPP, WPL = C::WPLANES;
     constexpr int BN = 32 * NB;
+    constexpr int NW = (NT * BN * 4 + 255) / 256;     // weight pieces per thread per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int TW = 1 << p.twl, TH = 1 << p.thl;
-
-    int bx = blockIdx.x;
-    const int tile_x = bx % p.tiles_x; bx /= p.tiles_x;
-    const int tile_y = bx % p.tiles_y;
-    const int ig = bx / p.tiles_y;
-    const int py0 = tile_y << p.thl, px0 = tile_x << p.twl, img0 = ig << p.iml;
     const int n0 = blockIdx.y * BN;
     const int CI = p.C0 + p.C1;
-    const int sy0 = py0 * p.IS + p.dymin, sx0 = px0 * p.IS + p.dxmin;
     const int hpi = p.HH * p.HW;   // halo pixels per image
+    const int piece = tid & 3;     // 256 % 4 == 0: a thread always stages the same 16-byte piece of a pixel / weight row
 
     // LDS carve: X planes then W planes.  Units: 16-byte entries (bf16) / floats (f32).
     T* Xs = reinterpret_cast<T*>(smem);
     const int x_elems = (CK / PIECE) * PPP * p.XP * (PPP == 1 ? PIECE : 1);
     T* Ws = Xs + x_elems;
-
-    // ---- per-thread halo staging items (independent of the chunk)
-    int pix[MAXI], nimg[MAXI], ldsx[MAXI];
+    const int w_chunk_units = p.ntaps * WPL * p.WP;          // 16-byte entries (bf16) / floats (f32) per chunk
+    // Tap tables go to LDS through STATIC indices: a runtime index into the by-value kernel argument would force the
+    // whole argument struct into scratch memory (every p.field access then becomes a scratch load).
+    int* s_tap = reinterpret_cast<int*>(smem + p.tap_lds);
 #pragma unroll
-    for (int j = 0; j < MAXI; ++j) {
+    for (int t = 0; t < CU_MAX_TAPS; ++t)
+        if (tid == t) { s_tap[t] = p.tap_off[t]; s_tap[16 + t] = p.tap_w[t]; }
+    __syncthreads();
+
+    // ---- tile-invariant halo staging geometry: (image, row, col) inside the halo patch
+    int geo[NX], ldsx[NX];
+    unsigned exist = 0;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
         const int i = tid + j * 256;
-        pix[j] = -2; nimg[j] = 0; ldsx[j] = 0;
-        if (i < p.halo_px * 4) {
-            const int piece = i & 3, hp = i >> 2;
-            const int im = hp / hpi;
-            const int rem = hp - im * hpi;
-            const int hy = rem / p.HW, hx = rem - hy * p.HW;
-            const int n = img0 + im, sy = sy0 + hy, sx = sx0 + hx;
-            const bool inb = (n < p.N) && (sy >= 0) && (sy < p.SH) && (sx >= 0) && (sx < p.SW);
-            pix[j] = inb ? (n * p.SH + sy) * p.SW + sx : -1;
-            nimg[j] = n;
-            ldsx[j] = piece * PPP * p.XP + hp;
+        const bool ex = i < p.halo_px * 4;
+        const int hp = ex ? (i >> 2) : 0;
+        const int im = hp / hpi;
+        const int rem = hp - im * hpi;
+        const int hy = rem / p.HW, hx = rem - hy * p.HW;
+        geo[j] = (im << 20) | (hy << 10) | hx;
+        ldsx[j] = piece * PPP * p.XP + hp;
+        exist |= (ex ? 1u : 0u) << j;
+    }
+    // ---- weight staging items
+    int wbase[NW], wlds[NW];
+    unsigned wexist = 0, wvalid = 0;
+    const int w_items = p.ntaps * BN * 4;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int i = tid + j * 256;
+        const bool ex = i < w_items;
+        const int col = (i >> 2) % BN;
+        int t = (i >> 2) / BN;
+        t = t < p.ntaps ? t : 0;
+        const int n = n0 + col;
+        const bool ok = ex && n < p.CO;
+        wbase[j] = (s_tap[16 + t] * p.CO + (ok ? n : 0)) * CI + piece * PIECE;
+        wlds[j] = (PPP == 1) ? (t * 4 + piece) * p.WP + col : (t * 16 + piece * 4) * p.WP + col;
+        wexist |= (ex ? 1u : 0u) << j;
+        wvalid |= (ok ? 1u : 0u) << j;
+    }
+    auto store_w = [&](const u32x4 (&wreg)[NW], int unit_off) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            if ((wexist >> j) & 1u) {
+                u32x4 v = wreg[j];
+                if (!((wvalid >> j) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
+                if constexpr (PIECE == 8) {
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(Ws) + (size_t)(unit_off + wlds[j]) * 8) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        reinterpret_cast<float*>(Ws)[unit_off + wlds[j] + e * p.WP] = __uint_as_float(v[e]);
+                }
+            }
+        }
+    };
+    if constexpr (WRES) {   // one-time staging of the whole weight slice
+        for (int c0 = 0, ci = 0; c0 < CI; c0 += CK, ++ci) {
+            u32x4 wreg[NW];
+            const T* wp = reinterpret_cast<const T*>(p.w) + c0;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) wreg[j] = *reinterpret_cast<const u32x4*>(wp + wbase[j]);
+            store_w(wreg, ci * w_chunk_units);
         }
     }
 
-    // ---- A-fragment base halo index per M block
-    int hpA[MA];
+    // ---- tile-invariant fragment geometry: this lane's pixel in each of its MA blocks
+    int hpA[MA], ptx[MA], pty[MA], pim[MA];
 #pragma unroll
     for (int a = 0; a < MA; ++a) {
         const int m = wave * 32 * MA + a * 32 + r;
-        const int tx = m & (TW - 1), ty = (m >> p.twl) & (TH - 1), im = m >> (p.twl + p.thl);
-        hpA[a] = im < p.imgs ? im * hpi + ty * p.IS * p.HW + tx * p.IS : 0;
+        ptx[a] = m & (TW - 1); pty[a] = (m >> p.twl) & (TH - 1); pim[a] = m >> (p.twl + p.thl);
+        hpA[a] = pim[a] < p.imgs ? pim[a] * hpi + pty[a] * p.IS * p.HW + ptx[a] * p.IS : 0;
     }
 
-    f32x16 acc[MA][NB];
-#pragma unroll
-    for (int a = 0; a < MA; ++a)
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    const int txl = p.txl, tyl = p.tyl;             // log2(tiles_x), log2(tiles_y)
+    const int ntiles = p.ntiles;
+    const bool one_img = p.imgs == 1;
 
-    const int w_items = p.ntaps * BN * 4;
-    constexpr int MAXW = (CU_MAX_TAPS * BN * 4 + 255) / 256;
-    u32x4 xreg[MAXI];
-    u32x4 wreg[MAXW];
+    // per-tile staging state
+    int pix[NX], nimg[NX];
+    unsigned inb_mask = 0;
+    u32x4 xreg[NX];
+    u32x4 wreg[NW];
+    float scv[PIECE], shv[PIECE];
+    int t_img0 = 0;
+
+    auto tile_geometry = [&](int tile) {
+        const int tile_x = tile & ((1 << txl) - 1);
+        const int tile_y = (tile >> txl) & ((1 << tyl) - 1);
+        const int ig = tile >> (txl + tyl);
+        const int py0 = tile_y << p.thl, px0 = tile_x << p.twl;
+        t_img0 = ig << p.iml;
+        const int sy0 = py0 * p.IS + p.dymin, sx0 = px0 * p.IS + p.dxmin;
+        inb_mask = 0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int im = geo[j] >> 20, hy = (geo[j] >> 10) & 1023, hx = geo[j] & 1023;
+            const int n = t_img0 + im, sy = sy0 + hy, sx = sx0 + hx;
+            const bool inb = ((exist >> j) & 1u) && (n < p.N) && (sy >= 0) && (sy < p.SH) && (sx >= 0) && (sx < p.SW);
+            pix[j] = inb ? (n * p.SH + sy) * p.SW + sx : 0;
+            nimg[j] = inb ? n : 0;
+            inb_mask |= (inb ? 1u : 0u) << j;
+        }
+    };
 
     auto prefetch = [&](int c0) {
         const bool s1 = c0 >= p.C0;
         const T* src = reinterpret_cast<const T*>(s1 ? p.src1 : p.src0);
         const int Cs = s1 ? p.C1 : p.C0;
-        const int cc = s1 ? c0 - p.C0 : c0;
+        const int cc = (s1 ? c0 - p.C0 : c0) + piece * PIECE;
 #pragma unroll
-        for (int j = 0; j < MAXI; ++j) {
-            if (pix[j] >= 0) {
-                const int piece = (tid + j * 256) & 3;
-                xreg[j] = *reinterpret_cast<const u32x4*>(src + (size_t)pix[j] * Cs + cc + piece * PIECE);
-            }
+        for (int j = 0; j < NX; ++j)
+            xreg[j] = *reinterpret_cast<const u32x4*>(src + (size_t)pix[j] * Cs + cc);
+        if constexpr (!WRES) {
+            const T* wp = reinterpret_cast<const T*>(p.w) + c0;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) wreg[j] = *reinterpret_cast<const u32x4*>(wp + wbase[j]);
         }
-        const T* wp = reinterpret_cast<const T*>(p.w);
+        if (!PLAIN && one_img) {
+            const float* sc = s1 ? p.sc1 : p.sc0;
+            const float* sh = s1 ? p.sh1 : p.sh0;
+            const bool aff = sc != nullptr;
+            const int nn = t_img0 < p.N ? t_img0 : 0;
+            // no affine: read any valid memory and select the identity afterwards (keeps the loads unconditional)
+            const float* scp = aff ? sc + (size_t)nn * Cs + cc : reinterpret_cast<const float*>(p.w);
+            const float* shp = aff ? sh + (size_t)nn * Cs + cc : reinterpret_cast<const float*>(p.w);
 #pragma unroll
-        for (int j = 0; j < MAXW; ++j) {
-            const int i = tid + j * 256;
-            if (i < w_items) {
-                const int piece = i & 3;
-                const int col = (i >> 2) % BN;
-                const int t = (i >> 2) / BN;
-                const int n = n0 + col;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (n < p.CO)
-                    v = *reinterpret_cast<const u32x4*>(wp + ((size_t)p.tap_w[t] * p.CO + n) * CI + c0 + piece * PIECE);
-                wreg[j] = v;
+            for (int e = 0; e < PIECE; ++e) {
+                const float a = scp[e], b = shp[e];
+                scv[e] = aff ? a : 1.f;
+                shv[e] = aff ? b : 0.f;
             }
         }
     };
@@ -151,38 +229,55 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvKArgs p) {
     auto commit = [&](int c0) {
         const bool s1 = c0 >= p.C0;
         const int Cs = s1 ? p.C1 : p.C0;
-        const int cc = s1 ? c0 - p.C0 : c0;
+        const int cc = (s1 ? c0 - p.C0 : c0) + piece * PIECE;
         const float* sc = s1 ? p.sc1 : p.sc0;
         const float* sh = s1 ? p.sh1 : p.sh0;
         const float slope = s1 ? p.slope1 : p.slope0;
+        if constexpr (PLAIN) {
 #pragma unroll
-        for (int j = 0; j < MAXI; ++j) {
-            if (pix[j] >= -1) {
-                float v[PIECE];
-                if (pix[j] >= 0) {
-                    const int piece = (tid + j * 256) & 3;
+            for (int j = 0; j < NX; ++j) {
+                if ((exist >> j) & 1u) {
+                    u32x4 v = xreg[j];
+                    if (!((inb_mask >> j) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
                     if constexpr (PIECE == 8) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[2 * e] = __uint_as_float(xreg[j][e] << 16);
-                            v[2 * e + 1] = __uint_as_float(xreg[j][e] & 0xffff0000u);
-                        }
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(Xs) + (size_t)ldsx[j] * 8) = v;
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(xreg[j][e]);
+                        for (int e = 0; e < 4; ++e)
+                            reinterpret_cast<float*>(Xs)[ldsx[j] + e * p.XP] = __uint_as_float(v[e]);
                     }
-                    if (sc != nullptr) {
-                        const float* scp = sc + (size_t)nimg[j] * Cs + cc + piece * PIECE;
-                        const float* shp = sh + (size_t)nimg[j] * Cs + cc + piece * PIECE;
-#pragma unroll
-                        for (int e = 0; e < PIECE; ++e) v[e] = v[e] * scp[e] + shp[e];
-                    }
-#pragma unroll
-                    for (int e = 0; e < PIECE; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < PIECE; ++e) v[e] = 0.f;
                 }
+            }
+        } else {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            float v[PIECE];
+            if constexpr (PIECE == 8) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] = __uint_as_float(xreg[j][e] << 16);
+                    v[2 * e + 1] = __uint_as_float(xreg[j][e] & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(xreg[j][e]);
+            }
+            if (one_img) {
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) v[e] = v[e] * scv[e] + shv[e];
+            } else if (sc != nullptr) {      // several small images per tile: per-item affine (tiny layers only)
+                const float* scp = sc + (size_t)nimg[j] * Cs + cc;
+                const float* shp = sh + (size_t)nimg[j] * Cs + cc;
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) v[e] = v[e] * scp[e] + shp[e];
+            }
+            const bool inb = (inb_mask >> j) & 1u;
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) {
+                const float y = v[e] > 0.f ? v[e] : v[e] * slope;
+                v[e] = inb ? y : 0.f;          // zero padding applies to the ACTIVATED tensor
+            }
+            if ((exist >> j) & 1u) {
                 if constexpr (PIECE == 8) {
                     store_piece<bf16_t>(reinterpret_cast<bf16_t*>(Xs) + (size_t)ldsx[j] * 8, v);
                 } else {
@@ -191,121 +286,156 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvKArgs p) {
                 }
             }
         }
-#pragma unroll
-        for (int j = 0; j < MAXW; ++j) {
-            const int i = tid + j * 256;
-            if (i < w_items) {
-                const int piece = i & 3;
-                const int col = (i >> 2) % BN;
-                const int t = (i >> 2) / BN;
-                if constexpr (PIECE == 8) {
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(Ws) +
-                                              ((size_t)(t * 4 + piece) * p.WP + col) * 8) = wreg[j];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        reinterpret_cast<float*>(Ws)[(t * 16 + piece * 4 + e) * p.WP + col] = __uint_as_float(wreg[j][e]);
-                }
-            }
         }
+        if constexpr (!WRES) store_w(wreg, 0);
     };
 
-    prefetch(0);
-    for (int c0 = 0; c0 < CI; c0 += CK) {
-        __syncthreads();          // previous chunk's fragment reads are done
-        commit(c0);
-        __syncthreads();
-        if (c0 + CK < CI) prefetch(c0 + CK);
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        tile_geometry(tile);
+        prefetch(0);
+    }
+    while (tile < ntiles) {
+        // origin of the tile being computed (the staging state may move on to the next tile before the epilogue)
+        const int cur_tile_x = tile & ((1 << txl) - 1), cur_tile_y = (tile >> txl) & ((1 << tyl) - 1);
+        const int cur_img0 = (tile >> (txl + tyl)) << p.iml;
+        const int py0 = cur_tile_y << p.thl, px0 = cur_tile_x << p.twl;
+        const int next = tile + gridDim.x;
 
-        for (int t = 0; t < p.ntaps; ++t) {
-            const int toff = p.tap_off[t];
+        f32x16 acc[MA][NB];
 #pragma unroll
-            for (int kk = 0; kk < C::KSTEPS; ++kk) {
-                if constexpr (PIECE == 8) {
-                    const bf16_t* X16 = reinterpret_cast<const bf16_t*>(Xs);
-                    const bf16_t* W16 = reinterpret_cast<const bf16_t*>(Ws);
-                    bf16x8 af[MA], bfr[NB];
+        for (int a = 0; a < MA; ++a)
 #pragma unroll
-                    for (int a = 0; a < MA; ++a)
-                        af[a] = *reinterpret_cast<const bf16x8*>(X16 + ((size_t)(2 * kk + h) * p.XP + hpA[a] + toff) * 8);
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-                    for (int b = 0; b < NB; ++b)
-                        bfr[b] = *reinterpret_cast<const bf16x8*>(
-                            W16 + ((size_t)(t * 4 + 2 * kk + h) * p.WP + b * 32 + r) * 8);
+                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+        for (int c0 = 0, ci = 0; c0 < CI; c0 += CK, ++ci) {
+            __syncthreads();          // previous chunk's fragment reads are done
+            if (!(p.dbg & 4)) commit(c0);
+            __syncthreads();
+            if (!(p.dbg & 8)) {
+            if (c0 + CK < CI) {
+                prefetch(c0 + CK);
+            } else if (next < ntiles) {   // cross-tile prefetch: the next tile's first chunk flies under these MFMAs
+                tile_geometry(next);
+                prefetch(0);
+            }
+            }
+            const int wbase_units = WRES ? ci * w_chunk_units : 0;
+            if (!(p.dbg & 2))
+            for (int t = 0; t < p.ntaps; ++t) {
+                const int toff = s_tap[t];
 #pragma unroll
-                    for (int a = 0; a < MA; ++a)
+                for (int kk = 0; kk < C::KSTEPS; ++kk) {
+                    if constexpr (PIECE == 8) {
+                        const bf16_t* X16 = reinterpret_cast<const bf16_t*>(Xs);
+                        const bf16_t* W16 = reinterpret_cast<const bf16_t*>(Ws);
+                        bf16x8 af[MA], bfr[NB];
+#pragma unroll
+                        for (int a = 0; a < MA; ++a)
+                            af[a] = *reinterpret_cast<const bf16x8*>(X16 + ((size_t)(2 * kk + h) * p.XP + hpA[a] + toff) * 8);
 #pragma unroll
                         for (int b = 0; b < NB; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
-                } else {
-                    const float* Xf = reinterpret_cast<const float*>(Xs);
-                    const float* Wf = reinterpret_cast<const float*>(Ws);
-                    float af[MA], bfr[NB];
+                            bfr[b] = *reinterpret_cast<const bf16x8*>(
+                                W16 + ((size_t)wbase_units + (t * 4 + 2 * kk + h) * p.WP + b * 32 + r) * 8);
 #pragma unroll
-                    for (int a = 0; a < MA; ++a) af[a] = Xf[(2 * kk + h) * p.XP + hpA[a] + toff];
+                        for (int a = 0; a < MA; ++a)
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) bfr[b] = Wf[(t * 16 + 2 * kk + h) * p.WP + b * 32 + r];
+                            for (int b = 0; b < NB; ++b)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
+                    } else {
+                        const float* Xf = reinterpret_cast<const float*>(Xs);
+                        const float* Wf = reinterpret_cast<const float*>(Ws);
+                        float af[MA], bfr[NB];
 #pragma unroll
-                    for (int a = 0; a < MA; ++a)
+                        for (int a = 0; a < MA; ++a) af[a] = Xf[(2 * kk + h) * p.XP + hpA[a] + toff];
 #pragma unroll
                         for (int b = 0; b < NB; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bfr[b], acc[a][b], 0, 0, 0);
+                            bfr[b] = Wf[wbase_units + (t * 16 + 2 * kk + h) * p.WP + b * 32 + r];
+#pragma unroll
+                        for (int a = 0; a < MA; ++a)
+#pragma unroll
+                            for (int b = 0; b < NB; ++b)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[b], af[a], acc[a][b], 0, 0, 0);
+                    }
                 }
             }
         }
-    }
 
-    // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int col = n0 + b * 32 + r;
-        if (col >= p.CO) continue;
-        const float bias = p.bias ? p.bias[col] : 0.f;
-        const bool d1 = col >= p.D0;
-        const int dcol = d1 ? col - p.D0 : col;
-        const int DC = d1 ? p.DC1 : p.DC0;
-        const int accum = d1 ? p.accum1 : p.accum0;
-        T* dst = reinterpret_cast<T*>(d1 ? p.dst1 : p.dst0);
-        if (p.out_nchw && dcol >= p.DC0) continue;
+        // ---- epilogue.  D[row = column][col = pixel]: lane -> pixel (lane & 31); register i -> column
+        //      (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5): each register quad is 4 consecutive output channels.
 #pragma unroll
         for (int a = 0; a < MA; ++a) {
+            const int n = cur_img0 + pim[a];
+            const int py = py0 + pty[a], px = px0 + ptx[a];
+            if (pim[a] >= p.imgs || n >= p.N || py >= p.PH || px >= p.PW || (p.dbg & 1)) continue;
+            const int oy = py * p.OS + p.OY0, ox = px * p.OS + p.OX0;
+            const size_t opix = ((size_t)n * p.OH + oy) * p.OW + ox;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-                const int m = wave * 32 * MA + a * 32 + row;
-                const int tx = m & (TW - 1), ty = (m >> p.twl) & (TH - 1), im = m >> (p.twl + p.thl);
-                const int n = img0 + im;
-                const int py = py0 + ty, px = px0 + tx;
-                if (im >= p.imgs || n >= p.N || py >= p.PH || px >= p.PW) continue;
-                const int oy = py * p.OS + p.OY0, ox = px * p.OS + p.OX0;
-                const float v = acc[a][b][i] + bias;
-                if (p.out_nchw) {
-                    float* o = reinterpret_cast<float*>(p.dst0) + (((size_t)n * p.DC0 + dcol) * p.OH + oy) * p.OW + ox;
-                    *o = accum ? *o + v : v;
-                } else {
-                    T* o = dst + (((size_t)n * p.OH + oy) * p.OW + ox) * DC + dcol;
-                    Elem<T>::st(o, accum ? Elem<T>::ld(o) + v : v);
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = n0 + b * 32 + 8 * g + 4 * h;
+                    if (col >= p.CO) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e];
+                    if (p.bias) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                    }
+                    if (p.out_nchw) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (col + e < p.DC0) {
+                                float* o = reinterpret_cast<float*>(p.dst0) +
+                                           (((size_t)n * p.DC0 + col + e) * p.OH + oy) * p.OW + ox;
+                                *o = p.accum0 ? *o + v[e] : v[e];
+                            }
+                        }
+                    } else {
+                        const bool d1 = col >= p.D0;
+                        const int dcol = d1 ? col - p.D0 : col;
+                        const int DC = d1 ? p.DC1 : p.DC0;
+                        const int accum = d1 ? p.accum1 : p.accum0;
+                        T* o = reinterpret_cast<T*>(d1 ? p.dst1 : p.dst0) + opix * DC + dcol;
+                        if constexpr (sizeof(T) == 2) {
+                            if (accum) {
+                                const u32x2 old = *reinterpret_cast<const u32x2*>(o);
+                                v[0] += __uint_as_float(old[0] << 16); v[1] += __uint_as_float(old[0] & 0xffff0000u);
+                                v[2] += __uint_as_float(old[1] << 16); v[3] += __uint_as_float(old[1] & 0xffff0000u);
+                            }
+                            u32x2 pk;
+                            pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                            pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                            *reinterpret_cast<u32x2*>(o) = pk;
+                        } else {
+                            f32x4 ov = {v[0], v[1], v[2], v[3]};
+                            if (accum) {
+                                const f32x4 old = *reinterpret_cast<const f32x4*>(o);
+                                ov += old;
+                            }
+                            *reinterpret_cast<f32x4*>(o) = ov;
+                        }
+                    }
                 }
             }
         }
+        tile = next;
     }
 }
 
-template <typename T, int MA, int NB>
-int launch(const ConvKArgs& a, int tiles, hipStream_t st) {
-    using C = Cfg<T>;
-    const size_t x_bytes = (size_t)(C::CK / C::PIECE) * C::PPP * a.XP * (C::PPP == 1 ? 16 : 4);
-    const size_t w_bytes = (size_t)a.ntaps * C::WPLANES * a.WP * (C::PPP == 1 ? 16 : 4);
-    const size_t lds = x_bytes + w_bytes;
-    CU_CHECK_ARG(lds <= 160 * 1024, "cu_conv_gemm: LDS %zu bytes exceeds 160 KiB", lds);
-    auto k = igemm_conv_kernel<T, MA, NB>;
+template <typename T, int MA, int NB, int NX, int NT, bool WRES, bool PLAIN>
+int launch(const ConvKArgs& a, size_t lds, int grid_x, int grid_y, hipStream_t st) {
+    auto k = igemm_conv_kernel<T, MA, NB, NX, NT, WRES, PLAIN>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
         CU_CHECK_ARG(e == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     }
-    dim3 grid(tiles, cdiv(a.CO, 32 * NB));
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k, dim3(grid_x, grid_y), dim3(256), lds, st, a);
     CU_LAUNCH_CHECK();
     return 0;
 }
@@ -317,7 +447,8 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
                             const float* bias, void* dst0, void* dst1, void* stream) {
     CU_CHECK_ARG(d != nullptr, "cu_conv_gemm: null descriptor");
     CU_CHECK_ARG(d->dtype == CU_F32 || d->dtype == CU_BF16, "cu_conv_gemm: bad dtype %d", d->dtype);
-    const int CK = d->dtype == CU_BF16 ? 32 : 16;
+    const bool bf = d->dtype == CU_BF16;
+    const int CK = bf ? 32 : 16;
     CU_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= CU_MAX_TAPS, "cu_conv_gemm: ntaps %d", d->ntaps);
     CU_CHECK_ARG(d->C0 > 0 && d->C0 % CK == 0 && d->C1 >= 0 && d->C1 % CK == 0,
                  "cu_conv_gemm: channel counts %d,%d must be multiples of %d", d->C0, d->C1, CK);
@@ -326,7 +457,11 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
                  "cu_conv_gemm: scale/shift must come in pairs");
     CU_CHECK_ARG(d->D0 > 0 && d->D0 <= d->CO && (d->D0 == d->CO || dst1), "cu_conv_gemm: bad destination split");
     CU_CHECK_ARG(d->D0 == d->CO || d->D0 % 32 == 0, "cu_conv_gemm: split point must be a multiple of 32");
+    CU_CHECK_ARG(d->CO % 4 == 0 && d->DC0 % 4 == 0 || d->out_nchw_f32, "cu_conv_gemm: CO and DC0 must be multiples of 4");
     CU_CHECK_ARG(d->N > 0 && d->PH > 0 && d->PW > 0 && d->IS >= 1 && d->OS >= 1, "cu_conv_gemm: bad geometry");
+    CU_CHECK_ARG((d->PH - 1) * d->OS + d->OY0 < d->OH && (d->PW - 1) * d->OS + d->OX0 < d->OW && d->OY0 >= 0 &&
+                     d->OX0 >= 0,
+                 "cu_conv_gemm: destination pixel out of range");
 
     ConvKArgs a;
     memset(&a, 0, sizeof(a));
@@ -337,22 +472,19 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
     a.DC0 = d->DC0; a.DC1 = d->DC1; a.ntaps = d->ntaps;
     a.slope0 = d->slope0; a.slope1 = d->slope1; a.accum0 = d->accum0; a.accum1 = d->accum1;
     a.out_nchw = d->out_nchw_f32;
+    const int CI = d->C0 + d->C1;
+    { const char* e = getenv("CU_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
 
-    // destination bounds: every loop pixel must land inside the destination image
-    CU_CHECK_ARG((d->PH - 1) * d->OS + d->OY0 < d->OH && (d->PW - 1) * d->OS + d->OX0 < d->OW && d->OY0 >= 0 &&
-                     d->OX0 >= 0,
-                 "cu_conv_gemm: destination pixel out of range");
-
-    // tile geometry: BM = 128 loop pixels = IMGS x TH x TW
-    const int BM = 128;
-    int tw = d->PW < 32 ? d->PW : 32;
-    int th = BM / tw;
-    if (th > d->PH) th = d->PH;
-    int imgs = BM / (tw * th);
-    a.twl = ilog2_exact(tw); a.thl = ilog2_exact(th); a.iml = ilog2_exact(imgs);
-    CU_CHECK_ARG(a.twl >= 0 && a.thl >= 0 && a.iml >= 0 && d->PW % tw == 0 && d->PH % th == 0,
-                 "cu_conv_gemm: loop grid %dx%d must be powers of two", d->PH, d->PW);
-    a.tiles_x = d->PW / tw; a.tiles_y = d->PH / th;
+    // ---- column tile: the widest of {128, 96, 64, 32} that divides the work without waste
+    int nb;
+    if (d->CO % 128 == 0) nb = 4;
+    else if (d->CO % 96 == 0) nb = 3;
+    else if (d->CO % 64 == 0) nb = 2;
+    else nb = 1;
+    if (d->D0 != d->CO && d->D0 % (32 * nb) != 0) nb = (d->D0 % 64 == 0 && d->CO % 64 == 0) ? 2 : 1;
+    if (!bf && nb > 2) nb = (d->CO % 64 == 0) ? 2 : 1;   // keep the f32 weight tile within LDS
+    const int coltiles = cdiv(d->CO, 32 * nb);
+    a.WP = 32 * nb + 2;
 
     int dymin = 1 << 20, dxmin = 1 << 20, dymax = -(1 << 20), dxmax = -(1 << 20);
     for (int t = 0; t < d->ntaps; ++t) {
@@ -360,37 +492,91 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
         dxmin = d->tap_dx[t] < dxmin ? d->tap_dx[t] : dxmin; dxmax = d->tap_dx[t] > dxmax ? d->tap_dx[t] : dxmax;
     }
     a.dymin = dymin; a.dxmin = dxmin;
-    a.HH = (th - 1) * d->IS + (dymax - dymin) + 1;
-    a.HW = (tw - 1) * d->IS + (dxmax - dxmin) + 1;
-    while (imgs > 1 && imgs * a.HH * a.HW * 4 > 256 * MAXI) imgs >>= 1;   // stride-2 gathers on tiny maps: fewer images per tile
+
+    // ---- pixel tile: BM = 128*MA loop pixels = IMGS x TH x TW.  MA = 2 (bf16, stride-1 gathers, 3x3) when there is
+    //      enough work to keep every CU busy with 256-pixel tiles.
+    const long total_px = (long)d->N * d->PH * d->PW;
+    int ma = (bf && d->IS == 1 && d->ntaps > 4 && total_px / 256 * coltiles >= 512) ? 2 : 1;
+    int tw = 0, th = 0, imgs = 0;
+    for (;; ma = 1) {
+        const int BM = 128 * ma;
+        tw = d->PW < 32 ? d->PW : 32;
+        th = BM / tw;
+        if (th > d->PH) th = d->PH;
+        imgs = BM / (tw * th);
+        a.twl = ilog2_exact(tw); a.thl = ilog2_exact(th);
+        CU_CHECK_ARG(a.twl >= 0 && a.thl >= 0 && ilog2_exact(imgs) >= 0 && d->PW % tw == 0 && d->PH % th == 0,
+                     "cu_conv_gemm: loop grid %dx%d must be powers of two", d->PH, d->PW);
+        a.HH = (th - 1) * d->IS + (dymax - dymin) + 1;
+        a.HW = (tw - 1) * d->IS + (dxmax - dxmin) + 1;
+        const int nxmax = ma == 2 ? 6 : MAXI;
+        while (imgs > 1 && imgs * a.HH * a.HW * 4 > 256 * nxmax) imgs >>= 1;   // stride-2 gathers on tiny maps
+        if (imgs * a.HH * a.HW * 4 <= 256 * nxmax || ma == 1) break;
+    }
     a.imgs = imgs; a.iml = ilog2_exact(imgs);
     a.halo_px = imgs * a.HH * a.HW;
     CU_CHECK_ARG(a.halo_px * 4 <= 256 * MAXI, "cu_conv_gemm: halo of %d pixels too large", a.halo_px);
+    CU_CHECK_ARG(a.HH < 1024 && a.HW < 1024, "cu_conv_gemm: halo too large");
+    a.tiles_x = d->PW / tw; a.tiles_y = d->PH / th;
+    a.txl = ilog2_exact(a.tiles_x); a.tyl = ilog2_exact(a.tiles_y);
+    CU_CHECK_ARG(a.txl >= 0 && a.tyl >= 0, "cu_conv_gemm: tile counts must be powers of two");
     const int igroups = cdiv(d->N, imgs);
+    a.ntiles = a.tiles_x * a.tiles_y * igroups;
     for (int t = 0; t < d->ntaps; ++t) {
         a.tap_off[t] = (d->tap_dy[t] - dymin) * a.HW + (d->tap_dx[t] - dxmin);
         a.tap_w[t] = d->tap_w[t];
         CU_CHECK_ARG(d->tap_w[t] >= 0, "cu_conv_gemm: negative weight tap index");
     }
-    const int mod = d->dtype == CU_BF16 ? 16 : 32;   // plane stride == 2 (mod 16 entries / 32 floats): conflict-free fills
+    const int mod = bf ? 16 : 32;   // plane stride == 2 (mod 16 entries / 32 floats): conflict-free fills
     a.XP = a.halo_px + ((2 - a.halo_px % mod) + mod) % mod;
 
+    // ---- LDS budget; resident weights when the whole slice fits beside the halo patch (bf16, <= 2 column blocks)
+    const int unit = bf ? 16 : 4;
+    const int wplanes = bf ? 4 : 16, xplanes = bf ? 4 : 16;
+    const size_t x_bytes = (size_t)xplanes * a.XP * unit;
+    const size_t w_chunk_bytes = (size_t)d->ntaps * wplanes * a.WP * unit;
+    const int nchunks = CI / CK;
+    const bool wres = bf && nb <= 2 && x_bytes + w_chunk_bytes * nchunks <= 96 * 1024 && a.ntiles >= 512;
+    const size_t lds_data = x_bytes + w_chunk_bytes * (wres ? nchunks : 1);
+    a.tap_lds = (int)((lds_data + 15) / 16 * 16);
+    const size_t lds = a.tap_lds + 128;
+    CU_CHECK_ARG(lds <= 160 * 1024, "cu_conv_gemm: LDS %zu bytes exceeds 160 KiB", lds);
+
+    // ---- grid: persistent over pixel tiles (a few workgroups per CU), one grid row per column tile
+    int grid_x = a.ntiles;
+    const int cap = wres ? 256 * 3 : 256 * 8;
+    if (grid_x > cap) grid_x = cap;
+
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int tiles = a.tiles_x * a.tiles_y * igroups;
-    // column tile: the widest of {128, 96, 64, 32} that divides the work without waste
-    int nb;
-    if (d->CO % 128 == 0) nb = 4;
-    else if (d->CO % 96 == 0) nb = 3;
-    else if (d->CO % 64 == 0) nb = 2;
-    else nb = 1;
-    if (d->D0 != d->CO && d->D0 % (32 * nb) != 0) nb = (d->D0 % 64 == 0 && d->CO % 64 == 0) ? 2 : 1;
-    if (d->dtype == CU_F32 && nb > 2) nb = (d->CO % 64 == 0) ? 2 : 1;   // keep the f32 weight tile within LDS
-    a.WP = 32 * nb + 2;
-#define CU_GO(T, NBv) return launch<T, 1, NBv>(a, tiles, st)
-    if (d->dtype == CU_BF16) {
-        switch (nb) { case 4: CU_GO(bf16_t, 4); case 3: CU_GO(bf16_t, 3); case 2: CU_GO(bf16_t, 2); default: CU_GO(bf16_t, 1); }
+    const int nx = ma == 2 ? 6 : (a.halo_px * 4 > 256 * 4 ? 10 : 4);
+    const bool taps9 = d->ntaps > 4;
+    const bool plain = !scale0 && d->slope0 == 1.0f && (d->C1 == 0 || (!scale1 && d->slope1 == 1.0f));
+#define CU_L(T, MAv, NBv, NXv, NTv, WR)                                                              \
+    do {                                                                                             \
+        if (plain) return launch<T, MAv, NBv, NXv, NTv, WR, true>(a, lds, grid_x, coltiles, st);     \
+        return launch<T, MAv, NBv, NXv, NTv, WR, false>(a, lds, grid_x, coltiles, st);               \
+    } while (0)
+#define CU_NXNT(T, NBv, WR)                                       \
+    do {                                                          \
+        if (ma == 2) CU_L(T, 2, NBv, 6, 9, WR);                   \
+        if (nx == 10) { if (taps9) CU_L(T, 1, NBv, 10, 9, WR); CU_L(T, 1, NBv, 10, 4, WR); } \
+        if (taps9) CU_L(T, 1, NBv, 4, 9, WR);                     \
+        CU_L(T, 1, NBv, 4, 4, WR);                                \
+    } while (0)
+    if (bf) {
+        switch (nb) {
+            case 4: CU_NXNT(bf16_t, 4, false);
+            case 3: CU_NXNT(bf16_t, 3, false);
+            case 2: if (wres) CU_NXNT(bf16_t, 2, true); CU_NXNT(bf16_t, 2, false);
+            default: if (wres) CU_NXNT(bf16_t, 1, true); CU_NXNT(bf16_t, 1, false);
+        }
     } else {
-        switch (nb) { case 2: CU_GO(float, 2); default: CU_GO(float, 1); }
+        ma = 1;
+        switch (nb) {
+            case 2: CU_NXNT(float, 2, false);
+            default: CU_NXNT(float, 1, false);
+        }
     }
-#undef CU_GO
+#undef CU_NXNT
+#undef CU_L
 }

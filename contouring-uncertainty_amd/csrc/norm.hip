@@ -111,6 +111,36 @@ __global__ void stats_finalize_kernel(const T* __restrict__ z, const float* __re
     stats[3 * NC + i] = b - mean * g * rstd;
 }
 
+// materialise a = LeakyReLU(z*scale + shift) (one streaming pass): the MFMA kernels then stage plain operands.
+// Measured on MI355X: re-doing this affine + activation inside every consumer's operand load made the thin-channel
+// convolutions VALU-bound (40-50 % of their time); one extra 2-byte write + read per element is far cheaper.
+template <typename T>
+__global__ __launch_bounds__(NT) void apply_kernel(const T* __restrict__ z, const float* __restrict__ stats, float slope,
+                                                   T* __restrict__ out, int N, int HW, int C, int tpp, int rows,
+                                                   int chunk) {
+    constexpr int PIECE = Elem<T>::PIECE;
+    const int n = blockIdx.x;
+    const int p0 = blockIdx.y * chunk, p1 = min(HW, p0 + chunk);
+    const int piece = threadIdx.x % tpp, prow = threadIdx.x / tpp;
+    if (prow >= rows) return;
+    const size_t NC = (size_t)N * C;
+    const size_t sidx = (size_t)n * C + piece * PIECE;
+    float sc[PIECE], sh[PIECE];
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) { sc[e] = stats[2 * NC + sidx + e]; sh[e] = stats[3 * NC + sidx + e]; }
+    const size_t base = (size_t)n * HW * C + piece * PIECE;
+    for (int p = p0 + prow; p < p1; p += rows) {
+        float v[PIECE];
+        load_piece<T>(z + base + (size_t)p * C, v);
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+            const float y = v[e] * sc[e] + sh[e];
+            v[e] = y > 0.f ? y : y * slope;
+        }
+        store_piece<T>(out + base + (size_t)p * C, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 template <typename T>
 __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ z,
@@ -357,6 +387,21 @@ extern "C" int cu_instnorm_stats(int dtype, int N, int HW, int C, const void* z,
         hipLaunchKernelGGL(stats_finalize_kernel<float>, dim3(fin_blocks), dim3(256), 0, st, (const float*)z, ws, gamma,
                            beta, eps, stats, N, HW, C);
     }
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_instnorm_apply(int dtype, int N, int HW, int C, const void* z, const float* stats, float slope,
+                                 void* out, void* stream) {
+    NORM_COMMON_CHECKS("cu_instnorm_apply");
+    CU_CHECK_ARG(z && stats && out, "cu_instnorm_apply: null pointer");
+    dim3 grid(N, nchunks);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL(apply_kernel<bf16_t>, grid, dim3(NT), 0, st, (const bf16_t*)z, stats, slope, (bf16_t*)out, N, HW,
+                           C, rm.tpp, rm.rows, chunk);
+    else
+        hipLaunchKernelGGL(apply_kernel<float>, grid, dim3(NT), 0, st, (const float*)z, stats, slope, (float*)out, N, HW, C,
+                           rm.tpp, rm.rows, chunk);
     CU_LAUNCH_CHECK();
     return 0;
 }

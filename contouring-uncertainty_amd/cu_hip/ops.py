@@ -22,6 +22,7 @@ class Act:
     z: Tensor                          # (N, H, W, C) raw
     stats: Optional[Tensor] = None     # (4, N, C) f32: mean, rstd, scale, shift   (None = no affine)
     slope: float = 1.0                 # LeakyReLU slope (1.0 = identity, 0.0 = ReLU)
+    a: Optional[Tensor] = None         # materialised LeakyReLU(z*scale+shift); consumers stage it as a plain operand
 
     @property
     def scale(self):
@@ -30,6 +31,12 @@ class Act:
     @property
     def shift(self):
         return None if self.stats is None else self.stats[3]
+
+    def operand(self):
+        """(tensor, scale, shift, slope) a consumer kernel should load."""
+        if self.a is not None:
+            return self.a, None, None, 1.0
+        return self.z, self.scale, self.shift, self.slope
 
 
 # ---- optional per-launch timing (bench.py's roofline pass): HIP events on the launch stream around every kernel call
@@ -79,9 +86,11 @@ def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: T
     s0 = srcs[0]
     s1 = srcs[1] if len(srcs) > 1 else None
     d = L.ConvDesc()
-    d.dtype = L.dtype_code(s0.z.dtype)
-    d.N, d.SH, d.SW, d.C0 = s0.z.shape
-    d.C1 = s1.z.shape[3] if s1 is not None else 0
+    t0, sc0, sh0, sl0 = s0.operand()
+    t1, sc1, sh1, sl1 = s1.operand() if s1 is not None else (None, None, None, 1.0)
+    d.dtype = L.dtype_code(t0.dtype)
+    d.N, d.SH, d.SW, d.C0 = t0.shape
+    d.C1 = t1.shape[3] if t1 is not None else 0
     d.PH, d.PW = grid
     d.IS = in_stride
     dst0 = dsts[0]
@@ -97,17 +106,15 @@ def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: T
     d.CO = n_cols if n_cols is not None else sum(dst_cols)
     d.D0 = dst_cols[0]
     _taps(d, [t[0] for t in taps], [t[1] for t in taps], [t[2] for t in taps])
-    d.slope0 = s0.slope
-    d.slope1 = s1.slope if s1 is not None else 1.0
+    d.slope0 = sl0
+    d.slope1 = sl1
     d.accum0, d.accum1 = int(accum[0]), int(accum[1]) if len(accum) > 1 else 0
     d.out_nchw_f32 = int(out_nchw)
-    assert w.dtype == s0.z.dtype and w.shape[-1] == d.C0 + d.C1 and w.shape[-2] == d.CO, (w.shape, d.CO, d.C0, d.C1)
+    assert w.dtype == t0.dtype and w.shape[-1] == d.C0 + d.C1 and w.shape[-2] == d.CO, (w.shape, d.CO, d.C0, d.C1)
     flops = 2.0 * d.N * d.PH * d.PW * d.ntaps * (d.C0 + d.C1) * (d.DC0 if out_nchw else d.CO)
     with _Prof("igemm_conv", flops):
-        rc = lib.cu_conv_gemm(d, L.ptr(s0.z), L.ptr(s0.scale), L.ptr(s0.shift),
-                              L.ptr(s1.z) if s1 is not None else None, L.ptr(s1.scale) if s1 is not None else None,
-                              L.ptr(s1.shift) if s1 is not None else None, L.ptr(w), L.ptr(bias), L.ptr(dst0),
-                              L.ptr(dsts[1]) if len(dsts) > 1 else None, L.stream_ptr())
+        rc = lib.cu_conv_gemm(d, L.ptr(t0), L.ptr(sc0), L.ptr(sh0), L.ptr(t1), L.ptr(sc1), L.ptr(sh1), L.ptr(w),
+                              L.ptr(bias), L.ptr(dst0), L.ptr(dsts[1]) if len(dsts) > 1 else None, L.stream_ptr())
     L.check(rc, "cu_conv_gemm")
 
 
@@ -118,9 +125,11 @@ def conv_wgrad(srcs: Sequence[Act], z: Tensor, dwk: Tensor, *, grid: Tuple[int, 
     s0 = srcs[0]
     s1 = srcs[1] if len(srcs) > 1 else None
     d = L.WgradDesc()
-    d.dtype = L.dtype_code(s0.z.dtype)
-    d.N, d.SH, d.SW, d.C0 = s0.z.shape
-    d.C1 = s1.z.shape[3] if s1 is not None else 0
+    t0, sc0, sh0, sl0 = s0.operand()
+    t1, sc1, sh1, sl1 = s1.operand() if s1 is not None else (None, None, None, 1.0)
+    d.dtype = L.dtype_code(t0.dtype)
+    d.N, d.SH, d.SW, d.C0 = t0.shape
+    d.C1 = t1.shape[3] if t1 is not None else 0
     d.PH, d.PW = grid
     d.IS = in_stride
     _, d.ZH, d.ZW, d.ZC = z.shape
@@ -128,15 +137,14 @@ def conv_wgrad(srcs: Sequence[Act], z: Tensor, dwk: Tensor, *, grid: Tuple[int, 
     d.CO = n_cols
     _taps(d, [t[0] for t in taps], [t[1] for t in taps], [t[4] for t in taps], [t[2] for t in taps],
           [t[3] for t in taps])
-    d.slope0 = s0.slope
-    d.slope1 = s1.slope if s1 is not None else 1.0
+    d.slope0 = sl0
+    d.slope1 = sl1
     d.splits = splits
-    assert dwk.dtype == torch.float32 and z.dtype == s0.z.dtype
+    assert dwk.dtype == torch.float32 and z.dtype == t0.dtype
     flops = 2.0 * d.N * d.PH * d.PW * d.ntaps * (d.C0 + d.C1) * d.CO
     with _Prof("igemm_wgrad", flops):
-        rc = lib.cu_conv_wgrad(d, L.ptr(s0.z), L.ptr(s0.scale), L.ptr(s0.shift),
-                               L.ptr(s1.z) if s1 is not None else None, L.ptr(s1.scale) if s1 is not None else None,
-                               L.ptr(s1.shift) if s1 is not None else None, L.ptr(z), L.ptr(dwk), L.stream_ptr())
+        rc = lib.cu_conv_wgrad(d, L.ptr(t0), L.ptr(sc0), L.ptr(sh0), L.ptr(t1), L.ptr(sc1), L.ptr(sh1), L.ptr(z),
+                               L.ptr(dwk), L.stream_ptr())
     L.check(rc, "cu_conv_wgrad")
 
 
@@ -162,6 +170,17 @@ def instnorm_stats(z: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], e
         L.check(L.load().cu_instnorm_stats(L.dtype_code(z.dtype), n, h * w_, c, L.ptr(z), L.ptr(gamma), L.ptr(beta), eps,
                                            L.ptr(stats), L.ptr(ws), L.stream_ptr()), "cu_instnorm_stats")
     return stats
+
+
+def instnorm_apply(act: Act) -> Tensor:
+    """Materialise LeakyReLU(z*scale + shift) and attach it to the Act."""
+    n, h, w_, c = act.z.shape
+    out = torch.empty_like(act.z)
+    with _Prof("instnorm_apply"):
+        L.check(L.load().cu_instnorm_apply(L.dtype_code(act.z.dtype), n, h * w_, c, L.ptr(act.z), L.ptr(act.stats),
+                                           act.slope, L.ptr(out), L.stream_ptr()), "cu_instnorm_apply")
+    act.a = out
+    return out
 
 
 def instnorm_lrelu_bwd(g: Tensor, act: Act, gamma: Optional[Tensor], dgamma, dbeta, dbias):

@@ -100,6 +100,10 @@ int cu_conv_c1_wgrad(int dtype, int N, int H, int W, int CO, const float* img, c
  * ws: f32 workspace [N][C][2], zero-filled by the call. */
 int cu_instnorm_stats(int dtype, int N, int HW, int C, const void* z, const float* gamma, const float* beta,
                       float eps, float* stats, float* ws, void* stream);
+/* out = LeakyReLU(z*scale + shift) [N][HW][C] (dtype): the activated tensor the next layers' kernels stage as a plain
+ * operand (measured: recomputing it in every consumer's load made thin layers VALU-bound). */
+int cu_instnorm_apply(int dtype, int N, int HW, int C, const void* z, const float* stats, float slope, void* out,
+                      void* stream);
 /* backward: g = dL/d(activated output) [N][HW][C] is overwritten in place with dL/dz.
  * dgamma/dbeta/dbias: f32 [C], accumulated (+=), any may be NULL.
  * ws: f32 workspace [N][C][2], zero-filled by the call. */

@@ -40,7 +40,11 @@ __device__ __forceinline__ bf16x4 tr_read(const void* lds_ptr) {
 }
 
 
-template <typename T, int NBLK, int CBLK>
+// NS / NZ: source / Z pieces per thread per tile (compile-time so that every staging load is unconditional, with a
+// clamped address and a mask -- predicated loads are serialised by hipcc).  PLAIN: the source needs no affine /
+// activation (materialised activations): staging is a pure 16-byte copy.  The next tile's loads are issued before
+// the current tile's MFMAs (register prefetch).
+template <typename T, int NBLK, int CBLK, int NS, int NZ, bool PLAIN>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
     using C = WCfg<T>;
     constexpr int PIECE = C::PIECE, KPIX = C::KPIX;
@@ -74,7 +78,50 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    for (int tile = blockIdx.y; tile < p.ntiles; tile += p.splits) {
+    // ---- tile-invariant staging geometry.  256 % SPP == 0 and 256 % ZPP == 0: a thread always stages the same piece.
+    const int s_piece = tid % SPP, z_piece = tid % ZPP;
+    const int s_c = c_base + s_piece * PIECE;                 // channel of this thread's source piece
+    const bool s_cok = s_c < CI;
+    const bool s_src1 = s_cok && s_c >= p.C0;      // out-of-range pieces read (and discard) source 0: never a null source 1
+    const T* s_ptr = reinterpret_cast<const T*>(s_src1 ? p.src1 : p.src0);
+    const int s_Cs = s_src1 ? p.C1 : p.C0;
+    const int s_cc = s_cok ? (s_src1 ? s_c - p.C0 : s_c) : 0;
+    const float* s_sc = s_src1 ? p.sc1 : p.sc0;
+    const float* s_sh = s_src1 ? p.sh1 : p.sh0;
+    const float s_slope = s_src1 ? p.slope1 : p.slope0;
+    const int z_col = n_base + z_piece * PIECE;
+    const bool z_cok = z_col < p.CO;
+    const int z_cc = z_cok ? z_col : 0;
+    int s_geo[NS], s_lds[NS], z_geo[NZ], z_lds[NZ];
+    unsigned s_exist = 0, z_exist = 0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int i = tid + j * 256;
+        const bool ex = i < p.s_halo * SPP;
+        const int hp = ex ? i / SPP : 0;
+        const int im = hp / s_hpi, rem = hp - im * s_hpi;
+        const int hy = rem / p.SHW, hx = rem - hy * p.SHW;
+        s_geo[j] = (im << 20) | (hy << 10) | hx;
+        s_lds[j] = hp * ROWS_B + s_piece * 16;
+        s_exist |= (ex ? 1u : 0u) << j;
+    }
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) {
+        const int i = tid + j * 256;
+        const bool ex = i < p.z_halo * ZPP;
+        const int hp = ex ? i / ZPP : 0;
+        const int im = hp / z_hpi, rem = hp - im * z_hpi;
+        const int hy = rem / p.ZHW, hx = rem - hy * p.ZHW;
+        z_geo[j] = (im << 20) | (hy << 10) | hx;
+        z_lds[j] = hp * ROWZ_B + z_piece * 16;
+        z_exist |= (ex ? 1u : 0u) << j;
+    }
+
+    u32x4 sreg[NS], zreg[NZ];
+    int s_img[NS];
+    unsigned s_inb = 0, z_inb = 0;
+
+    auto prefetch = [&](int tile) {
         int bx = tile;
         const int tile_x = bx % p.tiles_x; bx /= p.tiles_x;
         const int tile_y = bx % p.tiles_y;
@@ -82,50 +129,84 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
         const int py0 = tile_y << p.thl, px0 = tile_x << p.twl, img0 = ig << p.iml;
         const int sy0 = py0 * p.IS + p.sdymin, sx0 = px0 * p.IS + p.sdxmin;
         const int zy0 = py0 * p.ZS + p.zdymin, zx0 = px0 * p.ZS + p.zdxmin;
-
-        __syncthreads();   // previous tile's fragment reads are done
-        // ---- stage the source halo (with the producing layer's affine + LeakyReLU) and the Z patch
-#pragma unroll 4
-        for (int i = tid; i < p.s_halo * SPP; i += 256) {
-            const int piece = i % SPP, hp = i / SPP;
-            const int im = __umulhi((unsigned)hp, p.mg_shpi), rem = hp - im * s_hpi;
-            const int hy = __umulhi((unsigned)rem, p.mg_shw), hx = rem - hy * p.SHW;
+        s_inb = 0; z_inb = 0;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int im = s_geo[j] >> 20, hy = (s_geo[j] >> 10) & 1023, hx = s_geo[j] & 1023;
             const int n = img0 + im, sy = sy0 + hy, sx = sx0 + hx;
-            const int c = c_base + piece * PIECE;
-            float v[PIECE];
-#pragma unroll
-            for (int e = 0; e < PIECE; ++e) v[e] = 0.f;
-            if (n < p.N && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW && c < CI) {
-                const bool s1 = c >= p.C0;
-                const T* src = reinterpret_cast<const T*>(s1 ? p.src1 : p.src0);
-                const int Cs = s1 ? p.C1 : p.C0, cc = s1 ? c - p.C0 : c;
-                const float* sc = s1 ? p.sc1 : p.sc0;
-                const float* sh = s1 ? p.sh1 : p.sh0;
-                const float slope = s1 ? p.slope1 : p.slope0;
-                load_piece<T>(src + ((size_t)(n * p.SH + sy) * p.SW + sx) * Cs + cc, v);
-                if (sc != nullptr) {
-#pragma unroll
-                    for (int e = 0; e < PIECE; ++e) v[e] = v[e] * sc[(size_t)n * Cs + cc + e] + sh[(size_t)n * Cs + cc + e];
-                }
-#pragma unroll
-                for (int e = 0; e < PIECE; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
-            }
-            store_piece<T>(reinterpret_cast<T*>(Ss + hp * ROWS_B + piece * 16), v);
+            const bool inb = ((s_exist >> j) & 1u) && s_cok && n < p.N && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;
+            const size_t pix = inb ? (size_t)(n * p.SH + sy) * p.SW + sx : 0;
+            s_img[j] = inb ? n : 0;
+            s_inb |= (inb ? 1u : 0u) << j;
+            sreg[j] = *reinterpret_cast<const u32x4*>(s_ptr + pix * s_Cs + s_cc);
         }
-#pragma unroll 4
-        for (int i = tid; i < p.z_halo * ZPP; i += 256) {
-            const int piece = i % ZPP, hp = i / ZPP;
-            const int im = __umulhi((unsigned)hp, p.mg_zhpi), rem = hp - im * z_hpi;
-            const int hy = __umulhi((unsigned)rem, p.mg_zhw), hx = rem - hy * p.ZHW;
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) {
+            const int im = z_geo[j] >> 20, hy = (z_geo[j] >> 10) & 1023, hx = z_geo[j] & 1023;
             const int n = img0 + im, zy = zy0 + hy, zx = zx0 + hx;
-            const int col = n_base + piece * PIECE;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (n < p.N && zy >= 0 && zy < p.ZH && zx >= 0 && zx < p.ZW && col < p.CO)
-                v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.z) +
-                                                    ((size_t)(n * p.ZH + zy) * p.ZW + zx) * p.ZC + col);
-            *reinterpret_cast<u32x4*>(Zs + hp * ROWZ_B + piece * 16) = v;
+            const bool inb = ((z_exist >> j) & 1u) && z_cok && n < p.N && zy >= 0 && zy < p.ZH && zx >= 0 && zx < p.ZW;
+            const size_t pix = inb ? (size_t)(n * p.ZH + zy) * p.ZW + zx : 0;
+            z_inb |= (inb ? 1u : 0u) << j;
+            zreg[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.z) + pix * p.ZC + z_cc);
         }
+    };
+
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            if ((s_exist >> j) & 1u) {
+                u32x4 v = sreg[j];
+                const bool inb = (s_inb >> j) & 1u;
+                if constexpr (!PLAIN) {
+                    float f[PIECE];
+                    if constexpr (PIECE == 8) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            f[2 * e] = __uint_as_float(v[e] << 16);
+                            f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] = __uint_as_float(v[e]);
+                    }
+                    if (s_sc != nullptr) {
+                        const float* scp = s_sc + (size_t)s_img[j] * s_Cs + s_cc;
+                        const float* shp = s_sh + (size_t)s_img[j] * s_Cs + s_cc;
+#pragma unroll
+                        for (int e = 0; e < PIECE; ++e) f[e] = f[e] * scp[e] + shp[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < PIECE; ++e) f[e] = f[e] > 0.f ? f[e] : f[e] * s_slope;
+                    if constexpr (PIECE == 8) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = (unsigned)f32_to_bf16(f[2 * e]) | ((unsigned)f32_to_bf16(f[2 * e + 1]) << 16);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(f[e]);
+                    }
+                }
+                if (!inb) v = u32x4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(Ss + s_lds[j]) = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) {
+            if ((z_exist >> j) & 1u) {
+                u32x4 v = zreg[j];
+                if (!((z_inb >> j) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(Zs + z_lds[j]) = v;
+            }
+        }
+    };
+
+    int tile = blockIdx.y;
+    if (tile < p.ntiles) prefetch(tile);
+    for (; tile < p.ntiles; tile += p.splits) {
+        __syncthreads();   // previous tile's fragment reads are done
+        commit();
         __syncthreads();
+        if (tile + p.splits < p.ntiles) prefetch(tile + p.splits);   // flies under this tile's MFMAs
         if (!wave_active) continue;
 
         const int NK = p.tile_px / KPIX;
@@ -197,14 +278,14 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
     }
 }
 
-template <typename T, int NBLK, int CBLK>
-int launch(WgKArgs& a, hipStream_t st) {
+template <typename T, int NBLK, int CBLK, int NS, int NZ, bool PLAIN>
+int launch_k(WgKArgs& a, hipStream_t st) {
     constexpr int TN = 32 * NBLK, TC = 32 * CBLK;
     constexpr int ROWS_B = (sizeof(T) == 2) ? (TC == 32 ? 64 : 192) : TC * 4 + 16;
     constexpr int ROWZ_B = (sizeof(T) == 2) ? (TN == 32 ? 64 : 192) : TN * 4 + 16;
     const size_t lds = (size_t)a.s_halo * ROWS_B + (size_t)a.z_halo * ROWZ_B;
     CU_CHECK_ARG(lds <= 160 * 1024, "cu_conv_wgrad: LDS %zu bytes exceeds 160 KiB", lds);
-    auto k = igemm_wgrad_kernel<T, NBLK, CBLK>;
+    auto k = igemm_wgrad_kernel<T, NBLK, CBLK, NS, NZ, PLAIN>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
@@ -253,6 +334,9 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
     const int rows_b = d->dtype == CU_BF16 ? (wc ? 192 : 64) : (wc ? 64 : 32) * 4 + 16;
     const int rowz_b = d->dtype == CU_BF16 ? (wn ? 192 : 64) : (wn ? 64 : 32) * 4 + 16;
     const int kpix = d->dtype == CU_BF16 ? 16 : 2;
+    const int piece_elems = d->dtype == CU_BF16 ? 8 : 4;
+    const int ns_small = d->dtype == CU_BF16 ? 7 : 13, nz_small = d->dtype == CU_BF16 ? 4 : 8;
+    const int ns_big = d->dtype == CU_BF16 ? 11 : 21, nz_big = d->dtype == CU_BF16 ? 8 : 16;
     // loop-pixel tile: 128 pixels (64 for stride-2 gathers: 4x the halo), halved until both staged patches fit in LDS
     int BM = (d->IS > 1 || d->ZS > 1) ? 64 : 128;
     for (;; BM >>= 1) {
@@ -294,21 +378,35 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
             a.tap_w[t] = d->tap_w[t];
             if (a.z_off[t] != a.z_off[0]) a.zsame = 0;
         }
-        if ((size_t)a.s_halo * rows_b + (size_t)a.z_halo * rowz_b <= 150 * 1024) break;
+        const int spp = (wc ? 64 : 32) / piece_elems, zpp = (wn ? 64 : 32) / piece_elems;
+        if ((size_t)a.s_halo * rows_b + (size_t)a.z_halo * rowz_b <= 150 * 1024 && a.s_halo * spp <= 256 * ns_big &&
+            a.z_halo * zpp <= 256 * nz_big)
+            break;
     }
+    const int spp_f = (wc ? 64 : 32) / piece_elems, zpp_f = (wn ? 64 : 32) / piece_elems;
+    const bool small = a.s_halo * spp_f <= 256 * ns_small && a.z_halo * zpp_f <= 256 * nz_small;
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int CI = d->C0 + d->C1;
-    const bool wide_n = d->CO > 32, wide_c = CI > 32;
+    const bool plain = !scale0 && d->slope0 == 1.0f && (d->C1 == 0 || (!scale1 && d->slope1 == 1.0f));
+#define CU_W(T, NBv, CBv, NSs, NZs, NSb, NZb)                                          \
+    do {                                                                               \
+        if (small) {                                                                   \
+            if (plain) return launch_k<T, NBv, CBv, NSs, NZs, true>(a, st);            \
+            return launch_k<T, NBv, CBv, NSs, NZs, false>(a, st);                      \
+        }                                                                              \
+        if (plain) return launch_k<T, NBv, CBv, NSb, NZb, true>(a, st);                \
+        return launch_k<T, NBv, CBv, NSb, NZb, false>(a, st);                          \
+    } while (0)
     if (d->dtype == CU_BF16) {
-        if (wide_n && wide_c) return launch<bf16_t, 2, 2>(a, st);
-        if (wide_n) return launch<bf16_t, 2, 1>(a, st);
-        if (wide_c) return launch<bf16_t, 1, 2>(a, st);
-        return launch<bf16_t, 1, 1>(a, st);
+        if (wn && wc) CU_W(bf16_t, 2, 2, 7, 4, 11, 8);
+        if (wn) CU_W(bf16_t, 2, 1, 7, 4, 11, 8);
+        if (wc) CU_W(bf16_t, 1, 2, 7, 4, 11, 8);
+        CU_W(bf16_t, 1, 1, 7, 4, 11, 8);
     } else {
-        if (wide_n && wide_c) return launch<float, 2, 2>(a, st);
-        if (wide_n) return launch<float, 2, 1>(a, st);
-        if (wide_c) return launch<float, 1, 2>(a, st);
-        return launch<float, 1, 1>(a, st);
+        if (wn && wc) CU_W(float, 2, 2, 13, 8, 21, 16);
+        if (wn) CU_W(float, 2, 1, 13, 8, 21, 16);
+        if (wc) CU_W(float, 1, 2, 13, 8, 21, 16);
+        CU_W(float, 1, 1, 13, 8, 21, 16);
     }
+#undef CU_W
 }

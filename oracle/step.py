@@ -42,18 +42,20 @@ class OracleTask:
         params = list(self.sd.values()) + list(self.skew_sd.values())
         self.opt = torch.optim.Adam(params, lr=lr, weight_decay=weight_decay)
 
-    def forward_loss(self, img: Tensor, contour: Tensor) -> Dict[str, Tensor]:
+    def forward_loss(self, img: Tensor, contour: Tensor, masks=None, round_bf16: bool = False) -> Dict[str, Tensor]:
+        """masks / round_bf16: test aids, see oracle.unet._LeakyGivenMask / _RoundBf16."""
         if self.skew:
-            logits, feats = U.unet_forward(self.sd, img, self.spec, bottleneck_out=True)
+            logits, feats = U.unet_forward(self.sd, img, self.spec, bottleneck_out=True, masks=masks,
+                                           round_bf16=round_bf16)
             a = U.confidence_forward(self.skew_sd, feats)
             alpha = H.scatter_alpha(a, self.spec.num_classes, self.skew_indices)
             return H.dsnt_skew_loss(logits, alpha, contour, self.covar)
-        logits = U.unet_forward(self.sd, img, self.spec)
+        logits = U.unet_forward(self.sd, img, self.spec, masks=masks, round_bf16=round_bf16)
         return H.dsnt_al_loss(logits, contour, self.covar, self.mse_weight, self.log_penalty_weight)
 
-    def train_step(self, img: Tensor, contour: Tensor) -> Dict[str, float]:
+    def train_step(self, img: Tensor, contour: Tensor, masks=None) -> Dict[str, float]:
         self.opt.zero_grad(set_to_none=True)
-        logs = self.forward_loss(img, contour)
+        logs = self.forward_loss(img, contour, masks=masks)
         logs["loss"].backward()
         self.opt.step()
         return {k: float(v.detach()) for k, v in logs.items()}

@@ -131,46 +131,94 @@ def init_confidence_state(output_size: int, generator: Optional[torch.Generator]
 
 
 # --------------------------------------------------------------------------- forward
+class _LeakyGivenMask(torch.autograd.Function):
+    """LeakyReLU whose BACKWARD uses a given sign pattern.  Test aid: the derivative of LeakyReLU is discontinuous at 0,
+    so two correct implementations whose pre-activations differ by one ulp disagree by a factor 1/slope on that element.
+    Feeding the device's own sign pattern makes gradient comparisons exact everywhere else."""
+
+    @staticmethod
+    def forward(ctx, x, mask, slope):
+        ctx.save_for_backward(mask)
+        ctx.slope = slope
+        return torch.where(x > 0, x, x * slope)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return torch.where(mask, g, g * ctx.slope), None, None
+
+
+class _RoundBf16(torch.autograd.Function):
+    """x -> bf16 -> f32 in forward and the same rounding of the gradient in backward: what storing an activation and
+    its gradient in bf16 does (used to calibrate the production mode's expected noise)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
 def conv_layer(sd, prefix: str, x: Tensor, stride: int, spec: UNetSpec, drop_mask: Optional[Tensor] = None,
-               taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
+               taps: Optional[Dict[str, Tensor]] = None, masks: Optional[Dict[str, Tensor]] = None,
+               round_bf16: bool = False) -> Tensor:
     """layers.py:199-205: conv(3x3, pad 1, bias) -> [dropout2d] -> InstanceNorm2d(affine) -> LeakyReLU."""
-    y = F.conv2d(x, sd[f"{prefix}.conv.weight"], sd[f"{prefix}.conv.bias"], stride=stride, padding=1)
+    w = sd[f"{prefix}.conv.weight"]
+    if round_bf16:
+        w = _RoundBf16.apply(w)
+    y = F.conv2d(x, w, sd[f"{prefix}.conv.bias"], stride=stride, padding=1)
     if drop_mask is not None:          # Dropout2d(p=.5): whole channels zeroed, survivors x2 (layers.py:154-164)
         y = y * drop_mask
+    if round_bf16:
+        y = _RoundBf16.apply(y)
     if taps is not None:
         taps[f"{prefix}:z"] = y
     y = F.instance_norm(y, weight=sd[f"{prefix}.norm.weight"], bias=sd[f"{prefix}.norm.bias"], eps=spec.eps)
-    y = F.leaky_relu(y, spec.negative_slope)
+    if masks is not None:
+        y = _LeakyGivenMask.apply(y, masks[prefix], spec.negative_slope)
+    else:
+        y = F.leaky_relu(y, spec.negative_slope)
+    if round_bf16:
+        y = _RoundBf16.apply(y)
     if taps is not None:
         taps[f"{prefix}:a"] = y
     return y
 
 
-def conv_block(sd, prefix: str, x: Tensor, stride: int, spec: UNetSpec, taps=None) -> Tensor:
+def conv_block(sd, prefix: str, x: Tensor, stride: int, spec: UNetSpec, taps=None, masks=None,
+               round_bf16=False) -> Tensor:
     """layers.py:208-238: two ConvLayers, the first carries the stage stride."""
-    y = conv_layer(sd, f"{prefix}.conv1", x, stride, spec, taps=taps)
-    return conv_layer(sd, f"{prefix}.conv2", y, 1, spec, taps=taps)
+    y = conv_layer(sd, f"{prefix}.conv1", x, stride, spec, taps=taps, masks=masks, round_bf16=round_bf16)
+    return conv_layer(sd, f"{prefix}.conv2", y, 1, spec, taps=taps, masks=masks, round_bf16=round_bf16)
 
 
 def unet_forward(sd: Dict[str, Tensor], x: Tensor, spec: UNetSpec, bottleneck_out: bool = False,
-                 taps: Optional[Dict[str, Tensor]] = None):
+                 taps: Optional[Dict[str, Tensor]] = None, masks: Optional[Dict[str, Tensor]] = None,
+                 round_bf16: bool = False):
     """unet2.py:177-208 (deep supervision / ssn branches are off for the dsnt tasks)."""
-    out = conv_block(sd, "input_block", x, spec.strides[0], spec, taps)
+    out = conv_block(sd, "input_block", x, spec.strides[0], spec, taps, masks, round_bf16)
     enc = [out]
     nd = spec.n_stages - 2
     for i in range(nd):
-        out = conv_block(sd, f"downsamples.{i}", out, spec.strides[i + 1], spec, taps)
+        out = conv_block(sd, f"downsamples.{i}", out, spec.strides[i + 1], spec, taps, masks, round_bf16)
         enc.append(out)
-    out = conv_block(sd, "bottleneck", out, spec.strides[-1], spec, taps)
+    out = conv_block(sd, "bottleneck", out, spec.strides[-1], spec, taps, masks, round_bf16)
     bott = out.clone()
     if taps is not None:
         taps["bottleneck"] = bott
     up_strides = list(spec.strides[1:])[::-1]
     for i, skip in enumerate(reversed(enc)):
         s = up_strides[i]
-        out = F.conv_transpose2d(out, sd[f"upsamples.{i}.transp_conv.weight"], None, stride=s)   # layers.py:415-417
+        wt = sd[f"upsamples.{i}.transp_conv.weight"]
+        if round_bf16:
+            wt = _RoundBf16.apply(wt)
+        out = F.conv_transpose2d(out, wt, None, stride=s)                                          # layers.py:415-417
+        if round_bf16:
+            out = _RoundBf16.apply(out)
         out = torch.cat((out, skip), dim=1)                                                        # layers.py:436
-        out = conv_block(sd, f"upsamples.{i}.conv_block", out, 1, spec, taps)
+        out = conv_block(sd, f"upsamples.{i}.conv_block", out, 1, spec, taps, masks, round_bf16)
         if taps is not None:
             taps[f"upsamples.{i}"] = out
     out = F.conv2d(out, sd["output_block.conv.weight"], None)                                      # layers.py:456-463

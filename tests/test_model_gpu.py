@@ -33,6 +33,12 @@ def make_task(kind, n_stages, size, dtype, **kw):
                seq_psm_path="camus-cont_sequence_psm_11_no_std.npy", t_a=25, t_e=1, covar=True, **kw)
 
 
+def hip_kink_masks(model):
+    """LeakyReLU sign pattern the device used in its last forward (from the materialised activations), per conv layer."""
+    ctx = model.engine._last_ctx
+    return {prefix: (rec.out.a.float() > 0).permute(0, 3, 1, 2).cpu() for prefix, rec in ctx.convs.items()}
+
+
 def small_state():
     spec = OU.UNetSpec(in_channels=1, num_classes=5, strides=(1, 2, 2, 2))
     g = torch.Generator().manual_seed(11)
@@ -78,7 +84,12 @@ def test_unet_small_fwd_bwd_vs_reference_golden(golden_dir):
 @pytest.mark.parametrize("kind", ["dsnt-skew", "dsnt-al"])
 def test_train_steps_vs_reference_golden(golden_dir, kind):
     """BASELINE config c1 shape (6 stages, 64x64, batch 2), f32 parity mode: two full training steps
-    (forward, backward, fused Adam) reproduce the reference-composed step's logged values and updated weights."""
+    (forward, backward, fused Adam).
+      * every logged value of both steps vs the reference-composed step (golden, 3e-4);
+      * the updated weights vs the CPU oracle stepping in lock-step with the device's LeakyReLU sign pattern
+        (LeakyReLU' is discontinuous at 0: a pre-activation of +-1e-7 decided differently by two correct
+        implementations changes that element's gradient 100x, and Adam turns any gradient change into an O(lr) move);
+      * the updated weights vs the golden reference within half of the largest possible Adam move (2 * lr)."""
     g = np.load(golden_dir / "train_step.npz")
     task = make_task(kind, 6, 64, "f32")
     spec = OU.UNetSpec(strides=(1, 2, 2, 2, 2, 2))
@@ -87,10 +98,13 @@ def test_train_steps_vs_reference_golden(golden_dir, kind):
     if kind == "dsnt-skew":
         task.skew_block.load_state_dict(OU.init_confidence_state(42, gen), strict=True)
     task = task.to(DEV)
+    task.model.engine.debug = {}
+    ot = OracleTask(spec, task=kind, seed=0)
     opt = task.configure_optimizers()["optimizer"]
     img, contour = synthetic_batch(2, 64, 21, seed=1234)
     batch = {"img": img.to(DEV), "contour": contour.to(DEV)}
     keys = ["loss", "distance_loss", "loss_term1", "loss_term2", "loss_term3", "alpha_norm"]
+    n_flip = 0
     for it in range(2):
         opt.zero_grad(set_to_none=True)
         out = task.training_step(batch, it)
@@ -101,11 +115,21 @@ def test_train_steps_vs_reference_golden(golden_dir, kind):
         for j, r in enumerate(ref):
             v = float(out[f"train/{keys[j]}"])
             assert abs(v - r) <= 3e-4 * max(1.0, abs(r)), (it, keys[j], v, r)
-    # Adam moves every weight by ~lr per step whatever the gradient's size, so a LeakyReLU kink decided differently by
-    # rounding (|pre-activation| ~ 1e-7) shows up as a fraction of 2*lr = 2e-3: compare at 25 % of the maximum move
+        masks = hip_kink_masks(task.model)
+        taps = {}
+        OU.unet_forward({k: v.detach() for k, v in ot.sd.items()}, img, spec, taps=taps)
+        n_flip += sum(int(((taps[f"{p}:a"] > 0) != m).sum()) for p, m in masks.items())
+        ot.train_step(img, contour, masks=masks)
+    n_act = sum(m.numel() for m in masks.values())
+    # observed ~7e-5 of the decisions: pre-activations within rounding noise of 0 (the 2x2 / 4x4 InstanceNorms
+    # amplify 1e-7 relative differences of the conv outputs to ~1e-4)
+    assert n_flip <= 5e-4 * 2 * n_act, f"{n_flip} sign decisions differ out of {2 * n_act}"
     sd = task.model.state_dict()
-    assert torch.allclose(sd["output_block.conv.weight"].cpu(), T(g[f"{kind}_w_out"]), rtol=0, atol=5e-4)
-    assert torch.allclose(sd["input_block.conv1.conv.weight"].cpu(), T(g[f"{kind}_w_in"]), rtol=0, atol=5e-4)
+    for name in ("output_block.conv.weight", "input_block.conv1.conv.weight", "bottleneck.conv1.conv.weight",
+                 "upsamples.2.transp_conv.weight", "downsamples.1.conv2.norm.weight"):
+        assert torch.allclose(sd[name].cpu(), ot.sd[name].detach(), rtol=1e-3, atol=5e-5), name
+    assert torch.allclose(sd["output_block.conv.weight"].cpu(), T(g[f"{kind}_w_out"]), rtol=0, atol=1e-3)
+    assert torch.allclose(sd["input_block.conv1.conv.weight"].cpu(), T(g[f"{kind}_w_in"]), rtol=0, atol=1e-3)
 
 
 @pytest.mark.parametrize("kind", ["dsnt-skew", "dsnt-al"])
@@ -161,49 +185,66 @@ def test_full_size_forward_vs_reference_golden(golden_dir):
 
 
 def test_bf16_step_tracks_f32(golden_dir):
-    """Production mode (bf16 MFMA, f32 accumulate): same step as above; the NLL and the gradient direction must track
-    the f32 parity mode ("contour-NLL vs ref" of BASELINE.json's metric)."""
-    res = {}
-    for dtype in ("f32", "bf16"):
-        task = make_task("dsnt-skew", 6, 64, dtype)
-        spec = OU.UNetSpec(strides=(1, 2, 2, 2, 2, 2))
-        gen = torch.Generator().manual_seed(0)
-        task.model.load_state_dict(OU.init_unet_state(spec, gen), strict=True)
-        task.skew_block.load_state_dict(OU.init_confidence_state(42, gen), strict=True)
-        task = task.to(DEV)
-        img, contour = synthetic_batch(4, 64, 21, seed=1234)
-        out = task.training_step({"img": img.to(DEV), "contour": contour.to(DEV)}, 0)
-        out["loss"].backward()
-        flat, grad = task.model.flat_params()
-        res[dtype] = (float(out["loss"]), grad.clone())
-    lf, gf = res["f32"]
-    lb, gb = res["bf16"]
-    assert abs(lb - lf) < 0.05 * abs(lf), (lb, lf)
-    cos = float(torch.dot(gf, gb) / (gf.norm() * gb.norm()))
-    assert cos > 0.98, cos
+    """Production mode (bf16 operands, activations and activation gradients; f32 accumulate, statistics, weights):
+    "contour-NLL vs ref" of BASELINE.json's metric.  The loss must agree with the f32 parity mode to 1e-3, and the
+    gradient noise must be what bf16 storage itself causes: per layer, the device's error w.r.t. the f32 gradient is
+    compared with a CPU simulation that only rounds the same tensors to bf16 (oracle.unet._RoundBf16).  (At random
+    init this network amplifies rounding noise strongly through its 2x2 / 4x4 InstanceNorms: ~3 % at the output layer,
+    ~75 % at the first layer -- for the simulation and for the kernels alike.)"""
+    spec = OU.UNetSpec(strides=(1, 2, 2, 2, 2, 2))
+    img, contour = synthetic_batch(4, 64, 21, seed=1234)
+    ot = OracleTask(spec, task="dsnt-skew", seed=0)
+    ref = ot.forward_loss(img, contour)
+    ref["loss"].backward()
+    g32 = {k: v.grad.clone() for k, v in ot.sd.items() if v.grad is not None}
+    ot2 = OracleTask(spec, task="dsnt-skew", seed=0)
+    sim = ot2.forward_loss(img, contour, round_bf16=True)
+    sim["loss"].backward()
+    task = make_task("dsnt-skew", 6, 64, "bf16")
+    task.model.load_state_dict({k: v.detach() for k, v in ot.sd.items()}, strict=True)
+    task.skew_block.load_state_dict({k: v.detach() for k, v in ot.skew_sd.items()}, strict=True)
+    task = task.to(DEV)
+    out = task.training_step({"img": img.to(DEV), "contour": contour.to(DEV)}, 0)
+    out["loss"].backward()
+    assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-3 * abs(float(ref["loss"]))
+    params = dict(task.model.named_parameters())
+    for name in ("output_block.conv.weight", "upsamples.4.conv_block.conv2.conv.weight",
+                 "upsamples.3.conv_block.conv1.conv.weight", "upsamples.1.transp_conv.weight",
+                 "bottleneck.conv1.conv.weight", "downsamples.1.conv1.conv.weight", "input_block.conv2.conv.weight"):
+        truth = g32[name]
+        e_hip = float((params[name].grad.cpu() - truth).norm() / truth.norm())
+        e_sim = float((ot2.sd[name].grad - truth).norm() / truth.norm())
+        assert e_hip <= 1.6 * e_sim + 0.02, (name, e_hip, e_sim)
 
 
 def test_oracle_vs_hip_larger_batch():
     """Oracle (CPU) and HIP f32 path on the same seeded inputs at a size the oracle finishes in seconds: 6 stages,
-    64x64, batch 6 (not a multiple of the tile's image count), dsnt-al2 branch (covar=True) and covar=False."""
+    64x64, batch 6 (not a multiple of the tile's image count), dsnt-al2 branch (covar=True) and covar=False.
+    Every parameter gradient is compared; the oracle's backward is given the device's LeakyReLU sign pattern (see
+    test_train_steps_vs_reference_golden) and the number of differing sign decisions is bounded separately."""
     spec = OU.UNetSpec(strides=(1, 2, 2, 2, 2, 2))
     img, contour = synthetic_batch(6, 64, 21, seed=99)
     for covar in (True, False):
         ot = OracleTask(spec, task="dsnt-al", covar=covar, seed=3)
-        ref = ot.forward_loss(img, contour)
-        ref["loss"].backward()
         task = make_task("dsnt-al", 6, 64, "f32")
         task.hparams.covar = covar
         task.model.load_state_dict({k: v.detach() for k, v in ot.sd.items()}, strict=True)
         task = task.to(DEV)
+        task.model.engine.debug = {}
         out = task._shared_step({"img": img.to(DEV), "contour": contour.to(DEV)}, 0)
         out["loss"].backward()
+        masks = hip_kink_masks(task.model)
+        taps = {}
+        ref = ot.forward_loss(img, contour, masks=masks)
+        ref["loss"].backward()
         for k in ("loss", "distance_loss", "loss_term1", "loss_term2"):
             assert abs(float(out[k]) - float(ref[k])) <= 2e-4 * max(1.0, abs(float(ref[k]))), (covar, k)
         params = dict(task.model.named_parameters())
-        for name in ("output_block.conv.weight", "upsamples.0.transp_conv.weight", "bottleneck.conv1.conv.weight",
-                     "downsamples.0.conv1.conv.weight", "input_block.conv1.conv.weight",
-                     "upsamples.4.conv_block.conv1.conv.weight", "input_block.conv2.norm.weight"):
-            a, b = params[name].grad.cpu(), ot.sd[name].grad
-            err = float((a - b).norm() / b.norm())
-            assert err < 2e-3, (covar, name, err)
+        worst = 0.0
+        for name, p in params.items():
+            if p.grad is None or (name.endswith("conv.bias")):
+                continue
+            b = ot.sd[name].grad
+            err = float((p.grad.cpu() - b).norm() / b.norm())
+            worst = max(worst, err)
+            assert err < 5e-4, (covar, name, err)

@@ -1,0 +1,127 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/contour_hip.h declares (no compute calls),
+the drop-in classes keep the reference's names / shapes / hparams surface, and the product path fails loudly without a
+GPU instead of falling back."""
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet as OU
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def declared_symbols():
+    text = (ROOT / "include" / "contour_hip.h").read_text()
+    return sorted(set(re.findall(r"\b(cu_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cu_hip import lib
+    handle = lib.load()
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(handle, n), f"libcontour_hip.so lacks {n}"
+    assert sorted(lib.exported_symbols()) == names, "ctypes table and header disagree"
+    assert handle.cu_arch().decode() == "gfx950"
+    assert handle.cu_version() >= 100
+
+
+def test_bad_arguments_return_error_codes_not_crashes():
+    from cu_hip import lib
+    h = lib.load()
+    assert h.cu_conv_gemm(None, None, None, None, None, None, None, None, None, None, None, None) == -22
+    assert b"null descriptor" in h.cu_last_error()
+    d = lib.ConvDesc()
+    d.dtype = 7
+    assert h.cu_conv_gemm(d, None, None, None, None, None, None, None, None, None, None, None) == -22
+    assert h.cu_dsnt_head_fwd(4, 16, 24, None, 1, None, None, None, None) == -22      # non-square map (utils.py:9)
+    assert b"square" in h.cu_last_error()
+
+
+def _task(kind="dsnt-skew", stages=6, size=64):
+    from contour_uncertainty._compat import DataParameters
+    from contour_uncertainty.task.regression.dsnt.dsnt_al import DSNTAleatoric
+    from contour_uncertainty.task.regression.dsnt.dsnt_skew import DSNTSkew
+    cfg = {"_target_": "contour_uncertainty.models.nnUnet.unet2.UNet", "kernels": [[3, 3]] * stages,
+           "strides": [[1, 1]] + [[2, 2]] * (stages - 1), "patch_size": [256, 256], "drop_block": False,
+           "deep_supervision": False}
+    cls = DSNTSkew if kind == "dsnt-skew" else DSNTAleatoric
+    return cls(model=cfg, optim={"_target_": "torch.optim.Adam", "lr": 1e-3, "weight_decay": 1e-3}, choices={"task": kind},
+               data_params=DataParameters((1, size, size), (21, 2), [0, 1]), psm_path="camus-cont_psm_11_no_std.npy",
+               seq_psm_path="camus-cont_sequence_psm_11_no_std.npy", sequence_sampler=False, t_a=25, t_e=1,
+               log_figures=False, task_name="x", some_future_yaml_key=123)
+
+
+def test_state_dict_matches_reference_names_and_shapes(golden_dir):
+    task = _task("dsnt-skew", stages=8, size=256)
+    sd = task.state_dict()
+    ref_names = [str(n) for n in np.load(golden_dir / "unet_full.npz")["param_names"]]
+    assert [k[len("model."):] for k in sd if k.startswith("model.")] == ref_names
+    shapes = OU.param_shapes(OU.UNetSpec())
+    for k, shp in shapes.items():
+        assert tuple(sd["model." + k].shape) == tuple(shp), k
+    skew = {k[len("skew_block."):]: tuple(v.shape) for k, v in sd.items() if k.startswith("skew_block.")}
+    assert skew == {k: tuple(v) for k, v in OU.confidence_param_shapes(42).items()}
+    assert sum(v.numel() for k, v in sd.items() if k.startswith("model.")) == 41298912
+    # reference-shaped weights load strictly
+    g = torch.Generator().manual_seed(0)
+    task.model.load_state_dict(OU.init_unet_state(OU.UNetSpec(), g), strict=True)
+
+
+def test_hparams_and_optimizer_surface():
+    task = _task("dsnt-al")
+    hp = task.hparams
+    for key in ("model", "optim", "choices", "data_params", "covar", "mse_weight", "log_penalty_weight", "iterations",
+                "psm_path", "seq_psm_path", "sequence_sampler", "t_a", "t_e", "train_ensemble", "ensemble_ckpt",
+                "log_figures", "task_name", "some_future_yaml_key"):
+        assert key in hp, key
+    assert hp.covar is True and hp.t_a == 25 and hp.some_future_yaml_key == 123
+    opt = task.configure_optimizers()
+    assert set(opt.keys()) == {"optimizer"}
+    from cu_hip.optim import FusedAdam
+    assert isinstance(opt["optimizer"], FusedAdam)
+    assert opt["optimizer"].defaults["lr"] == 1e-3 and opt["optimizer"].defaults["weight_decay"] == 1e-3
+    s = task.get_cov_matrix(torch.ones(2, 21), 2 * torch.ones(2, 21), 0.5 * torch.ones(2, 21))
+    assert s.shape == (2, 21, 2, 2) and float(s[0, 0, 0, 1]) == 0.5 and float(s[0, 0, 1, 1]) == 2.0
+
+
+def test_unsupported_reference_options_are_refused_not_ignored():
+    from contour_uncertainty.models.nnUnet.unet2 import UNet
+    for kw in ({"attention": True}, {"residual": True}, {"deep_supervision": True}, {"ssn_rank": 5},
+               {"normalization_layer": "batch"}):
+        with pytest.raises(NotImplementedError):
+            UNet((1, 64, 64), (21, 1, 64), [256, 256], [[3, 3]] * 6, [[1, 1]] + [[2, 2]] * 5, **kw)
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly when there is no GPU (or the tensor is not on it)."""
+    from cu_hip.lib import ContourHipError
+    task = _task("dsnt-al")
+    batch = {"img": torch.rand(2, 1, 64, 64), "contour": torch.rand(2, 21, 2) * 60}
+    with pytest.raises(ContourHipError):
+        task.training_step(batch, 0)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = ROOT / "contouring-uncertainty_amd"
+    for f in pkg.rglob("*.py"):
+        text = f.read_text()
+        assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_validation_mask_and_dice_helpers():
+    from contour_uncertainty.utils.contour import contour_to_mask, linear_reconstruction
+    from contour_uncertainty.utils.metrics import Dice
+    t = np.linspace(0, 2 * np.pi, 21, endpoint=False)
+    c = np.stack([32 + 12 * np.cos(t), 30 + 9 * np.sin(t)], -1)
+    m = linear_reconstruction(c, (64, 64))
+    area = np.pi * 12 * 9
+    assert abs(m.sum() - area) / area < 0.08
+    assert m[30, 32] and not m[5, 5]
+    d = Dice(labels=[0, 1])
+    assert d(m.astype(int)[None], m.astype(int)[None]) == 1.0
+    assert contour_to_mask(c, (64, 64), apply_argmax=False).shape == (1, 64, 64)

@@ -1,0 +1,111 @@
+"""N > 1 path on CPU: 2 ranks over gloo exercise the bucketed gradient exchange (cu_hip.ddp) with the real U-Net
+parameter inventory and the kernel schedule's completion order."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+for p in (str(ROOT), str(ROOT / "contouring-uncertainty_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _completion_order(names):
+    """Layer prefixes in the order UNetEngine.backward reports them (decoder first)."""
+    prefixes = []
+    for n in names:
+        if n.endswith("conv.weight") and "conv_block" in n or (n.endswith("conv.weight") and n.count(".") == 3):
+            pass
+    layers = []
+    for n in names:
+        parts = n.split(".")
+        if parts[-2:] == ["conv", "weight"] and parts[0] != "output_block":
+            layers.append(".".join(parts[:-2]))
+        elif parts[-2] == "transp_conv":
+            layers.append(".".join(parts[:-1]))
+    layers.append("output_block")
+    # forward order -> backward order: output, then blocks reversed with conv2 before conv1 and transp_conv last
+    return list(reversed(layers))
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cu_hip.ddp import BucketedAllReduce, prefix_ranges
+        from oracle.unet import UNetSpec, param_shapes
+        spec = UNetSpec(strides=(1, 2, 2, 2, 2, 2))
+        shapes = {k: v for k, v in param_shapes(spec).items() if not k.startswith("deep_supervision")}
+        names = list(shapes)
+        sizes = [int(torch.tensor(s).prod()) for s in shapes.values()]
+        total = sum(sizes)
+        ranges = prefix_ranges(names, sizes)
+        g = torch.Generator().manual_seed(100 + rank)
+        flat = torch.randn(total, generator=g)
+        mine = flat.clone()
+        bar = BucketedAllReduce(total, bucket_elems=1 << 20)
+        bar.begin(flat)
+        for prefix in _completion_order(names):
+            lo, hi = ranges[prefix]
+            bar.ready(lo, hi)
+        bar.finish()
+        # expected: sum over ranks
+        other = torch.randn(total, generator=torch.Generator().manual_seed(100 + (1 - rank)))
+        ok = torch.allclose(flat, mine + other, atol=1e-6)
+        covered = sorted(bar.launched)
+        contiguous = covered[0][0] == 0 and covered[-1][1] == total and all(
+            covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+        several = len(covered) >= 3
+        ret[rank] = (bool(ok), bool(contiguous), bool(several), len(covered))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_two_ranks_gloo():
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert len(ret) == 2
+    for rank in (0, 1):
+        ok, contiguous, several, n = ret[rank]
+        assert ok, "all-reduced gradient != sum of the ranks' gradients"
+        assert contiguous, "buckets do not tile the flat gradient buffer exactly once"
+        assert several, f"expected several buckets for overlap, got {n}"
+
+
+def test_prefix_ranges_cover_layers():
+    from cu_hip.ddp import prefix_ranges
+    names = ["input_block.conv1.conv.weight", "input_block.conv1.conv.bias", "input_block.conv1.norm.weight",
+             "input_block.conv1.norm.bias", "upsamples.0.transp_conv.weight", "output_block.conv.weight"]
+    sizes = [288, 32, 32, 32, 1000, 672]
+    r = prefix_ranges(names, sizes)
+    assert r["input_block.conv1"] == (0, 384)
+    assert r["upsamples.0.transp_conv"] == (384, 1384)
+    assert r["output_block"] == (1384, 2056)
+
+
+def test_single_rank_needs_no_process_group():
+    from cu_hip.ddp import BucketedAllReduce
+    flat = torch.arange(10.0)
+    bar = BucketedAllReduce(10, bucket_elems=4)
+    bar.begin(flat)
+    bar.ready(6, 10)
+    bar.ready(2, 6)
+    bar.finish()
+    assert sorted(bar.launched) == [(0, 2), (2, 6), (6, 10)]
+    assert torch.equal(flat, torch.arange(10.0))

@@ -369,15 +369,55 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvKArgs p) {
         for (int a = 0; a < MA; ++a) {
             const int n = cur_img0 + pim[a];
             const int py = py0 + pty[a], px = px0 + ptx[a];
-            if (pim[a] >= p.imgs || n >= p.N || py >= p.PH || px >= p.PW || (p.dbg & 1)) continue;
+            const bool pvalid = !(pim[a] >= p.imgs || n >= p.N || py >= p.PH || px >= p.PW || (p.dbg & 1));
             const int oy = py * p.OS + p.OY0, ox = px * p.OS + p.OX0;
-            const size_t opix = ((size_t)n * p.OH + oy) * p.OW + ox;
+            const size_t opix = pvalid ? ((size_t)n * p.OH + oy) * p.OW + ox : 0;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
+                const int colb = n0 + b * 32;
+                if (colb >= p.CO) continue;                       // uniform
+                const bool d1 = colb >= p.D0;
+                const int accum = d1 ? p.accum1 : p.accum0;
+                if constexpr (sizeof(T) == 2) {
+                    if (!p.out_nchw && !accum) {
+                        // bf16 fast path: lanes l and l+32 hold interleaved channel quads of the same pixel; two
+                        // v_permlane32_swap per quad pair give each lane 16 CONSECUTIVE channels -> two 16-byte stores
+                        // (cdna_hip_programming.md T21).  EXEC is full here; only the stores are predicated.
+                        unsigned q[4][2];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e];
+                            if (p.bias) {
+                                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + colb + 8 * g + 4 * h);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                            }
+                            q[g][0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                            q[g][1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                        }
+#pragma unroll
+                        for (int w2 = 0; w2 < 2; ++w2) {
+                            auto r02 = __builtin_amdgcn_permlane32_swap(q[0][w2], q[2][w2], false, false);
+                            q[0][w2] = r02[0]; q[2][w2] = r02[1];
+                            auto r13 = __builtin_amdgcn_permlane32_swap(q[1][w2], q[3][w2], false, false);
+                            q[1][w2] = r13[0]; q[3][w2] = r13[1];
+                        }
+                        if (pvalid) {
+                            const int dcol = (d1 ? colb - p.D0 : colb) + 16 * h;
+                            const int DC = d1 ? p.DC1 : p.DC0;
+                            bf16_t* o = reinterpret_cast<bf16_t*>(d1 ? p.dst1 : p.dst0) + opix * DC + dcol;
+                            *reinterpret_cast<u32x4*>(o) = u32x4{q[0][0], q[0][1], q[2][0], q[2][1]};
+                            *reinterpret_cast<u32x4*>(o + 8) = u32x4{q[1][0], q[1][1], q[3][0], q[3][1]};
+                        }
+                        continue;
+                    }
+                }
+                if (!pvalid) continue;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int col = n0 + b * 32 + 8 * g + 4 * h;
-                    if (col >= p.CO) continue;
+                    const int col = colb + 8 * g + 4 * h;
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e];
@@ -396,10 +436,8 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvKArgs p) {
                             }
                         }
                     } else {
-                        const bool d1 = col >= p.D0;
                         const int dcol = d1 ? col - p.D0 : col;
                         const int DC = d1 ? p.DC1 : p.DC0;
-                        const int accum = d1 ? p.accum1 : p.accum0;
                         T* o = reinterpret_cast<T*>(d1 ? p.dst1 : p.dst0) + opix * DC + dcol;
                         if constexpr (sizeof(T) == 2) {
                             if (accum) {

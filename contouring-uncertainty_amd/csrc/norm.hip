@@ -26,11 +26,46 @@ static inline RowMap row_map(int C, int piece) {
 }
 
 // Block-level reduction over pixel rows of per-thread partials v[NV][PIECE]; result lands in thread (prow == 0).
+// When tpp (threads per pixel) divides the wave, lanes l, l+tpp, l+2tpp ... hold the same channel piece: butterfly
+// shuffles reduce the wave, then 4 LDS rows combine the waves.  (The first version let `tpp` threads sum up to 64 LDS
+// rows serially, which dominated these HBM-bound kernels.)
 template <int NV, int PIECE>
 __device__ __forceinline__ void reduce_rows(float (&v)[NV][PIECE], float* lds, int piece, int prow, int rows, int tpp,
                                             bool active) {
-    // lds: [rows][tpp][NV*PIECE]
     const int stride = NV * PIECE;
+    const bool pow2 = (tpp & (tpp - 1)) == 0 && tpp <= 32;
+    if (pow2) {       // uniform; every thread of the block is active when tpp divides 256
+        for (int off = tpp; off < 64; off <<= 1) {
+#pragma unroll
+            for (int a = 0; a < NV; ++a)
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) v[a][e] += __shfl_xor(v[a][e], off, 64);
+        }
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane < tpp) {
+            float* d = lds + ((size_t)wave * tpp + lane) * stride;
+#pragma unroll
+            for (int a = 0; a < NV; ++a)
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) d[a * PIECE + e] = v[a][e];
+        }
+        __syncthreads();
+        if (prow == 0) {      // threads 0 .. tpp-1 (wave 0, lane == piece)
+#pragma unroll
+            for (int a = 0; a < NV; ++a)
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) v[a][e] = 0.f;
+            for (int w = 0; w < NT / 64; ++w) {
+                const float* s = lds + ((size_t)w * tpp + piece) * stride;
+#pragma unroll
+                for (int a = 0; a < NV; ++a)
+#pragma unroll
+                    for (int e = 0; e < PIECE; ++e) v[a][e] += s[a * PIECE + e];
+            }
+        }
+        return;
+    }
+    // general case (C = 480: 60 or 120 pieces, 4 or 2 rows): lds[rows][tpp][NV*PIECE]
     if (active) {
         float* d = lds + ((size_t)prow * tpp + piece) * stride;
 #pragma unroll
@@ -68,7 +103,22 @@ __global__ __launch_bounds__(NT) void stats_partial_kernel(const T* __restrict__
         const T* base = z + (size_t)n * HW * C + piece * PIECE;
         float k[PIECE];
         load_piece<T>(base, k);   // shift by the image's first pixel: avoids E[x^2]-E[x]^2 cancellation
-        for (int p = p0 + prow; p < p1; p += rows) {
+        // 4 independent 16-byte loads in flight per thread (the loop is latency-bound otherwise)
+        int p = p0 + prow;
+        for (; p + 3 * rows < p1; p += 4 * rows) {
+            float v[4][PIECE];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load_piece<T>(base + (size_t)(p + u * rows) * C, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) {
+                    const float d = v[u][e] - k[e];
+                    acc[0][e] += d;
+                    acc[1][e] += d * d;
+                }
+        }
+        for (; p < p1; p += rows) {
             float v[PIECE];
             load_piece<T>(base + (size_t)p * C, v);
 #pragma unroll
@@ -129,7 +179,22 @@ __global__ __launch_bounds__(NT) void apply_kernel(const T* __restrict__ z, cons
 #pragma unroll
     for (int e = 0; e < PIECE; ++e) { sc[e] = stats[2 * NC + sidx + e]; sh[e] = stats[3 * NC + sidx + e]; }
     const size_t base = (size_t)n * HW * C + piece * PIECE;
-    for (int p = p0 + prow; p < p1; p += rows) {
+    int p = p0 + prow;
+    for (; p + 3 * rows < p1; p += 4 * rows) {
+        float v[4][PIECE];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load_piece<T>(z + base + (size_t)(p + u * rows) * C, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) {
+                const float y = v[u][e] * sc[e] + sh[e];
+                v[u][e] = y > 0.f ? y : y * slope;
+            }
+            store_piece<T>(out + base + (size_t)(p + u * rows) * C, v[u]);
+        }
+    }
+    for (; p < p1; p += rows) {
         float v[PIECE];
         load_piece<T>(z + base + (size_t)p * C, v);
 #pragma unroll
@@ -166,7 +231,25 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const T* __restrict__ g,
             sc[e] = stats[2 * NC + sidx + e]; sh[e] = stats[3 * NC + sidx + e];
         }
         const size_t base = (size_t)n * HW * C + piece * PIECE;
-        for (int p = p0 + prow; p < p1; p += rows) {
+        int p = p0 + prow;
+        for (; p + rows < p1; p += 2 * rows) {
+            float zv[2][PIECE], gv[2][PIECE];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                load_piece<T>(z + base + (size_t)(p + u * rows) * C, zv[u]);
+                load_piece<T>(g + base + (size_t)(p + u * rows) * C, gv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) {
+                    const float y = zv[u][e] * sc[e] + sh[e];
+                    const float gl = y > 0.f ? gv[u][e] : gv[u][e] * slope;
+                    acc[0][e] += gl;
+                    acc[1][e] += gl * (zv[u][e] - mean[e]) * rstd[e];
+                }
+        }
+        for (; p < p1; p += rows) {
             float zv[PIECE], gv[PIECE];
             load_piece<T>(z + base + (size_t)p * C, zv);
             load_piece<T>(g + base + (size_t)p * C, gv);
@@ -226,7 +309,28 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(T* __restrict__ g, const 
             }
         }
         const size_t base = (size_t)n * HW * C + piece * PIECE;
-        for (int p = p0 + prow; p < p1; p += rows) {
+        int p = p0 + prow;
+        for (; p + rows < p1; p += 2 * rows) {
+            float zv[2][PIECE], gv[2][PIECE];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                load_piece<T>(z + base + (size_t)(p + u * rows) * C, zv[u]);
+                load_piece<T>(g + base + (size_t)(p + u * rows) * C, gv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) {
+                    const float y = zv[u][e] * sc[e] + sh[e];
+                    const float gl = y > 0.f ? gv[u][e] : gv[u][e] * slope;
+                    const float xh = (zv[u][e] - mean[e]) * rstd[e];
+                    gv[u][e] = gr[e] * (gl - a1[e] - xh * a2[e]);
+                    acc[0][e] += gv[u][e];
+                }
+                store_piece<T>(g + base + (size_t)(p + u * rows) * C, gv[u]);
+            }
+        }
+        for (; p < p1; p += rows) {
             float zv[PIECE], gv[PIECE];
             load_piece<T>(z + base + (size_t)p * C, zv);
             load_piece<T>(g + base + (size_t)p * C, gv);

@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvKArgs p) {
     using C = Cfg<T>;
     constexpr int CK = C::CK, PIECE = C::PIECE, PPP = C::PPP, WPL = C::WPLANES;
     constexpr int BN = 32 * NB;
-    constexpr int NW = (NT * BN * 4 + 255) / 256;     // weight pieces per thread per chunk
+    constexpr int NTCAP = NT > 0 ? NT : 4;            // NT > 0: exactly NT taps, unrolled; NT == 0: <= 4 taps, runtime loop
+    constexpr int NW = (NTCAP * BN * 4 + 255) / 256;  // weight pieces per thread per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -323,42 +324,50 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvKArgs p) {
             }
             }
             const int wbase_units = WRES ? ci * w_chunk_units : 0;
-            if (!(p.dbg & 2))
-            for (int t = 0; t < p.ntaps; ++t) {
+            auto tap_step = [&](int t, int kk) {
                 const int toff = s_tap[t];
+                if constexpr (PIECE == 8) {
+                    const bf16_t* X16 = reinterpret_cast<const bf16_t*>(Xs);
+                    const bf16_t* W16 = reinterpret_cast<const bf16_t*>(Ws);
+                    bf16x8 af[MA], bfr[NB];
 #pragma unroll
-                for (int kk = 0; kk < C::KSTEPS; ++kk) {
-                    if constexpr (PIECE == 8) {
-                        const bf16_t* X16 = reinterpret_cast<const bf16_t*>(Xs);
-                        const bf16_t* W16 = reinterpret_cast<const bf16_t*>(Ws);
-                        bf16x8 af[MA], bfr[NB];
+                    for (int a = 0; a < MA; ++a)
+                        af[a] = *reinterpret_cast<const bf16x8*>(X16 + ((size_t)(2 * kk + h) * p.XP + hpA[a] + toff) * 8);
 #pragma unroll
-                        for (int a = 0; a < MA; ++a)
-                            af[a] = *reinterpret_cast<const bf16x8*>(X16 + ((size_t)(2 * kk + h) * p.XP + hpA[a] + toff) * 8);
+                    for (int b = 0; b < NB; ++b)
+                        bfr[b] = *reinterpret_cast<const bf16x8*>(
+                            W16 + ((size_t)wbase_units + (t * 4 + 2 * kk + h) * p.WP + b * 32 + r) * 8);
 #pragma unroll
-                        for (int b = 0; b < NB; ++b)
-                            bfr[b] = *reinterpret_cast<const bf16x8*>(
-                                W16 + ((size_t)wbase_units + (t * 4 + 2 * kk + h) * p.WP + b * 32 + r) * 8);
-#pragma unroll
-                        for (int a = 0; a < MA; ++a)
-#pragma unroll
-                            for (int b = 0; b < NB; ++b)
-                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
-                    } else {
-                        const float* Xf = reinterpret_cast<const float*>(Xs);
-                        const float* Wf = reinterpret_cast<const float*>(Ws);
-                        float af[MA], bfr[NB];
-#pragma unroll
-                        for (int a = 0; a < MA; ++a) af[a] = Xf[(2 * kk + h) * p.XP + hpA[a] + toff];
+                    for (int a = 0; a < MA; ++a)
 #pragma unroll
                         for (int b = 0; b < NB; ++b)
-                            bfr[b] = Wf[wbase_units + (t * 16 + 2 * kk + h) * p.WP + b * 32 + r];
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
+                } else {
+                    const float* Xf = reinterpret_cast<const float*>(Xs);
+                    const float* Wf = reinterpret_cast<const float*>(Ws);
+                    float af[MA], bfr[NB];
 #pragma unroll
-                        for (int a = 0; a < MA; ++a)
+                    for (int a = 0; a < MA; ++a) af[a] = Xf[(2 * kk + h) * p.XP + hpA[a] + toff];
 #pragma unroll
-                            for (int b = 0; b < NB; ++b)
-                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[b], af[a], acc[a][b], 0, 0, 0);
-                    }
+                    for (int b = 0; b < NB; ++b)
+                        bfr[b] = Wf[wbase_units + (t * 16 + 2 * kk + h) * p.WP + b * 32 + r];
+#pragma unroll
+                    for (int a = 0; a < MA; ++a)
+#pragma unroll
+                        for (int b = 0; b < NB; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[b], af[a], acc[a][b], 0, 0, 0);
+                }
+            };
+            if (!(p.dbg & 2)) {
+                if constexpr (NT > 0) {      // exact tap count: branch-free, the scheduler hoists the fragment reads
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int kk = 0; kk < C::KSTEPS; ++kk) tap_step(t, kk);
+                } else {
+                    for (int t = 0; t < p.ntaps; ++t)
+#pragma unroll
+                        for (int kk = 0; kk < C::KSTEPS; ++kk) tap_step(t, kk);
                 }
             }
         }
@@ -487,7 +496,7 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
     CU_CHECK_ARG(d->dtype == CU_F32 || d->dtype == CU_BF16, "cu_conv_gemm: bad dtype %d", d->dtype);
     const bool bf = d->dtype == CU_BF16;
     const int CK = bf ? 32 : 16;
-    CU_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= CU_MAX_TAPS, "cu_conv_gemm: ntaps %d", d->ntaps);
+    CU_CHECK_ARG(d->ntaps == 9 || (d->ntaps >= 1 && d->ntaps <= 4), "cu_conv_gemm: ntaps must be 9 or <= 4 (got %d)", d->ntaps);
     CU_CHECK_ARG(d->C0 > 0 && d->C0 % CK == 0 && d->C1 >= 0 && d->C1 % CK == 0,
                  "cu_conv_gemm: channel counts %d,%d must be multiples of %d", d->C0, d->C1, CK);
     CU_CHECK_ARG(src0 && w && dst0 && (d->C1 == 0 || src1), "cu_conv_gemm: null pointer");
@@ -534,7 +543,7 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
     // ---- pixel tile: BM = 128*MA loop pixels = IMGS x TH x TW.  MA = 2 (bf16, stride-1 gathers, 3x3) when there is
     //      enough work to keep every CU busy with 256-pixel tiles.
     const long total_px = (long)d->N * d->PH * d->PW;
-    int ma = (bf && d->IS == 1 && d->ntaps > 4 && total_px / 256 * coltiles >= 512) ? 2 : 1;
+    int ma = (bf && d->IS == 1 && d->ntaps == 9 && total_px / 256 * coltiles >= 512) ? 2 : 1;
     int tw = 0, th = 0, imgs = 0;
     for (;; ma = 1) {
         const int BM = 128 * ma;
@@ -587,7 +596,6 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nx = ma == 2 ? 6 : (a.halo_px * 4 > 256 * 4 ? 10 : 4);
-    const bool taps9 = d->ntaps > 4;
     const bool plain = !scale0 && d->slope0 == 1.0f && (d->C1 == 0 || (!scale1 && d->slope1 == 1.0f));
 #define CU_L(T, MAv, NBv, NXv, NTv, WR)                                                              \
     do {                                                                                             \
@@ -597,9 +605,14 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
 #define CU_NXNT(T, NBv, WR)                                       \
     do {                                                          \
         if (ma == 2) CU_L(T, 2, NBv, 6, 9, WR);                   \
-        if (nx == 10) { if (taps9) CU_L(T, 1, NBv, 10, 9, WR); CU_L(T, 1, NBv, 10, 4, WR); } \
-        if (taps9) CU_L(T, 1, NBv, 4, 9, WR);                     \
-        CU_L(T, 1, NBv, 4, 4, WR);                                \
+        if (nx == 10) {                                           \
+            if (d->ntaps == 9) CU_L(T, 1, NBv, 10, 9, WR);        \
+            if (d->ntaps == 4) CU_L(T, 1, NBv, 10, 4, WR);        \
+            CU_L(T, 1, NBv, 10, 0, WR);                           \
+        }                                                         \
+        if (d->ntaps == 9) CU_L(T, 1, NBv, 4, 9, WR);             \
+        if (d->ntaps == 4) CU_L(T, 1, NBv, 4, 4, WR);             \
+        CU_L(T, 1, NBv, 4, 0, WR);                                \
     } while (0)
     if (bf) {
         switch (nb) {

@@ -10,6 +10,8 @@
 // shifts are plain row offsets; f32 parity mode uses v_mfma_f32_32x32x2_f32 with scalar LDS reads.
 // One workgroup owns a (32*NBLK) x (32*CBLK) block of dW for all taps (<= 9 accumulators of 32x32 per wave) and walks
 // pixel tiles split over grid.y; partial sums are added with f32 atomics in 128-byte rows.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -28,6 +30,7 @@ struct WgKArgs {
     unsigned mg_shpi, mg_shw, mg_zhpi, mg_zhw; // ceil(2^32/d) magics for the halo index decode
     float slope0, slope1;
     int zsame;                                 // all taps read the same Z pixel
+    int dbg;                                   // CU_CONV_DBG bits (timing experiments): 1 no atomics, 2 no MFMA, 4 no commit, 8 no loads
 };
 
 template <typename T> struct WCfg;
@@ -44,7 +47,9 @@ __device__ __forceinline__ bf16x4 tr_read(const void* lds_ptr) {
 // clamped address and a mask -- predicated loads are serialised by hipcc).  PLAIN: the source needs no affine /
 // activation (materialised activations): staging is a pure 16-byte copy.  The next tile's loads are issued before
 // the current tile's MFMAs (register prefetch).
-template <typename T, int NBLK, int CBLK, int NS, int NZ, bool PLAIN>
+// NTAPS is compile-time (9 = 3x3, 4 = 2x2 transposed conv, 1 = 1x1): no branches between the taps, so the scheduler
+// issues all fragment reads of a k-step ahead of its MFMAs.
+template <typename T, int NBLK, int CBLK, int NS, int NZ, bool PLAIN, int NTAPS>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
     using C = WCfg<T>;
     constexpr int PIECE = C::PIECE, KPIX = C::KPIX;
@@ -72,9 +77,9 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
     const int s_hpi = p.SHH * p.SHW, z_hpi = p.ZHH * p.ZHW;
     const bool wave_active = (n_base + nblk * 32 < p.CO) && (c_base + cblk * 32 < CI);
 
-    f32x16 acc[CU_MAX_TAPS];
+    f32x16 acc[NTAPS];
 #pragma unroll
-    for (int t = 0; t < CU_MAX_TAPS; ++t)
+    for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
@@ -204,10 +209,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
     if (tile < p.ntiles) prefetch(tile);
     for (; tile < p.ntiles; tile += p.splits) {
         __syncthreads();   // previous tile's fragment reads are done
-        commit();
+        if (!(p.dbg & 4)) commit();
         __syncthreads();
-        if (tile + p.splits < p.ntiles) prefetch(tile + p.splits);   // flies under this tile's MFMAs
-        if (!wave_active) continue;
+        if (tile + p.splits < p.ntiles && !(p.dbg & 8)) prefetch(tile + p.splits);   // flies under this tile's MFMAs
+        if (!wave_active || (p.dbg & 2)) continue;
 
         const int NK = p.tile_px / KPIX;
         for (int ks = kpart; ks < NK; ks += KSPLIT) {
@@ -229,20 +234,23 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
                     const bf16x4 a1 = tr_read(Zs + zbase[1] + p.z_off[0] * ROWZ_B);
                     af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
+                bf16x8 bfr[NTAPS], afr[NTAPS];
 #pragma unroll
-                for (int t = 0; t < CU_MAX_TAPS; ++t) {
-                    if (t < p.ntaps) {
-                        if (!p.zsame) {
-                            const bf16x4 a0 = tr_read(Zs + zbase[0] + p.z_off[t] * ROWZ_B);
-                            const bf16x4 a1 = tr_read(Zs + zbase[1] + p.z_off[t] * ROWZ_B);
-                            af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                        }
-                        const bf16x4 b0 = tr_read(Ss + sbase[0] + p.s_off[t] * ROWS_B);
-                        const bf16x4 b1 = tr_read(Ss + sbase[1] + p.s_off[t] * ROWS_B);
-                        const bf16x8 bfr = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+                for (int t = 0; t < NTAPS; ++t) {
+                    if (!p.zsame) {
+                        const bf16x4 a0 = tr_read(Zs + zbase[0] + p.z_off[t] * ROWZ_B);
+                        const bf16x4 a1 = tr_read(Zs + zbase[1] + p.z_off[t] * ROWZ_B);
+                        afr[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    } else {
+                        afr[t] = af;
                     }
+                    const bf16x4 b0 = tr_read(Ss + sbase[0] + p.s_off[t] * ROWS_B);
+                    const bf16x4 b1 = tr_read(Ss + sbase[1] + p.s_off[t] * ROWS_B);
+                    bfr[t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[t], bfr[t], acc[t], 0, 0, 0);
             } else {
                 const int r = lane & 31, hh = lane >> 5;
                 const int m = ks * 2 + hh;
@@ -250,42 +258,38 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
                 const int sbase = (im * s_hpi + ty * p.IS * p.SHW + tx * p.IS) * ROWS_B + (cblk * 32 + r) * 4;
                 const int zbase = (im * z_hpi + ty * p.ZS * p.ZHW + tx * p.ZS) * ROWZ_B + (nblk * 32 + r) * 4;
 #pragma unroll
-                for (int t = 0; t < CU_MAX_TAPS; ++t) {
-                    if (t < p.ntaps) {
-                        const float a = *reinterpret_cast<const float*>(Zs + zbase + p.z_off[t] * ROWZ_B);
-                        const float b = *reinterpret_cast<const float*>(Ss + sbase + p.s_off[t] * ROWS_B);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-                    }
+                for (int t = 0; t < NTAPS; ++t) {
+                    const float a = *reinterpret_cast<const float*>(Zs + zbase + p.z_off[t] * ROWZ_B);
+                    const float b = *reinterpret_cast<const float*>(Ss + sbase + p.s_off[t] * ROWS_B);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
                 }
             }
         }
     }
 
-    if (!wave_active) return;
+    if (!wave_active || (p.dbg & 1)) return;
     // ---- atomics: col (lane&31) = c, rows = n
     const int r = lane & 31, hh = lane >> 5;
     const int c = c_base + cblk * 32 + r;
     if (c >= CI) return;
 #pragma unroll
-    for (int t = 0; t < CU_MAX_TAPS; ++t) {
-        if (t < p.ntaps) {
+    for (int t = 0; t < NTAPS; ++t) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int n = n_base + nblk * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                if (n < p.CO) unsafeAtomicAdd(p.dw + ((size_t)p.tap_w[t] * p.CO + n) * CI + c, acc[t][i]);
-            }
+        for (int i = 0; i < 16; ++i) {
+            const int n = n_base + nblk * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            if (n < p.CO) unsafeAtomicAdd(p.dw + ((size_t)p.tap_w[t] * p.CO + n) * CI + c, acc[t][i]);
         }
     }
 }
 
-template <typename T, int NBLK, int CBLK, int NS, int NZ, bool PLAIN>
+template <typename T, int NBLK, int CBLK, int NS, int NZ, bool PLAIN, int NTAPS>
 int launch_k(WgKArgs& a, hipStream_t st) {
     constexpr int TN = 32 * NBLK, TC = 32 * CBLK;
     constexpr int ROWS_B = (sizeof(T) == 2) ? (TC == 32 ? 64 : 192) : TC * 4 + 16;
     constexpr int ROWZ_B = (sizeof(T) == 2) ? (TN == 32 ? 64 : 192) : TN * 4 + 16;
     const size_t lds = (size_t)a.s_halo * ROWS_B + (size_t)a.z_halo * ROWZ_B;
     CU_CHECK_ARG(lds <= 160 * 1024, "cu_conv_wgrad: LDS %zu bytes exceeds 160 KiB", lds);
-    auto k = igemm_wgrad_kernel<T, NBLK, CBLK, NS, NZ, PLAIN>;
+    auto k = igemm_wgrad_kernel<T, NBLK, CBLK, NS, NZ, PLAIN, NTAPS>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
@@ -296,7 +300,7 @@ int launch_k(WgKArgs& a, hipStream_t st) {
     const int ntn = cdiv(a.CO, TN);
     if (a.splits <= 0) {
         // enough workgroups to fill 256 CUs a few times over, but never more splits than tiles
-        int want = cdiv(1024, a.ctiles * ntn);
+        int want = cdiv(512, a.ctiles * ntn);      // ~2 workgroups per CU: every extra split re-adds the whole dW tile atomically
         a.splits = want < 1 ? 1 : want;
     }
     if (a.splits > a.ntiles) a.splits = a.ntiles;
@@ -328,6 +332,7 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
     a.N = d->N; a.PH = d->PH; a.PW = d->PW; a.SH = d->SH; a.SW = d->SW; a.C0 = d->C0; a.C1 = d->C1; a.IS = d->IS;
     a.ZH = d->ZH; a.ZW = d->ZW; a.ZC = d->ZC; a.ZS = d->ZS; a.CO = d->CO; a.ntaps = d->ntaps;
     a.slope0 = d->slope0; a.slope1 = d->slope1; a.splits = d->splits;
+    { const char* e = getenv("CU_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
 
     const int CI_all = d->C0 + d->C1;
     const bool wn = d->CO > 32, wc = CI_all > 32;
@@ -338,8 +343,12 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
     const int ns_small = d->dtype == CU_BF16 ? 7 : 13, nz_small = d->dtype == CU_BF16 ? 4 : 8;
     const int ns_big = d->dtype == CU_BF16 ? 11 : 21, nz_big = d->dtype == CU_BF16 ? 8 : 16;
     // loop-pixel tile: 128 pixels (64 for stride-2 gathers: 4x the halo), halved until both staged patches fit in LDS
-    int BM = (d->IS > 1 || d->ZS > 1) ? 64 : 128;
+    // Thin blocks (32x32, 64x32) get bigger pixel tiles so that every wave still has >= 8 k-steps between barriers;
+    // first pass keeps the patches within 80 KiB (two workgroups per CU), second pass takes what fits.
+    int BM = (d->IS > 1 || d->ZS > 1) ? 64 : 512;
+    size_t lds_cap = 80 * 1024;
     for (;; BM >>= 1) {
+        if (BM < 128 && lds_cap < 150 * 1024 && d->IS == 1 && d->ZS == 1) { BM = 128; lds_cap = 150 * 1024; }
         CU_CHECK_ARG(BM >= 16 && BM >= kpix, "cu_conv_wgrad: patches do not fit in LDS");
         a.tile_px = BM;
         int tw = d->PW < 32 ? d->PW : 32;
@@ -379,7 +388,8 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
             if (a.z_off[t] != a.z_off[0]) a.zsame = 0;
         }
         const int spp = (wc ? 64 : 32) / piece_elems, zpp = (wn ? 64 : 32) / piece_elems;
-        if ((size_t)a.s_halo * rows_b + (size_t)a.z_halo * rowz_b <= 150 * 1024 && a.s_halo * spp <= 256 * ns_big &&
+        if (d->IS > 1 || d->ZS > 1) lds_cap = 150 * 1024;
+        if ((size_t)a.s_halo * rows_b + (size_t)a.z_halo * rowz_b <= lds_cap && a.s_halo * spp <= 256 * ns_big &&
             a.z_halo * zpp <= 256 * nz_big)
             break;
     }
@@ -388,14 +398,19 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool plain = !scale0 && d->slope0 == 1.0f && (d->C1 == 0 || (!scale1 && d->slope1 == 1.0f));
+    CU_CHECK_ARG(d->ntaps == 9 || d->ntaps == 4 || d->ntaps == 1, "cu_conv_wgrad: ntaps must be 9, 4 or 1 (got %d)", d->ntaps);
+    CU_CHECK_ARG(plain || d->ntaps == 9, "cu_conv_wgrad: fused-activation sources are only built for 3x3 taps");
+#define CU_WT(T, NBv, CBv, NSv, NZv)                                                   \
+    do {                                                                               \
+        if (!plain) return launch_k<T, NBv, CBv, NSv, NZv, false, 9>(a, st);           \
+        if (d->ntaps == 9) return launch_k<T, NBv, CBv, NSv, NZv, true, 9>(a, st);     \
+        if (d->ntaps == 4) return launch_k<T, NBv, CBv, NSv, NZv, true, 4>(a, st);     \
+        return launch_k<T, NBv, CBv, NSv, NZv, true, 1>(a, st);                        \
+    } while (0)
 #define CU_W(T, NBv, CBv, NSs, NZs, NSb, NZb)                                          \
     do {                                                                               \
-        if (small) {                                                                   \
-            if (plain) return launch_k<T, NBv, CBv, NSs, NZs, true>(a, st);            \
-            return launch_k<T, NBv, CBv, NSs, NZs, false>(a, st);                      \
-        }                                                                              \
-        if (plain) return launch_k<T, NBv, CBv, NSb, NZb, true>(a, st);                \
-        return launch_k<T, NBv, CBv, NSb, NZb, false>(a, st);                          \
+        if (small) CU_WT(T, NBv, CBv, NSs, NZs);                                       \
+        CU_WT(T, NBv, CBv, NSb, NZb);                                                  \
     } while (0)
     if (d->dtype == CU_BF16) {
         if (wn && wc) CU_W(bf16_t, 2, 2, 7, 4, 11, 8);
@@ -408,5 +423,6 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
         if (wc) CU_W(float, 1, 2, 13, 8, 21, 16);
         CU_W(float, 1, 1, 13, 8, 21, 16);
     }
+#undef CU_WT
 #undef CU_W
 }

@@ -170,7 +170,8 @@ def test_conv_transpose(dtype, case):
                   taps=[(dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)], dsts=[din], dst_cols=[ci])
     assert rel_err(nchw(din), rin.grad) < tol(dtype)
     dwk = torch.zeros(4, co, ci, device=DEV)
-    ops.conv_wgrad([a], dun, dwk, grid=(size, size), in_stride=1, z_stride=2,
+    a_plain = ops.Act(nhwc(r, dtype), None, 1.0)      # materialised activation (what the engine feeds)
+    ops.conv_wgrad([a_plain], dun, dwk, grid=(size, size), in_stride=1, z_stride=2,
                    taps=[(0, 0, dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)], n_cols=co)
     gw = torch.zeros_like(w)
     ops.grad_unprep(dwk, gw, "convT", accumulate=True)

@@ -333,3 +333,21 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: floa
     with _Prof("adam"):
         L.check(L.load().cu_adam_step(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), lr, beta1, beta2, eps,
                                       weight_decay, step, grad_scale, L.stream_ptr()), "cu_adam_step")
+
+
+def psm_sample_gauss(mu: Tensor, cov3: Tensor, cov0: Tensor, xbar: Tensor, smean: Tensor, sscale: Tensor,
+                     init_pts, tables: Tensor, sigma2, sample_level, n: int, eps: Optional[Tensor] = None,
+                     seed: int = 0) -> Tensor:
+    """mu (F,K,2), cov3 (F,K,3) -> contour samples (F, n, K, 2)  (cu_psm_sample_gauss)."""
+    import ctypes as C
+    f, k, _ = mu.shape
+    out = torch.empty((f, n, k, 2), dtype=torch.float32, device=mu.device)
+    ip = (C.c_int * len(init_pts))(*init_pts)
+    s2 = (C.c_float * len(sigma2))(*sigma2)
+    sl = (C.c_int * len(sample_level))(*sample_level)
+    with _Prof("psm_sampler"):
+        L.check(L.load().cu_psm_sample_gauss(f, n, k, L.ptr(mu), L.ptr(cov3), L.ptr(cov0), L.ptr(xbar), L.ptr(smean),
+                                             L.ptr(sscale), len(init_pts), C.cast(ip, C.c_void_p), len(sigma2),
+                                             L.ptr(tables), C.cast(s2, C.c_void_p), C.cast(sl, C.c_void_p),
+                                             L.ptr(eps), seed, L.ptr(out), L.stream_ptr()), "cu_psm_sample_gauss")
+    return out

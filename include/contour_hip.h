@@ -160,6 +160,22 @@ int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_ci, const f
 int cu_adam_step(size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Monte-Carlo contour sampler, Gaussian posterior shape model
+ * (sampler/posterior_shape_model/psm.py:73-93,199-440; posteriorshapemodel.py:9-81), one workgroup per frame.
+ *   mu_pred [F][K][2] pixel (x,y); cov_pred [F][K][3] = {xx, yy, xy}; cov0 [2K][2K] = covariance of the PSM training
+ *   shapes about their own mean xbar [2K] (transformed units); smean / sscale [2K] = the PSM scaler.
+ *   init_pts (HOST array, n_init <= 8): anchor points drawn from their own predicted distribution.
+ *   tables (DEVICE ints, n_levels rows of 2 + 48 + 32): {ng, nt, g_flat[48], t_pts[32]} = flat indices already known
+ *   and points produced at that level; sigma2 / sample_level (HOST arrays): PSM slack and 1 = draw / 0 = fill with the
+ *   conditional mean.  eps [F][S][K][2] standard-normal draws or NULL (then a counter-based generator keyed by seed).
+ *   out [F][S][K][2].
+ * ---------------------------------------------------------------------------------------------------------------- */
+int cu_psm_sample_gauss(int F, int S, int K, const float* mu_pred, const float* cov_pred, const float* cov0,
+                        const float* xbar, const float* smean, const float* sscale, int n_init, const int* init_pts,
+                        int n_levels, const int* tables, const float* sigma2, const int* sample_level,
+                        const float* eps, uint64_t seed, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -530,6 +530,8 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
     else nb = 1;
     if (d->D0 != d->CO && d->D0 % (32 * nb) != 0) nb = (d->D0 % 64 == 0 && d->CO % 64 == 0) ? 2 : 1;
     if (!bf && nb > 2) nb = (d->CO % 64 == 0) ? 2 : 1;   // keep the f32 weight tile within LDS
+    { const char* e = getenv("CU_CONV_NBMAX"); const int cap = e ? atoi(e) : 4;
+      while (nb > cap) nb = (nb == 4) ? 2 : (nb == 3 ? 1 : 1); }
     const int coltiles = cdiv(d->CO, 32 * nb);
     a.WP = 32 * nb + 2;
 
@@ -581,9 +583,21 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
     const int unit = bf ? 16 : 4;
     const int wplanes = bf ? 4 : 16, xplanes = bf ? 4 : 16;
     const size_t x_bytes = (size_t)xplanes * a.XP * unit;
-    const size_t w_chunk_bytes = (size_t)d->ntaps * wplanes * a.WP * unit;
     const int nchunks = CI / CK;
-    const bool wres = bf && nb <= 2 && x_bytes + w_chunk_bytes * nchunks <= 96 * 1024 && a.ntiles >= 512;
+    auto wbytes = [&](int nbv) { return (size_t)d->ntaps * wplanes * (32 * nbv + 2) * unit; };
+    auto wres_ok = [&](int nbv) {
+        return bf && nbv <= 2 && x_bytes + wbytes(nbv) * nchunks <= 96 * 1024 && a.ntiles >= 512;
+    };
+    // a 64-column tile whose weight slice does not fit LDS loses to two resident 32-column tiles (measured: 64->64 at
+    // 128^2, 190 -> 150 us)
+    int coltiles2 = coltiles;
+    if (bf && nb == 2 && !wres_ok(2) && wres_ok(1) && (d->D0 == d->CO || d->D0 % 32 == 0)) {
+        nb = 1;
+        a.WP = 34;
+        coltiles2 = cdiv(d->CO, 32);
+    }
+    const size_t w_chunk_bytes = wbytes(nb);
+    const bool wres = wres_ok(nb);
     const size_t lds_data = x_bytes + w_chunk_bytes * (wres ? nchunks : 1);
     a.tap_lds = (int)((lds_data + 15) / 16 * 16);
     const size_t lds = a.tap_lds + 128;
@@ -599,8 +613,8 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
     const bool plain = !scale0 && d->slope0 == 1.0f && (d->C1 == 0 || (!scale1 && d->slope1 == 1.0f));
 #define CU_L(T, MAv, NBv, NXv, NTv, WR)                                                              \
     do {                                                                                             \
-        if (plain) return launch<T, MAv, NBv, NXv, NTv, WR, true>(a, lds, grid_x, coltiles, st);     \
-        return launch<T, MAv, NBv, NXv, NTv, WR, false>(a, lds, grid_x, coltiles, st);               \
+        if (plain) return launch<T, MAv, NBv, NXv, NTv, WR, true>(a, lds, grid_x, coltiles2, st);     \
+        return launch<T, MAv, NBv, NXv, NTv, WR, false>(a, lds, grid_x, coltiles2, st);               \
     } while (0)
 #define CU_NXNT(T, NBv, WR)                                       \
     do {                                                          \

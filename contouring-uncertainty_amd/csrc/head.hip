@@ -140,7 +140,7 @@ __global__ __launch_bounds__(HT) void nll_kernel(int M, int skew, float w_mse, f
                                                  const float* __restrict__ sigma, const float* __restrict__ y,
                                                  const float* __restrict__ alpha, float* __restrict__ logs,
                                                  float* __restrict__ gmu, float* __restrict__ gsigma,
-                                                 float* __restrict__ galpha) {
+                                                 float* __restrict__ galpha, float* __restrict__ terms) {
     __shared__ float lds[16];
     const float invM = 1.f / (float)M;
     float l_loss = 0.f, l_dist = 0.f, l_t1 = 0.f, l_t2 = 0.f, l_t3 = 0.f, l_an = 0.f;
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(HT) void nll_kernel(int M, int skew, float w_mse, f
         if (!skew) {
             const float t1 = w_log * logdet, t2 = w_mse * quad;
             l_t1 += t1; l_t2 += t2; l_loss += t1 + t2;
+            if (terms) { terms[4 * i] = t1 + t2; terms[4 * i + 1] = t1; terms[4 * i + 2] = t2; terms[4 * i + 3] = 0.f; }
             g1 = w_mse * dq_d1; g2 = w_mse * dq_d2;
             ga = w_log * dl_da + w_mse * dq_da; gb = w_log * dl_db + w_mse * dq_db; gc = w_log * dl_dc + w_mse * dq_dc;
         } else {
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(HT) void nll_kernel(int M, int skew, float w_mse, f
             const float t3 = logf(cdf + 1e-7f);
             const float nll = 0.5f * logdet + 0.5f * quad - t3;
             l_t1 += logdet; l_t2 += quad; l_t3 += t3; l_loss += nll;
+            if (terms) { terms[4 * i] = nll; terms[4 * i + 1] = logdet; terms[4 * i + 2] = quad; terms[4 * i + 3] = t3; }
             l_an += fabsf(al1) + fabsf(al2);                       // torch.norm(alpha_flat, dim=-1) over a size-1 dim
             // d(-t3)/dz = -phi(z)/(cdf + 1e-7)
             const float phi = 0.3989422804014327f * expf(-0.5f * zz * zz);
@@ -276,11 +278,11 @@ extern "C" int cu_dsnt_head_bwd(int NK, int H, int W, const float* logits, const
 
 extern "C" int cu_nll_fwd_bwd(int M, int skew, float w_mse, float w_log, const float* mu, const float* sigma,
                               const float* y, const float* alpha, float* logs, float* gmu, float* gsigma,
-                              float* galpha, void* stream) {
+                              float* galpha, float* terms, void* stream) {
     CU_CHECK_ARG(M > 0 && mu && sigma && y && logs, "cu_nll_fwd_bwd: bad argument");
     CU_CHECK_ARG(!skew || alpha, "cu_nll_fwd_bwd: skew NLL needs alpha");
     hipLaunchKernelGGL(nll_kernel, dim3(1), dim3(HT), 0, reinterpret_cast<hipStream_t>(stream), M, skew, w_mse, w_log, mu,
-                       sigma, y, alpha, logs, gmu, gsigma, galpha);
+                       sigma, y, alpha, logs, gmu, gsigma, galpha, terms);
     CU_LAUNCH_CHECK();
     return 0;
 }

@@ -60,12 +60,14 @@ _SIGS = {
     "cu_nhwc_to_nchw_f32": (C.c_int, [C.c_int] * 4 + [_P] * 2 + [C.c_int, _P]),
     "cu_dsnt_head_fwd": (C.c_int, [C.c_int] * 3 + [_P, C.c_int] + [_P] * 4),
     "cu_dsnt_head_bwd": (C.c_int, [C.c_int] * 3 + [_P] * 4 + [C.c_int] + [_P] * 2),
-    "cu_nll_fwd_bwd": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float] + [_P] * 9),
+    "cu_nll_fwd_bwd": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float] + [_P] * 10),
     "cu_linear_fwd": (C.c_int, [C.c_int] * 3 + [_P] * 5),
     "cu_linear_bwd": (C.c_int, [C.c_int] * 3 + [_P] * 7),
     "cu_weight_prep": (C.c_int, [C.c_int] * 5 + [C.c_long, C.c_long] + [_P] * 4),
     "cu_grad_unprep": (C.c_int, [C.c_int] * 4 + [C.c_long, C.c_long] + [_P] * 2 + [C.c_int, _P]),
     "cu_psm_sample_gauss": (C.c_int, [C.c_int] * 3 + [_P] * 6 + [C.c_int, _P, C.c_int] + [_P] * 4 + [C.c_uint64, _P, _P]),
+    "cu_logpdf_grid": (C.c_int, [C.c_int] * 3 + [_P] * 6),
+    "cu_skew_rvs": (C.c_int, [C.c_int] * 2 + [_P] * 4 + [C.c_uint64, _P, _P]),
     "cu_adam_step": (C.c_int, [C.c_size_t] + [_P] * 4 + [C.c_float] * 5 + [C.c_int, C.c_float, _P]),
 }
 

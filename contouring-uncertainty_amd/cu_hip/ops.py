@@ -251,7 +251,7 @@ def dsnt_head_bwd(logits: Tensor, aux: Tensor, gmu: Tensor, gsigma: Tensor, use_
 
 
 def nll_fwd_bwd(mu: Tensor, sigma: Tensor, y: Tensor, alpha: Optional[Tensor], w_mse: float = 1.0,
-                w_log: float = 1.0, need_grad: bool = True):
+                w_log: float = 1.0, need_grad: bool = True, terms: Optional[Tensor] = None):
     m = mu.numel() // 2
     dev = mu.device
     logs = torch.empty(8, dtype=torch.float32, device=dev)
@@ -261,7 +261,7 @@ def nll_fwd_bwd(mu: Tensor, sigma: Tensor, y: Tensor, alpha: Optional[Tensor], w
     with _Prof("small"):
         L.check(L.load().cu_nll_fwd_bwd(m, int(alpha is not None), w_mse, w_log, L.ptr(mu), L.ptr(sigma), L.ptr(y),
                                         L.ptr(alpha), L.ptr(logs), L.ptr(gmu), L.ptr(gsigma), L.ptr(galpha),
-                                        L.stream_ptr()), "cu_nll_fwd_bwd")
+                                        L.ptr(terms), L.stream_ptr()), "cu_nll_fwd_bwd")
     return logs, gmu, gsigma, galpha
 
 
@@ -350,4 +350,23 @@ def psm_sample_gauss(mu: Tensor, cov3: Tensor, cov0: Tensor, xbar: Tensor, smean
                                              L.ptr(sscale), len(init_pts), C.cast(ip, C.c_void_p), len(sigma2),
                                              L.ptr(tables), C.cast(s2, C.c_void_p), C.cast(sl, C.c_void_p),
                                              L.ptr(eps), seed, L.ptr(out), L.stream_ptr()), "cu_psm_sample_gauss")
+    return out
+
+
+def logpdf_grid(pts: Tensor, mu: Tensor, sigma3: Tensor, alpha: Optional[Tensor] = None, pairwise: bool = False) -> Tensor:
+    """pts (P,2), mu (M,2), sigma3 (M,3), alpha (M,2)|None -> log density (M,P) or (P,) when pairwise."""
+    m, p = mu.shape[0], pts.shape[0]
+    out = torch.empty((p,) if pairwise else (m, p), dtype=torch.float32, device=pts.device)
+    with _Prof("small"):
+        L.check(L.load().cu_logpdf_grid(m, p, int(pairwise), L.ptr(pts), L.ptr(mu), L.ptr(sigma3), L.ptr(alpha),
+                                        L.ptr(out), L.stream_ptr()), "cu_logpdf_grid")
+    return out
+
+
+def skew_rvs(mu: Tensor, sigma3: Tensor, alpha: Tensor, n: int, eps: Optional[Tensor] = None, seed: int = 0) -> Tensor:
+    m = mu.shape[0]
+    out = torch.empty((m, n, 2), dtype=torch.float32, device=mu.device)
+    with _Prof("small"):
+        L.check(L.load().cu_skew_rvs(m, n, L.ptr(mu), L.ptr(sigma3), L.ptr(alpha), L.ptr(eps), seed, L.ptr(out),
+                                     L.stream_ptr()), "cu_skew_rvs")
     return out

@@ -135,9 +135,11 @@ int cu_dsnt_head_bwd(int NK, int H, int W, const float* logits, const float* aux
 /* Gaussian NLL of dsnt_al.py:64-74 and skew-normal NLL of bivariateskewnormal.py:36-61 (closed-form 2x2 algebra,
  * Sigma^-1/2 = ((Sigma + sqrt(det) I)/sqrt(tr + 2 sqrt(det)))^-1 instead of distributions/utils.py:100-129's eig).
  * y [M][2]; alpha [M][2] or NULL (gauss).  logs[8] = {loss, distance_loss, term1, term2, term3, alpha_norm, 0, 0}
- * (means over M).  Gradients of `loss` (already divided by M): gmu [M][2], gsigma [M][3], galpha [M][2]. */
+ * (means over M).  Gradients of `loss` (already divided by M): gmu [M][2], gsigma [M][3], galpha [M][2].
+ * terms [M][4] (optional) = per-point {nll, term1, term2, term3} as BivariateSkewNormal.nll returns them. */
 int cu_nll_fwd_bwd(int M, int skew, float w_mse, float w_log, const float* mu, const float* sigma, const float* y,
-                   const float* alpha, float* logs, float* gmu, float* gsigma, float* galpha, void* stream);
+                   const float* alpha, float* logs, float* gmu, float* gsigma, float* galpha, float* terms,
+                   void* stream);
 
 /* ConfidenceNet Linear (unet2.py:28-29): x [N][IN] f32, w [OUT][IN], out [N][OUT]; and its backward. */
 int cu_linear_fwd(int N, int IN, int OUT, const float* x, const float* w, const float* b, float* out, void* stream);
@@ -175,6 +177,15 @@ int cu_psm_sample_gauss(int F, int S, int K, const float* mu_pred, const float* 
                         const float* xbar, const float* smean, const float* sscale, int n_init, const int* init_pts,
                         int n_levels, const int* tables, const float* sigma2, const int* sample_level,
                         const float* eps, uint64_t seed, float* out, void* stream);
+
+/* log-density of M bivariate normal (alpha == NULL) or skew-normal distributions at P points [P][2]
+ * (distributions/bivariatenormal.py:15-36, bivariateskewnormal.py:19-49): out [M][P], or [P] when pairwise (M == P). */
+int cu_logpdf_grid(int M, int P, int pairwise, const float* pts, const float* mu, const float* sigma,
+                   const float* alpha, float* out, void* stream);
+/* BivariateSkewNormal.rvs_fast (bivariateskewnormal.py:159-191): S draws of each of M distributions, out [M][S][2];
+ * eps [M][S][3] standard-normal draws or NULL (counter-based generator keyed by seed). */
+int cu_skew_rvs(int M, int S, const float* mu, const float* sigma, const float* alpha, const float* eps, uint64_t seed,
+                float* out, void* stream);
 
 #ifdef __cplusplus
 }

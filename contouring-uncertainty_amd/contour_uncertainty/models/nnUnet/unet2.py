@@ -92,7 +92,7 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module: "UNet", x: Tensor, *params: Tensor):
         P = dict(zip(module._pnames, params))
-        logits, feats, ectx = module.engine.forward(P, x, module.bottleneck_out)
+        logits, feats, ectx = module.engine.forward(P, x, module.bottleneck_out, module.training)
         ctx.module, ctx.ectx = module, ectx
         ctx.save_for_backward(*params)
         if module.bottleneck_out:
@@ -148,7 +148,7 @@ class UNet(nn.Module):
         if len(patch_size) != 2:
             raise NotImplementedError("Only 2D patches are on the MI355X dsnt path")
         for flag, name in ((deep_supervision, "deep_supervision"), (attention, "attention"), (residual, "residual"),
-                           (out_seg_bias, "out_seg_bias"), (ssn_rank != 0, "ssn_rank"), (drop_block, "drop_block")):
+                           (out_seg_bias, "out_seg_bias"), (ssn_rank != 0, "ssn_rank")):
             if flag:
                 raise NotImplementedError(f"{name} is not enabled by any task=dsnt-* config and is out of scope "
                                           "(SURVEY.md section 2 row 3)")
@@ -186,6 +186,16 @@ class UNet(nn.Module):
 
         self.engine = UNetEngine(self.in_channels, self.num_classes, st, f, negative_slope, 1e-5,
                                  _dtype_of(compute_dtype))
+        self.drop_block = drop_block
+        if drop_block:
+            # reference unet2.py:129-136 (bottleneck) and :302 (`len(in_channels) - i <= 2`: the last two downsamples);
+            # both ConvLayers of a block get the Dropout2d (layers.py:231-232)
+            nd = len(self.downsamples)
+            blocks = [f"downsamples.{i}" for i in range(nd) if nd - i <= 2] + ["bottleneck"]
+            for b in blocks:
+                for li in ("conv1", "conv2"):
+                    self.engine.drop_layers.add(f"{b}.{li}")
+                    getattr(self.get_submodule(b), li).use_drop_block = True
         self._pnames = [n for n, _ in self.named_parameters()]
         self._used_names = [n for n in self._pnames if not n.startswith("deep_supervision_heads")]
         self._flat = None

@@ -390,6 +390,17 @@ __global__ __launch_bounds__(NT) void act_bwd_kernel(T* __restrict__ g, const T*
     }
 }
 
+// x[n][p][c] *= mask[n][c]: nn.Dropout2d(p=0.5) between conv and norm (reference layers.py:154-164,199-202), whole
+// channels zeroed or doubled.  Only the three deepest encoder blocks use it (tiny tensors).
+template <typename T>
+__global__ void channel_scale_kernel(T* __restrict__ x, const float* __restrict__ mask, int N, int HW, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * HW * C) return;
+    const int c = i % C;
+    const int n = (i / C) / HW;
+    Elem<T>::st(x + i, Elem<T>::ld(x + i) * mask[(size_t)n * C + c]);
+}
+
 // ------------------------------------------------------------------------------------------------ layout helpers (tiny tensors)
 template <typename T>
 __global__ void act_to_nchw_kernel(const T* __restrict__ z, const float* __restrict__ stats, float slope,
@@ -594,6 +605,20 @@ extern "C" int cu_nhwc_to_nchw_f32(int dtype, int N, int HW, int C, const void* 
     else
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)in, out, N, HW, C,
                            accumulate);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_channel_scale(int dtype, int N, int HW, int C, void* x, const float* mask, void* stream) {
+    CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_channel_scale: bad dtype");
+    CU_CHECK_ARG(x && mask && N > 0 && HW > 0 && C > 0, "cu_channel_scale: bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t total = (size_t)N * HW * C;
+    const int blocks = (int)((total + 255) / 256);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL(channel_scale_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (bf16_t*)x, mask, N, HW, C);
+    else
+        hipLaunchKernelGGL(channel_scale_kernel<float>, dim3(blocks), dim3(256), 0, st, (float*)x, mask, N, HW, C);
     CU_LAUNCH_CHECK();
     return 0;
 }

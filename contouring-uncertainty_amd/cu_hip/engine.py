@@ -41,6 +41,7 @@ class _ConvRec:
     out: Act
     stride: int
     first: bool = False          # Cin == 1 direct conv
+    drop_mask: Optional[Tensor] = None   # Dropout2d multipliers (N, C) applied between conv and norm
 
 
 @dataclass
@@ -53,6 +54,7 @@ class _UpRec:
 @dataclass
 class UNetCtx:
     img: Tensor
+    training: bool = False
     convs: Dict[str, _ConvRec] = field(default_factory=dict)
     ups: List[_UpRec] = field(default_factory=list)
     enc: List[Act] = field(default_factory=list)
@@ -75,6 +77,11 @@ class UNetEngine:
         # True: one streaming pass materialises LeakyReLU(InstanceNorm(z)) per layer and every consumer stages a plain
         # operand; False: consumers recompute it in their operand load (less HBM traffic, but VALU-bound thin layers)
         self.materialize = True
+        # Dropout2d(p=0.5) between conv and norm in the listed ConvLayers (reference unet2.py:129-136,302: the last two
+        # downsample blocks and the bottleneck when task.model.drop_block=True); active in training mode only
+        self.drop_layers: set = set()
+        self.drop_p = 0.5
+        self.drop_mask_fn: Optional[Callable[[str, int, int, torch.device], Tensor]] = None   # tests inject masks
         self.debug: Optional[Dict[str, Tensor]] = None    # tests/tools: set to {} to capture per-layer gradients (NHWC)
 
     # ------------------------------------------------------------------------------------------ operand copies
@@ -97,11 +104,19 @@ class UNetEngine:
         z = torch.empty((n, oh, ow, co), dtype=self.dtype, device=w.device)
         ops.conv_gemm(srcs, wf, P[f"{prefix}.conv.bias"], grid=(oh, ow), in_stride=stride, taps=TAPS3, dsts=[z],
                       dst_cols=[co])
+        mask = None
+        if ctx.training and prefix in self.drop_layers:
+            if self.drop_mask_fn is not None:
+                mask = self.drop_mask_fn(prefix, n, co, z.device).float().contiguous()
+            else:
+                keep = torch.rand((n, co), device=z.device) >= self.drop_p
+                mask = keep.float() / (1.0 - self.drop_p)
+            ops.channel_scale(z, mask)
         stats = ops.instnorm_stats(z, P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"], self.eps)
         out = Act(z, stats, self.slope)
         if self.materialize:
             ops.instnorm_apply(out)
-        ctx.convs[prefix] = _ConvRec(prefix, srcs, out, stride)
+        ctx.convs[prefix] = _ConvRec(prefix, srcs, out, stride, drop_mask=mask)
         return out
 
     def _first_layer_fwd(self, P, ctx: UNetCtx, prefix: str, img: Tensor) -> Act:
@@ -142,11 +157,11 @@ class UNetEngine:
         return out
 
     # ------------------------------------------------------------------------------------------ forward
-    def forward(self, P: Dict[str, Tensor], img: Tensor, want_bottleneck: bool):
+    def forward(self, P: Dict[str, Tensor], img: Tensor, want_bottleneck: bool, training: bool = False):
         """P: parameter name -> float32 device tensor (reference names).  img: (N, 1, H, W) float32."""
         assert img.dtype == torch.float32 and img.is_cuda and img.shape[1] == 1
         img = img.contiguous()
-        ctx = UNetCtx(img=img)
+        ctx = UNetCtx(img=img, training=training)
         if self.debug is not None:
             self._last_ctx = ctx
         st = self.strides
@@ -192,6 +207,8 @@ class UNetEngine:
         # accumulates rounding noise there.  G[conv.bias] stays exactly 0 (no kernel work, no atomics contention).
         ops.instnorm_lrelu_bwd(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
                                G[f"{prefix}.norm.bias"], None)
+        if rec.drop_mask is not None:          # gradient through the Dropout2d that sits between conv and norm
+            ops.channel_scale(g, rec.drop_mask)
         if self.debug is not None:
             self.debug[f"{prefix}:dz"] = g.float().clone()
         w = P[f"{prefix}.conv.weight"]

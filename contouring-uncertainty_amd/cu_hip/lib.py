@@ -54,6 +54,7 @@ _SIGS = {
     "cu_instnorm_stats": (C.c_int, [C.c_int] * 4 + [_P] * 3 + [C.c_float] + [_P] * 3),
     "cu_instnorm_apply": (C.c_int, [C.c_int] * 4 + [_P] * 2 + [C.c_float] + [_P] * 2),
     "cu_instnorm_lrelu_bwd": (C.c_int, [C.c_int] * 4 + [_P] * 4 + [C.c_float] + [_P] * 5),
+    "cu_channel_scale": (C.c_int, [C.c_int] * 4 + [_P] * 3),
     "cu_act_bwd": (C.c_int, [C.c_int] * 4 + [_P] * 2 + [C.c_float] + [_P] * 2),
     "cu_act_to_nchw_f32": (C.c_int, [C.c_int] * 4 + [_P] * 2 + [C.c_float] + [_P] * 2),
     "cu_nchw_f32_to_nhwc": (C.c_int, [C.c_int] * 5 + [_P] * 3),

@@ -193,6 +193,14 @@ def instnorm_lrelu_bwd(g: Tensor, act: Act, gamma: Optional[Tensor], dgamma, dbe
                                                L.ptr(dbias), L.ptr(ws), L.stream_ptr()), "cu_instnorm_lrelu_bwd")
 
 
+def channel_scale(x: Tensor, mask: Tensor):
+    """x (N,H,W,C) *= mask (N,C) in place (Dropout2d)."""
+    n, h, w_, c = x.shape
+    with _Prof("small"):
+        L.check(L.load().cu_channel_scale(L.dtype_code(x.dtype), n, h * w_, c, L.ptr(x), L.ptr(mask), L.stream_ptr()),
+                "cu_channel_scale")
+
+
 def act_bwd(g: Tensor, z: Tensor, slope: float, dbias):
     n, h, w_, c = g.shape
     with _Prof("small"):

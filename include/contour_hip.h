@@ -110,6 +110,9 @@ int cu_instnorm_apply(int dtype, int N, int HW, int C, const void* z, const floa
 int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, const void* z, const float* stats,
                           const float* gamma, float slope, float* dgamma, float* dbeta, float* dbias,
                           float* ws, void* stream);
+/* x[n][p][c] *= mask[n][c] in place: nn.Dropout2d(p) between conv and norm (layers.py:154-164,199-202), forward and
+ * backward (mask entries are 0 or 1/(1-p)) */
+int cu_channel_scale(int dtype, int N, int HW, int C, void* x, const float* mask, void* stream);
 /* plain activation backward for layers without norm (ConfidenceNet ReLU): g *= (z > 0 ? 1 : slope); dbias[c] += sum g */
 int cu_act_bwd(int dtype, int N, int HW, int C, void* g, const void* z, float slope, float* dbias, void* stream);
 /* materialise act(z*scale+shift) as NCHW f32 (the bottleneck clone handed to the skew head, unet2.py:186) and back */

@@ -188,23 +188,28 @@ def conv_layer(sd, prefix: str, x: Tensor, stride: int, spec: UNetSpec, drop_mas
 
 
 def conv_block(sd, prefix: str, x: Tensor, stride: int, spec: UNetSpec, taps=None, masks=None,
-               round_bf16=False) -> Tensor:
-    """layers.py:208-238: two ConvLayers, the first carries the stage stride."""
-    y = conv_layer(sd, f"{prefix}.conv1", x, stride, spec, taps=taps, masks=masks, round_bf16=round_bf16)
-    return conv_layer(sd, f"{prefix}.conv2", y, 1, spec, taps=taps, masks=masks, round_bf16=round_bf16)
+               round_bf16=False, drop=None) -> Tensor:
+    """layers.py:208-238: two ConvLayers, the first carries the stage stride.  ``drop``: prefix -> (N, C) Dropout2d
+    multipliers (0 or 2), applied between conv and norm as layers.py:199-202 does."""
+    def dm(p):
+        return None if drop is None or p not in drop else drop[p][:, :, None, None]
+    y = conv_layer(sd, f"{prefix}.conv1", x, stride, spec, drop_mask=dm(f"{prefix}.conv1"), taps=taps, masks=masks,
+                   round_bf16=round_bf16)
+    return conv_layer(sd, f"{prefix}.conv2", y, 1, spec, drop_mask=dm(f"{prefix}.conv2"), taps=taps, masks=masks,
+                      round_bf16=round_bf16)
 
 
 def unet_forward(sd: Dict[str, Tensor], x: Tensor, spec: UNetSpec, bottleneck_out: bool = False,
                  taps: Optional[Dict[str, Tensor]] = None, masks: Optional[Dict[str, Tensor]] = None,
-                 round_bf16: bool = False):
+                 round_bf16: bool = False, drop: Optional[Dict[str, Tensor]] = None):
     """unet2.py:177-208 (deep supervision / ssn branches are off for the dsnt tasks)."""
     out = conv_block(sd, "input_block", x, spec.strides[0], spec, taps, masks, round_bf16)
     enc = [out]
     nd = spec.n_stages - 2
     for i in range(nd):
-        out = conv_block(sd, f"downsamples.{i}", out, spec.strides[i + 1], spec, taps, masks, round_bf16)
+        out = conv_block(sd, f"downsamples.{i}", out, spec.strides[i + 1], spec, taps, masks, round_bf16, drop)
         enc.append(out)
-    out = conv_block(sd, "bottleneck", out, spec.strides[-1], spec, taps, masks, round_bf16)
+    out = conv_block(sd, "bottleneck", out, spec.strides[-1], spec, taps, masks, round_bf16, drop)
     bott = out.clone()
     if taps is not None:
         taps["bottleneck"] = bott

@@ -253,3 +253,50 @@ def test_oracle_vs_hip_larger_batch():
             err = float((p.grad.cpu() - b).norm() / b.norm())
             worst = max(worst, err)
             assert err < 5e-4, (covar, name, err)
+
+
+def test_drop_block_matches_oracle_with_shared_masks():
+    """task.model.drop_block=True (tmi_scripts/train.sh:9): Dropout2d between conv and norm in the last two downsample
+    blocks and the bottleneck, training mode only.  Same channel masks on both sides -> same loss and gradients."""
+    from contour_uncertainty.models.nnUnet.unet2 import UNet
+    spec = OU.UNetSpec(strides=(1, 2, 2, 2, 2, 2))
+    gen = torch.Generator().manual_seed(4)
+    sd = OU.init_unet_state(spec, gen)
+    img, contour = synthetic_batch(3, 64, 21, seed=5)
+    net = UNet((1, 64, 64), (21, 1, 64), [256, 256], [[3, 3]] * 6, [[1, 1]] + [[2, 2]] * 5, drop_block=True,
+               compute_dtype="f32")
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV)
+    assert sorted(net.engine.drop_layers) == ["bottleneck.conv1", "bottleneck.conv2", "downsamples.2.conv1",
+                                              "downsamples.2.conv2", "downsamples.3.conv1", "downsamples.3.conv2"]
+    masks = {}
+
+    def mask_fn(prefix, n, c, device):
+        g = torch.Generator().manual_seed(hash(prefix) % 1000)
+        masks[prefix] = (torch.rand(n, c, generator=g) >= 0.5).float() * 2.0
+        return masks[prefix].to(device)
+
+    net.engine.drop_mask_fn = mask_fn
+    net.engine.debug = {}
+    net.train()
+    logits = net(img.to(DEV))
+    from cu_hip.head import dsnt_nll
+    logs, _, _ = dsnt_nll(logits, contour.to(DEV))
+    logs["loss"].backward()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    kinks = hip_kink_masks(net)
+    ref_logits = OU.unet_forward(sdr, img, spec, masks=kinks, drop=masks)
+    ref = OH.dsnt_al_loss(ref_logits, contour)
+    ref["loss"].backward()
+    assert abs(float(logs["loss"]) - float(ref["loss"])) < 2e-4 * abs(float(ref["loss"]))
+    params = dict(net.named_parameters())
+    for name in ("downsamples.3.conv1.conv.weight", "bottleneck.conv2.conv.weight", "downsamples.2.conv2.norm.weight",
+                 "input_block.conv1.conv.weight", "upsamples.0.transp_conv.weight"):
+        a, b = params[name].grad.cpu(), sdr[name].grad
+        assert float((a - b).norm() / b.norm()) < 5e-4, name
+    # eval mode: no dropout, different output
+    net.eval()
+    with torch.no_grad():
+        ev = net(img.to(DEV))
+    ref_eval = OU.unet_forward(sd, img, spec)
+    assert torch.allclose(ev.cpu(), ref_eval, rtol=1e-3, atol=1e-3)

@@ -102,11 +102,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")     # "gloo" lets a 1-GPU box rehearse the N-rank flow
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"launched {world} ranks for --gpus {args.gpus}"
 
     from cu_hip import ops
@@ -169,14 +175,17 @@ def main():
                        "mfma_roofline_frac_whole_step": round(value / world * flops_step_img / PEAK_BF16_DENSE, 4)},
         }
 
-    # ---- roofline of the dominant kernel family: separate profiled pass (events around every launch)
-    if rank == 0 and not args.no_roofline:
-        ops.PROFILE.clear()
-        ops.PROFILE_ON[0] = True
+    # ---- roofline of the dominant kernel family: separate profiled pass (events around every launch).  Every rank
+    #      runs the two extra steps (they contain collectives); only rank 0 records.
+    if not args.no_roofline:
+        if rank == 0:
+            ops.PROFILE.clear()
+            ops.PROFILE_ON[0] = True
         for i in range(2):
             step(i)
         torch.cuda.synchronize()
         ops.PROFILE_ON[0] = False
+    if rank == 0 and not args.no_roofline:
         fam = {}
         for name, flops, e0, e1 in ops.PROFILE:
             ms_k = e0.elapsed_time(e1)
@@ -188,14 +197,21 @@ def main():
         dom = max(fam.items(), key=lambda kv: kv[1][1])
         name, (fl, ms_k, cnt) = dom
         achieved = fl / (ms_k * 1e-3) / 1e12
+        traffic = None
+        pmc = ROOT / "profiles" / "r01_pmc_hbm_traffic.json"     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this bench
+        if pmc.exists() and args.batch == 64 and args.size == 256 and args.dtype == "bf16":
+            famrec = json.loads(pmc.read_text())["families"].get(name)
+            if famrec:
+                traffic = round(famrec["bytes_per_launch"])
         result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
                               "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
-                              "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": None,
+                              "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": traffic,
+                              "traffic_source": "profiles/r01_pmc_hbm_traffic.json (HBM bytes per launch, PMC)" if traffic else None,
                               "launches_per_step": cnt // 2, "avg_launch_ms": round(ms_k / cnt, 4),
                               "flops_per_launch": fl / cnt,
                               "family_ms_per_step": {k: round(v[1] / 2, 3) for k, v in fam.items()},
                               "family_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 2) for k, v in fam.items()
-                                                if v[1] > 0},
+                                                if v[1] > 0 and v[0] > 0},
                               "profiled_ms_per_step": round(total_ms / 2, 3)}
     if world > 1:
         dist.barrier()

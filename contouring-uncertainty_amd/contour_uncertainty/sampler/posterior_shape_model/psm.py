@@ -71,6 +71,7 @@ class PosteriorShapeModelSampler(Sampler):
             tab[i, 2:2 + len(g)] = g
             tab[i, 2 + 48:2 + 48 + len(t)] = t
         self._tables, self._sigma2, self._sample = torch.from_numpy(tab), sigma2, sample
+        self._rec_stride = ops.psm_record_floats([len(g) for g, _ in rows], [len(t) for _, t in rows])
 
     def _on(self, device):
         key = str(device)
@@ -94,11 +95,38 @@ class PosteriorShapeModelSampler(Sampler):
         return ops.psm_sample_gauss(mu, cov3, cov0, xbar, smean, sscale, self.initial_points, tables, self._sigma2,
                                     self._sample, n, eps, seed)
 
+    def sample_batch_skew(self, mu: torch.Tensor, cov: torch.Tensor, alpha: torch.Tensor, n: int = 1, skew_bits: int = 0,
+                          eps: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None,
+                          seed: Optional[int] = None, prior_mu: Optional[torch.Tensor] = None,
+                          prior_cov: Optional[torch.Tensor] = None, use_initial_pdf: bool = False,
+                          flip_alpha_y: bool = True, grid_size: int = 256) -> torch.Tensor:
+        """mu (F,K,2), cov (F,K,2,2), alpha (F,K,2) -> (F, n, K, 2): anchors by ``rvs_fast`` (alpha_y negated first,
+        psm.py:235-236 / psm_skew.py:232), points whose bit is set in ``skew_bits`` by the grid product, the others by
+        the product-of-Gaussians merge (``cu_psm_setup`` + ``cu_psm_sample_skew``).
+
+        eps (F,n,K,3) standard normals / u (F,n,K) uniforms in [0,1) replace the internal generator (parity tests).
+        prior_mu (F,n,K,2) / prior_cov (F,n,K,2,2): extra Gaussian factor of every point's table (the ED/ES coupling of
+        SequenceSkewPSMSampler); with ``use_initial_pdf`` the anchors are drawn from skew-pdf x prior as well."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if not mu.is_cuda else mu.device
+        f32 = lambda t: None if t is None else t.to(dev, torch.float32).contiguous()
+        lower3 = lambda c: torch.stack([c[..., 0, 0], c[..., 1, 1], c[..., 1, 0]], -1).contiguous()
+        mu, alpha = f32(mu), f32(alpha)
+        cov3 = lower3(cov.to(dev, torch.float32))
+        cov0, xbar, smean, sscale, tables = self._on(dev)
+        rec = ops.psm_setup(mu.reshape(mu.shape[0], -1), cov0, xbar, smean, sscale, tables, self._sigma2, self._rec_stride)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        p3 = None if prior_cov is None else lower3(prior_cov.to(dev, torch.float32))
+        return ops.psm_sample_skew(mu, cov3, alpha, -1.0 if flip_alpha_y else 1.0, skew_bits, rec, smean, sscale,
+                                   self.initial_points, tables, self._sample, n, f32(prior_mu), p3, use_initial_pdf,
+                                   grid_size, f32(eps), f32(u), seed)
+
     def __call__(self, mu: torch.Tensor, cov: torch.Tensor, alpha: torch.Tensor = None, n: int = 1,
                  debug_img=None) -> torch.Tensor:
-        """mu (K, 2), cov (K, 2, 2) -> (n, K, 2) on mu's device (reference psm.py:73-93)."""
+        """mu (K, 2), cov (K, 2, 2) -> (n, K, 2) on mu's device (reference psm.py:73-93).  With ``alpha`` the anchors
+        are skew-normal draws and every other point stays Gaussian (psm.py:233-238)."""
         if alpha is not None:
-            raise NotImplementedError("skew-normal anchors belong to SkewPosteriorShapeModelSampler")
+            return self.sample_batch_skew(mu[None], cov[None], alpha[None], n=n, skew_bits=0)[0].to(mu.device)
         return self.sample_batch(mu[None], cov[None], n=n)[0].to(mu.device)
 
     @staticmethod

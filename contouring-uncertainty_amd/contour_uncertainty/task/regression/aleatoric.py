@@ -46,7 +46,7 @@ class AleatoricUncertaintyTask(ContourUncertaintyTask):
         from contour_uncertainty.sampler.posterior_shape_model.sequence_sampler import SequencePSMSampler
         n = mu.shape[0]
         if isinstance(self.sampler, SequencePSMSampler):
-            cs = [self.sampler(mu[:, t], cov[:, t], n=t_a).numpy() for t in range(mu.shape[1])]
+            cs = [self.sampler(mu[:, t], cov[:, t], n=t_a).cpu().numpy() for t in range(mu.shape[1])]
             return np.array(cs).transpose((2, 0, 1, 3, 4))
         # frames are independent: the batched GPU sampler takes all (frame, t_e) pairs in one call
         out = self.sampler.sample_batch(mu.reshape(-1, *mu.shape[2:]), cov.reshape(-1, *cov.shape[2:]), n=t_a)

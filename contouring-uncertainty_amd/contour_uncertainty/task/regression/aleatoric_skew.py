@@ -20,8 +20,11 @@ class SkewUncertaintyTask(AleatoricUncertaintyTask):
 
     def _build_sampler(self):
         from contour_uncertainty.sampler.posterior_shape_model.psm_skew import SkewPosteriorShapeModelSampler
+        from contour_uncertainty.sampler.posterior_shape_model.psm_skew_sequence import SequenceSkewPSMSampler
         if self.hparams.sequence_sampler:
-            raise NotImplementedError("SequenceSkewPSMSampler (reference psm_skew_sequence.py) is not built yet")
+            # the reference drops skew_indices here (aleatoric_skew.py:37-38): every point is a skew point
+            return SequenceSkewPSMSampler(sequence_psm_path=Path(to_absolute_path(self.hparams.seq_psm_path)),
+                                          psm_path=Path(to_absolute_path(self.hparams.psm_path)))
         # the reference passes the raw (possibly None) skew_indices (aleatoric_skew.py:41-42);
         # the resolved list is what its sampler needs
         return SkewPosteriorShapeModelSampler(psm_path=Path(to_absolute_path(self.hparams.psm_path)),
@@ -32,8 +35,14 @@ class SkewUncertaintyTask(AleatoricUncertaintyTask):
 
     def sample(self, mu, cov, alpha, T):
         """(N, T_e, K, .) -> (N, T_e, T, K, 2)  (reference aleatoric_skew.py:48-53)"""
-        cs = [self.sampler(mu[:, t], cov[:, t], alpha[:, t], n=T).numpy() for t in range(mu.shape[1])]
-        return np.array(cs).transpose(1, 0, 2, 3, 4)
+        from contour_uncertainty.sampler.posterior_shape_model.psm_skew_sequence import SequenceSkewPSMSampler
+        if isinstance(self.sampler, SequenceSkewPSMSampler):      # an ED/ES pair is one unit: (2, T, K, 2) per t_e
+            cs = [self.sampler(mu[:, t], cov[:, t], alpha[:, t], n=T).cpu().numpy() for t in range(mu.shape[1])]
+            return np.array(cs).transpose(1, 0, 2, 3, 4)
+        # frames are independent: all (frame, t_e) pairs and all T samples in one launch
+        n, te, k = mu.shape[:3]
+        out = self.sampler.sample_batch(mu.reshape(-1, k, 2), cov.reshape(-1, k, 2, 2), alpha.reshape(-1, k, 2), n=T)
+        return out.reshape(n, te, T, k, 2).cpu().numpy()
 
     def _predict_step(self, batch: Any) -> BatchResult:
         """reference aleatoric_skew.py:55-127 (mode / u-map projection is 8(f) rank 3: taken from the datamodule fn)."""

@@ -361,6 +361,67 @@ def psm_sample_gauss(mu: Tensor, cov3: Tensor, cov0: Tensor, xbar: Tensor, smean
     return out
 
 
+def psm_record_floats(ng, nt) -> int:
+    import ctypes as C
+    a, b = (C.c_int * len(ng))(*ng), (C.c_int * len(nt))(*nt)
+    return L.load().cu_psm_record_floats(len(ng), C.cast(a, C.c_void_p), C.cast(b, C.c_void_p))
+
+
+def psm_setup(mu_flat: Tensor, cov0: Tensor, xbar: Tensor, smean: Tensor, sscale: Tensor, tables: Tensor, sigma2,
+              rec_stride: int) -> Tensor:
+    """mu_flat (F, P) pixel units -> per-frame PSM records (F, rec_stride)  (cu_psm_setup)."""
+    import ctypes as C
+    f, p = mu_flat.shape
+    rec = torch.zeros((f, rec_stride), dtype=torch.float32, device=mu_flat.device)
+    s2 = (C.c_float * len(sigma2))(*sigma2)
+    with _Prof("psm_sampler"):
+        L.check(L.load().cu_psm_setup(f, p, L.ptr(mu_flat), L.ptr(cov0), L.ptr(xbar), L.ptr(smean), L.ptr(sscale),
+                                      len(sigma2), L.ptr(tables), C.cast(s2, C.c_void_p), L.ptr(rec), rec_stride,
+                                      L.stream_ptr()), "cu_psm_setup")
+    return rec
+
+
+def psm_sample_skew(mu: Tensor, cov3: Tensor, alpha: Tensor, alpha_y_sign: float, skew_bits: int, rec: Tensor,
+                    smean: Tensor, sscale: Tensor, init_pts, tables: Tensor, sample_level, n: int,
+                    prior_mu: Optional[Tensor] = None, prior_cov3: Optional[Tensor] = None, use_initial_pdf: bool = False,
+                    grid: int = 256, eps: Optional[Tensor] = None, u: Optional[Tensor] = None, seed: int = 0) -> Tensor:
+    """mu (F,K,2), cov3 (F,K,3), alpha (F,K,2) -> contour samples (F, n, K, 2)  (cu_psm_sample_skew)."""
+    import ctypes as C
+    f, k, _ = mu.shape
+    out = torch.empty((f, n, k, 2), dtype=torch.float32, device=mu.device)
+    ip = (C.c_int * len(init_pts))(*init_pts)
+    sl = (C.c_int * len(sample_level))(*sample_level)
+    if prior_mu is not None:
+        assert prior_mu.shape == (f, n, k, 2) and prior_cov3.shape == (f, n, k, 3)
+    with _Prof("psm_sampler"):
+        L.check(L.load().cu_psm_sample_skew(f, n, k, L.ptr(mu), L.ptr(cov3), L.ptr(alpha), alpha_y_sign, skew_bits,
+                                            L.ptr(rec), rec.shape[1], L.ptr(smean), L.ptr(sscale), len(init_pts),
+                                            C.cast(ip, C.c_void_p), len(sample_level), L.ptr(tables),
+                                            C.cast(sl, C.c_void_p), L.ptr(prior_mu), L.ptr(prior_cov3),
+                                            int(use_initial_pdf), grid, L.ptr(eps), L.ptr(u), seed, L.ptr(out),
+                                            L.stream_ptr()), "cu_psm_sample_skew")
+    return out
+
+
+def psm_condition(rec: Tensor, table: Tensor, nt: int, known: Tensor, per_rec: int, smean: Tensor, sscale: Tensor,
+                  mu_p: Optional[Tensor] = None, cov_p3: Optional[Tensor] = None):
+    """known (N, P) -> mu_c (N, nt, 2), cov_c (R, nt, 2, 2) [, mu_f (N, nt, 2), cov_f (R, nt, 2, 2)]  (cu_psm_condition)."""
+    n, p = known.shape
+    r = rec.shape[0]
+    dev = known.device
+    mu_c = torch.empty((n, nt, 2), dtype=torch.float32, device=dev)
+    cov_c = torch.empty((r, nt, 2, 2), dtype=torch.float32, device=dev)
+    mu_f = cov_f = None
+    if mu_p is not None:
+        mu_f = torch.empty((n, nt, 2), dtype=torch.float32, device=dev)
+        cov_f = torch.empty((r, nt, 2, 2), dtype=torch.float32, device=dev)
+    with _Prof("psm_sampler"):
+        L.check(L.load().cu_psm_condition(n, p, per_rec, L.ptr(rec), rec.shape[1], L.ptr(table), nt, L.ptr(known),
+                                          L.ptr(smean), L.ptr(sscale), L.ptr(mu_p), L.ptr(cov_p3), L.ptr(mu_c),
+                                          L.ptr(cov_c), L.ptr(mu_f), L.ptr(cov_f), L.stream_ptr()), "cu_psm_condition")
+    return mu_c, cov_c, mu_f, cov_f
+
+
 def logpdf_grid(pts: Tensor, mu: Tensor, sigma3: Tensor, alpha: Optional[Tensor] = None, pairwise: bool = False) -> Tensor:
     """pts (P,2), mu (M,2), sigma3 (M,3), alpha (M,2)|None -> log density (M,P) or (P,) when pairwise."""
     m, p = mu.shape[0], pts.shape[0]

@@ -181,6 +181,38 @@ int cu_psm_sample_gauss(int F, int S, int K, const float* mu_pred, const float* 
                         int n_levels, const int* tables, const float* sigma2, const int* sample_level,
                         const float* eps, uint64_t seed, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Skew-normal and ED/ES sequence samplers (sampler/posterior_shape_model/psm_skew.py:45-158,162-503,
+ * sequence_sampler.py:13-160, psm_skew_sequence.py:21-166).
+ *
+ * cu_psm_setup: per-frame record of the PSM algebra (PCA re-centred on mu_pred [F][P], P = 2K <= 96): for every level
+ *   row of `tables` the gains C[t,g](C[g,g]+sigma2 I)^-1 and the scaled 2x2 conditional covariance of every target
+ *   point.  rec [F][rec_stride] floats, rec_stride >= cu_psm_record_floats(n_levels, ng[], nt[]) (HOST arrays).
+ *   Record layout: m[96] | covc[48][4] {xx,xy,yx,yy} | gains (level-major, rows 2*nt, cols ng).
+ * cu_psm_sample_skew: one workgroup per (frame, sample).  Anchors: BivariateSkewNormal.rvs_fast (or, when
+ *   use_initial_pdf, a draw from skew-pdf x prior on the grid).  Points with their bit set in skew_bits:
+ *   `numerical_sampling` = inverse-CDF draw from skew-pdf(mu_pred, cov_pred, alpha) x N(mu_c, cov_c) [x prior] on the
+ *   grid x grid lattice linspace(0,255,grid)^2 in torch.meshgrid(indexing='ij') order; other points: product-of-
+ *   Gaussians merge + draw.  alpha_y_sign = -1 applies psm_skew.py:232.  prior_mu [F][S][K][2] / prior_cov [F][S][K][3]
+ *   {xx,yy,xy} or NULL.  eps [F][S][K][3] standard normals or NULL; u [F][S][K] uniforms in [0,1) or NULL (then a
+ *   counter-based generator keyed by seed).  A table without mass falls back to mu_c (psm_skew.py:135-154).
+ * cu_psm_condition: conditional mean of a one-level record given sampled contours known [N][P] (sample i uses record
+ *   i / per_rec): mu_c [N][nt][2], cov_c [R][nt][4]; with mu_p [R][P] / cov_p [R][P/2][3] also the product-of-Gaussians
+ *   merge mu_f [N][nt][2], cov_f [R][nt][4] (sequence_sampler.py:83-91).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int cu_psm_record_floats(int n_levels, const int* ng, const int* nt);
+int cu_psm_setup(int F, int P, const float* mu_pred, const float* cov0, const float* xbar, const float* smean,
+                 const float* sscale, int n_levels, const int* tables, const float* sigma2, float* rec, int rec_stride,
+                 void* stream);
+int cu_psm_sample_skew(int F, int S, int K, const float* mu_pred, const float* cov_pred, const float* alpha,
+                       float alpha_y_sign, uint64_t skew_bits, const float* rec, int rec_stride, const float* smean,
+                       const float* sscale, int n_init, const int* init_pts, int n_levels, const int* tables,
+                       const int* sample_level, const float* prior_mu, const float* prior_cov, int use_initial_pdf,
+                       int grid, const float* eps, const float* u, uint64_t seed, float* out, void* stream);
+int cu_psm_condition(int N, int P, int per_rec, const float* rec, int rec_stride, const int* table, int nt,
+                     const float* known, const float* smean, const float* sscale, const float* mu_p, const float* cov_p,
+                     float* mu_c, float* cov_c, float* mu_f, float* cov_f, void* stream);
+
 /* log-density of M bivariate normal (alpha == NULL) or skew-normal distributions at P points [P][2]
  * (distributions/bivariatenormal.py:15-36, bivariateskewnormal.py:19-49): out [M][P], or [P] when pairwise (M == P). */
 int cu_logpdf_grid(int M, int P, int pairwise, const float* pts, const float* mu, const float* sigma,

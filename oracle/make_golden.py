@@ -322,11 +322,68 @@ def gen_psm():
     np.savez_compressed(OUT / "psm_math.npz", **out)
 
 
+# ----------------------------------------------------------------------------------------------- (v) skew grid sampler
+def gen_skew_grid():
+    """Pieces of SkewPosteriorShapeModelSampler / SequenceSkewPSMSampler that ARE importable: the density tables of
+    `numerical_sampling` (psm_skew.py:60-88), rvs_fast with the generator state pinned, and the two-instant PSM
+    conditional (sequence_sampler.py:83-86)."""
+    from torch.distributions import MultivariateNormal
+    from contour_uncertainty.distributions.bivariatenormal import BivariateNormal
+    from contour_uncertainty.distributions.bivariateskewnormal import BivariateSkewNormal
+    from contour_uncertainty.sampler.posterior_shape_model.posteriorshapemodel import posterior_shape_model, pca
+    from contour_uncertainty.sampler.posterior_shape_model.utils import index_to_flat
+    x = torch.linspace(0, 255, 256)
+    X, Y = torch.meshgrid(x, x, indexing="ij")
+    grid = torch.stack([X, Y], dim=-1)
+    cases = [   # mu1, cov1, alpha1, mu2, cov2
+        ([120.3, 88.6], [[30.0, 8.0], [8.0, 18.0]], [2.5, -1.0], [123.0, 91.5], [[9.0, -2.0], [-2.0, 14.0]]),
+        ([40.2, 200.7], [[12.0, -5.0], [-5.0, 25.0]], [-4.0, 3.0], [37.5, 204.0], [[20.0, 3.0], [3.0, 6.0]]),
+        ([3.0, 250.0], [[50.0, 0.0], [0.0, 40.0]], [0.0, 0.0], [1.0, 253.0], [[16.0, 1.0], [1.0, 16.0]]),   # clipped by the border
+    ]
+    out = {}
+    for i, (m1, c1, a1, m2, c2) in enumerate(cases):
+        m1, c1, a1, m2, c2 = (torch.tensor(v) for v in (m1, c1, a1, m2, c2))
+        p1 = BivariateSkewNormal.pdf(grid, m1, c1, a1)
+        p2 = torch.exp(MultivariateNormal(m2, c2, validate_args=False).log_prob(grid))
+        p2b = BivariateNormal.pdf(grid, m2, c2)
+        p = p1 * p2
+        p = p / torch.sum(p)
+        out.update({f"c{i}_mu1": npy(m1), f"c{i}_cov1": npy(c1), f"c{i}_alpha1": npy(a1), f"c{i}_mu2": npy(m2),
+                    f"c{i}_cov2": npy(c2), f"c{i}_p1": npy(p1), f"c{i}_p2": npy(p2), f"c{i}_p2_bn": npy(p2b),
+                    f"c{i}_p": npy(p)})
+    # rvs_fast: MultivariateNormal.sample = scale_tril @ randn under the global generator
+    m, c, a = torch.tensor([100.0, 150.0]), torch.tensor([[10.0, -5.0], [-5.0, 12.0]]), torch.tensor([4.0, -2.0])
+    torch.manual_seed(11)
+    xs = BivariateSkewNormal.rvs_fast(m, c, a, size=(64,))
+    torch.manual_seed(11)
+    eps = torch.randn(64, 3)
+    out.update({"rvs_mu": npy(m), "rvs_cov": npy(c), "rvs_alpha": npy(a), "rvs_eps": npy(eps), "rvs_x": npy(xs)})
+    # two-instant PSM conditional, fixed (file) model and re-centred model
+    seq = np.load(REF / "camus-cont_sequence_psm_11_no_std.npy", allow_pickle=True).item()
+    smu, sQ = torch.tensor(seq["mu"], dtype=torch.float), torch.tensor(seq["Q"], dtype=torch.float)
+    xv = torch.tensor(np.asarray(seq["X_val"])[7], dtype=torch.float)
+    for first in (0, 1):
+        sg = torch.zeros(84)
+        sl = slice(0, 42) if first == 0 else slice(42, 84)
+        sg[sl] = xv[sl] + 1.5
+        idx = index_to_flat(list(range(21)) if first == 0 else list(range(21, 42)))
+        mu_c, cov_c = posterior_shape_model(sg.reshape(-1, 1), idx, smu, sQ, sigma2=1)
+        out[f"seq{first}_sg"] = npy(sg)
+        out[f"seq{first}_mu_c"] = npy(mu_c.squeeze())
+        out[f"seq{first}_cov_blocks"] = npy(torch.stack([cov_c[2 * i:2 * i + 2, 2 * i:2 * i + 2] for i in range(42)]))
+        pm, pQ = pca(torch.tensor(np.asarray(seq["X_train"]), dtype=torch.float), xv.reshape(-1, 1))
+        mu_c, cov_c = posterior_shape_model(sg.reshape(-1, 1), idx, pm, pQ, sigma2=1)
+        out[f"seqpca{first}_mu_c"] = npy(mu_c.squeeze())
+        out[f"seqpca{first}_cov_blocks"] = npy(torch.stack([cov_c[2 * i:2 * i + 2, 2 * i:2 * i + 2] for i in range(42)]))
+    out["seq_xv"] = npy(xv)
+    np.savez_compressed(OUT / "skew_grid.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dsnt", "nll", "unet_small", "unet_full", "step", "psm"]
+    which = sys.argv[1:] or ["dsnt", "nll", "unet_small", "unet_full", "step", "psm", "skew_grid"]
     for w in which:
         print("generating", w, flush=True)
         {"dsnt": gen_dsnt, "nll": gen_nll, "unet_small": gen_unet_small, "unet_full": gen_unet_full,
-         "step": gen_step, "psm": gen_psm}[w]()
+         "step": gen_step, "psm": gen_psm, "skew_grid": gen_skew_grid}[w]()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)

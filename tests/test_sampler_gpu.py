@@ -66,3 +66,176 @@ def test_sampler_statistics_with_internal_generator(golden_dir):
     assert float(d.max()) < 60.0
     one = smp(mu[0].cuda(), cov[0].cuda(), n=5)
     assert one.shape == (5, 21, 2) and one.is_cuda
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# skew-normal grid sampler and the ED/ES sequence samplers
+# ---------------------------------------------------------------------------------------------------------------------
+def _alpha(f, seed=2):
+    return torch.randn(f, 21, 2, generator=torch.Generator().manual_seed(seed)) * 2.0
+
+
+class _F64:
+    def __enter__(self):
+        torch.set_default_dtype(torch.float64)
+
+    def __exit__(self, *a):
+        torch.set_default_dtype(torch.float32)
+
+
+def _agreement(out, ref):
+    """fraction of contours that agree to 0.05 px, and the worst deviation of the others."""
+    d = (out.double() - ref.double()).abs().flatten(-2).max(-1).values.flatten()
+    return float((d < 0.05).double().mean()), float(d.max())
+
+
+def test_skew_sampler_matches_oracle_with_shared_draws(golden_dir):
+    """Same normals (anchors) and uniforms (grid cells): the kernel picks the cells the reference algorithm picks.
+    The oracle runs in f64 (the reference's f32 PSM algebra is itself only good to a few tenths of a pixel, which moves
+    cell boundaries); a draw within ~1e-6 of a cell boundary may land in the neighbouring cell, and later levels are
+    conditioned on it, so a small fraction of contours may differ by a few pixels."""
+    from contour_uncertainty.sampler.posterior_shape_model.psm_skew import SkewPosteriorShapeModelSampler
+    psm, mu, cov = _inputs(golden_dir, f=2, seed=4)
+    alpha = _alpha(2)
+    smp = SkewPosteriorShapeModelSampler(golden_dir / "camus-cont_psm_11_no_std.npz")
+    n = 8
+    g = torch.Generator().manual_seed(9)
+    eps = torch.randn(2, n, 21, 3, generator=g)
+    u = torch.rand(2, n, 21, generator=g)
+    out = smp.sample_batch(mu.cuda(), cov.cuda(), alpha.cuda(), n=n, eps=eps, u=u).cpu()
+    assert out.shape == (2, n, 21, 2) and torch.isfinite(out).all()
+    with _F64():
+        orc = S.SkewPSMSamplerOracle(psm, dtype=torch.float64)
+        ref = orc(mu.double(), cov.double(), alpha.double(), n, eps.double(), u.double())
+    frac, worst = _agreement(out, ref)
+    assert frac >= 0.85 and worst < 6.0, (frac, worst)
+    # grid points are integer pixel coordinates; the final fill (4 points) is the PSM mean
+    pts = [j for lv in smp.points_order for j in lv]
+    assert torch.equal(out[:, :, pts], out[:, :, pts].round())
+
+
+def test_skew_sampler_partial_skew_indices_and_gaussian_anchors(golden_dir):
+    """skew_indices subset: the other points take the product-of-Gaussians branch; PosteriorShapeModelSampler with
+    alpha = skew anchors + Gaussian points everywhere (psm.py:233-238)."""
+    from contour_uncertainty.sampler.posterior_shape_model.psm import PosteriorShapeModelSampler
+    from contour_uncertainty.sampler.posterior_shape_model.psm_skew import SkewPosteriorShapeModelSampler
+    psm, mu, cov = _inputs(golden_dir, f=1, seed=6)
+    alpha = _alpha(1, seed=8)
+    skew_idx = [0, 2, 5, 10, 13, 15, 20]
+    alpha_masked = torch.zeros_like(alpha)
+    alpha_masked[:, skew_idx] = alpha[:, skew_idx]
+    n = 6
+    g = torch.Generator().manual_seed(10)
+    eps = torch.randn(1, n, 21, 3, generator=g)
+    u = torch.rand(1, n, 21, generator=g)
+    smp = SkewPosteriorShapeModelSampler(golden_dir / "camus-cont_psm_11_no_std.npz", skew_indices=skew_idx)
+    out = smp.sample_batch(mu.cuda(), cov.cuda(), alpha_masked.cuda(), n=n, eps=eps, u=u).cpu()
+    with _F64():
+        orc = S.SkewPSMSamplerOracle(psm, skew_indices=skew_idx, dtype=torch.float64)
+        ref = orc(mu.double(), cov.double(), alpha_masked.double(), n, eps.double(), u.double())
+    frac, worst = _agreement(out, ref)
+    assert frac >= 0.8 and worst < 6.0, (frac, worst)
+    # Gaussian sampler with alpha: no grid cells at all -> exact agreement
+    gs = PosteriorShapeModelSampler(golden_dir / "camus-cont_psm_11_no_std.npz")
+    out = gs.sample_batch_skew(mu.cuda(), cov.cuda(), alpha.cuda(), n=n, skew_bits=0, eps=eps).cpu()
+    with _F64():
+        orc = S.SkewPSMSamplerOracle(psm, skew_indices=[], dtype=torch.float64)
+        ref = orc(mu.double(), cov.double(), alpha.double(), n, eps.double(), u.double())
+    assert float((out.double() - ref).abs().max()) < 2e-2
+    one = gs(mu[0].cuda(), cov[0].cuda(), alpha[0].cuda(), n=3)
+    assert one.shape == (3, 21, 2)
+
+
+def test_skew_sampler_statistics_with_internal_generator(golden_dir):
+    """Distributional check (the reference's torch.multinomial stream cannot be reproduced): anchors have the
+    skew-normal mean mu + sqrt(2/pi) delta; level-1 points follow the normalised table skew-pdf x N(mu_c, cov_c)
+    averaged over the anchors; same seed -> same draws."""
+    import math
+    from contour_uncertainty.sampler.posterior_shape_model.psm_skew import SkewPosteriorShapeModelSampler
+    psm, mu, cov = _inputs(golden_dir, f=1, seed=12)
+    alpha = _alpha(1, seed=13)
+    smp = SkewPosteriorShapeModelSampler(golden_dir / "camus-cont_psm_11_no_std.npz")
+    a = smp.sample_batch(mu.cuda(), cov.cuda(), alpha.cuda(), n=2048, seed=21).cpu()
+    b = smp.sample_batch(mu.cuda(), cov.cuda(), alpha.cuda(), n=2048, seed=21).cpu()
+    c = smp.sample_batch(mu.cuda(), cov.cuda(), alpha.cuda(), n=2048, seed=22).cpu()
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+    al = alpha[0] * torch.tensor([1.0, -1.0])
+    for j in (0, 10, 20):
+        delta = cov[0, j] @ al[j] / torch.sqrt(1 + al[j] @ cov[0, j] @ al[j])
+        mean = mu[0, j] + math.sqrt(2 / math.pi) * delta
+        se = torch.sqrt(torch.diagonal(cov[0, j]) / 2048)
+        assert ((a[0, :, j].mean(0) - mean).abs() < 5 * se).all()
+    # level-1 points: given the anchors the kernel drew, point j follows the normalised table
+    # skew-pdf(prediction) x N(mu_c, cov_c); sum_i (x_i - E_i[x]) / sqrt(sum_i Var_i[x]) is a standard normal
+    orc = S.SkewPSMSamplerOracle(psm)
+    X, Y, grid = S.make_grid(256)
+    pca_mu, Q = S.pca(orc.X_train, orc.transform(mu[0]).reshape(-1, 1))
+    for j in (5, 15):
+        p1 = torch.exp(S.skew_logpdf(grid, mu[0, j], cov[0, j], al[j]))
+        num, var = torch.zeros(2, dtype=torch.double), torch.zeros(2, dtype=torch.double)
+        for i in range(96):
+            contour = torch.zeros(21, 2)
+            contour[[0, 10, 20]] = a[0, i, [0, 10, 20]]
+            mu_c, cov_c = orc.compute_psm(contour, [0, 10, 20], 1, pca_mu, Q)
+            p = (p1 * S.mvn_pdf(grid, mu_c[j], cov_c[j])).double()
+            p = p / p.sum()
+            ex, ey = (p * X).sum(), (p * Y).sum()
+            num += a[0, i, j].double() - torch.stack([ex, ey])
+            var += torch.stack([(p * (X - ex) ** 2).sum(), (p * (Y - ey) ** 2).sum()])
+        z = num / var.sqrt()
+        assert (z.abs() < 5).all(), (j, z)
+
+
+def test_sequence_sampler_matches_oracle(golden_dir):
+    from contour_uncertainty.sampler.posterior_shape_model.sequence_sampler import SequencePSMSampler
+    psm = dict(np.load(golden_dir / "camus-cont_psm_11_no_std.npz"))
+    seq = dict(np.load(golden_dir / "camus-cont_sequence_psm_11_no_std.npz"))
+    g = torch.Generator().manual_seed(3)
+    mu = torch.tensor(seq["X_val"][5] + seq["scaler_mean"]).float().reshape(2, 21, 2) + torch.randn(2, 21, 2, generator=g)
+    a = torch.randn(2, 21, 2, 2, generator=g)
+    cov = a @ a.transpose(-1, -2) * 6.0 + torch.eye(2) * 2.0
+    smp = SequencePSMSampler(golden_dir / "camus-cont_psm_11_no_std.npz", golden_dir / "camus-cont_sequence_psm_11_no_std.npz")
+    firsts = [0, 1, 1, 0, 1]
+    eps = torch.randn(len(firsts), 2, 21, 2, generator=g)
+    out = smp.sample_sequence(mu.cuda(), cov.cuda(), firsts, eps=eps).cpu()
+    assert out.shape == (5, 2, 21, 2)
+    with _F64():
+        orc = S.SequencePSMSamplerOracle(psm, seq, dtype=torch.float64)
+        ref = orc.sample(mu.double(), cov.double(), firsts, eps.double())
+        r0 = orc.sample_two_contours(mu.double(), cov.double(), 0, eps[0].double())
+    assert float((out.double() - ref).abs().max()) < 3e-2, float((out.double() - ref).abs().max())
+    # the conditional / merged rows of the second instant
+    d = smp.sample_two_contours(mu.cuda(), cov.cuda(), first_sample=r0["s"][0].float(), first_instant=0)
+    assert float((d["mu_c"].cpu().double() - r0["mu_c"][1]).abs().max()) < 2e-2
+    assert float((d["cov_c"].cpu().double() - r0["cov_c"][1]).abs().max()) < 2e-2
+    assert float((d["mu_f"].cpu().double() - r0["mu_f"][1]).abs().max()) < 2e-2
+    assert float((d["cov_f"].cpu().double() - r0["cov_f"][1]).abs().max()) < 2e-2
+    import random
+    random.seed(4)
+    exp_firsts = [random.randint(0, 1) for _ in range(7)]
+    random.seed(4)
+    o = smp(mu.cuda(), cov.cuda(), n=7)
+    assert o.shape == (7, 2, 21, 2) and len(exp_firsts) == 7 and torch.isfinite(o).all()
+
+
+def test_sequence_skew_sampler_matches_oracle(golden_dir):
+    from contour_uncertainty.sampler.posterior_shape_model.psm_skew_sequence import SequenceSkewPSMSampler
+    psm = dict(np.load(golden_dir / "camus-cont_psm_11_no_std.npz"))
+    seq = dict(np.load(golden_dir / "camus-cont_sequence_psm_11_no_std.npz"))
+    g = torch.Generator().manual_seed(31)
+    mu = torch.tensor(seq["X_val"][9] + seq["scaler_mean"]).float().reshape(2, 21, 2) + torch.randn(2, 21, 2, generator=g)
+    a = torch.randn(2, 21, 2, 2, generator=g)
+    cov = a @ a.transpose(-1, -2) * 6.0 + torch.eye(2) * 2.0
+    alpha = torch.randn(2, 21, 2, generator=g) * 2.0
+    smp = SequenceSkewPSMSampler(golden_dir / "camus-cont_psm_11_no_std.npz", golden_dir / "camus-cont_sequence_psm_11_no_std.npz")
+    firsts = [0, 1, 1, 0, 0, 1]
+    eps = torch.randn(len(firsts), 2, 21, 3, generator=g)
+    u = torch.rand(len(firsts), 2, 21, generator=g)
+    out = smp.sample_sequence(mu.cuda(), cov.cuda(), alpha.cuda(), firsts, eps=eps, u=u).cpu()
+    with _F64():
+        orc = S.SequenceSkewPSMSamplerOracle(psm, seq, dtype=torch.float64)
+        ref = orc.sample(mu.double(), cov.double(), alpha.double(), firsts, eps.double(), u.double()).permute(1, 0, 2, 3)
+    d = (out.double() - ref).abs().flatten(-2).max(-1).values       # (n, 2)
+    assert float((d < 0.05).double().mean()) >= 0.75 and float(d.max()) < 8.0, (d,)
+    o = smp(mu.cuda(), cov.cuda(), alpha.cuda(), n=4)
+    assert o.shape == (2, 4, 21, 2) and torch.isfinite(o).all()

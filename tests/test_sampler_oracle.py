@@ -69,3 +69,47 @@ def test_sampler_statistics_anchor_points(golden_dir):
         assert torch.allclose(out[:, j].mean(0), mu[j], atol=0.6)
         c = torch.cov(out[:, j].T)
         assert torch.allclose(c, cov[j], atol=2.5)
+
+
+def test_skew_grid_tables_match_reference(golden_dir):
+    """oracle densities / normalised product / rvs_fast / two-instant conditional vs outputs of the imported reference."""
+    from oracle import sampler as S
+    g = np.load(golden_dir / "skew_grid.npz")
+    X, Y, grid = S.make_grid(256)
+    for i in range(3):
+        m1, c1, a1, m2, c2 = (torch.from_numpy(g[f"c{i}_{k}"]) for k in ("mu1", "cov1", "alpha1", "mu2", "cov2"))
+        p1 = torch.exp(S.skew_logpdf(grid, m1, c1, a1))
+        p2 = S.mvn_pdf(grid, m2, c2)
+        assert torch.allclose(p1, torch.from_numpy(g[f"c{i}_p1"]), rtol=2e-4, atol=1e-9)
+        assert torch.allclose(p2, torch.from_numpy(g[f"c{i}_p2"]), rtol=2e-4, atol=1e-12)
+        assert torch.allclose(torch.exp(S.gauss_logpdf(grid, m2, c2)), torch.from_numpy(g[f"c{i}_p2_bn"]), rtol=2e-4, atol=1e-12)
+        p = p1 * p2
+        p = p / p.sum()
+        ref = torch.from_numpy(g[f"c{i}_p"])
+        assert torch.allclose(p, ref, rtol=5e-4, atol=1e-10)
+        # the inverse-CDF pick selects the same cells from the oracle's and the reference's table
+        for u in (0.0, 0.013, 0.25, 0.5, 0.77, 0.999):
+            a, b = S.inverse_cdf_pick(p, u), S.inverse_cdf_pick(ref, u)
+            assert abs(a - b) <= 1 or abs(abs(a - b) - 256) <= 1
+    x = S.rvs_fast(torch.from_numpy(g["rvs_mu"]), torch.from_numpy(g["rvs_cov"]), torch.from_numpy(g["rvs_alpha"]),
+                   torch.from_numpy(g["rvs_eps"]))
+    assert torch.allclose(x, torch.from_numpy(g["rvs_x"]), rtol=1e-5, atol=1e-4)
+
+
+def test_sequence_conditional_matches_reference(golden_dir):
+    """Two-instant PSM conditional (sequence_sampler.py:83, psm_skew_sequence.py:66,78) on the shipped 84-dim model."""
+    from oracle import sampler as S
+    g = np.load(golden_dir / "skew_grid.npz")
+    seq = dict(np.load(golden_dir / "camus-cont_sequence_psm_11_no_std.npz"))
+    smu, sQ = torch.from_numpy(seq["mu"]).float(), torch.from_numpy(seq["Q"]).float()
+    blocks = lambda c: torch.stack([c[2 * i:2 * i + 2, 2 * i:2 * i + 2] for i in range(42)])
+    for first in (0, 1):
+        sg = torch.from_numpy(g[f"seq{first}_sg"]).reshape(-1, 1)
+        idx = S.index_to_flat(list(range(21)) if first == 0 else list(range(21, 42)))
+        mu_c, cov_c = S.posterior_shape_model(sg, idx, smu, sQ, sigma2=1)
+        assert torch.allclose(mu_c.squeeze(), torch.from_numpy(g[f"seq{first}_mu_c"]), rtol=1e-4, atol=5e-3)
+        assert torch.allclose(blocks(cov_c), torch.from_numpy(g[f"seq{first}_cov_blocks"]), rtol=1e-3, atol=5e-3)
+        pm, pQ = S.pca(torch.from_numpy(seq["X_train"]).float(), torch.from_numpy(g["seq_xv"]).reshape(-1, 1))
+        mu_c, cov_c = S.posterior_shape_model(sg, idx, pm, pQ, sigma2=1)
+        assert torch.allclose(mu_c.squeeze(), torch.from_numpy(g[f"seqpca{first}_mu_c"]), rtol=1e-3, atol=5e-2)
+        assert torch.allclose(blocks(cov_c), torch.from_numpy(g[f"seqpca{first}_cov_blocks"]), rtol=1e-2, atol=5e-2)

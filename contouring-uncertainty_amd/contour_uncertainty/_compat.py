@@ -141,6 +141,21 @@ except ImportError:
         def log(self, name, value, **_kw):
             self.logged[name] = value
 
+        # checkpoints in Lightning's layout: {"state_dict": ..., "hyper_parameters": ...}
+        def save_checkpoint(self, path):
+            hp = {k: v for k, v in self._hparams.items() if k != "task"}
+            torch.save({"state_dict": self.state_dict(), "hyper_parameters": hp}, str(path))
+
+        @classmethod
+        def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict: bool = True, **overrides):
+            ckpt = torch.load(str(checkpoint_path), map_location=map_location or "cpu", weights_only=False)
+            hp = dict(ckpt.get("hyper_parameters", {}))
+            hp.pop("task", None)
+            hp.update(overrides)
+            obj = cls(**hp)
+            obj.load_state_dict(ckpt["state_dict"], strict=strict)
+            return obj
+
         def log_dict(self, d, **_kw):
             self.logged.update(d)
 
@@ -198,6 +213,15 @@ except ImportError:
             result = prefix(self._shared_step(*args, **kwargs), "test/")
             self.log_dict(result, **(self.hparams.get("val_log_kwargs") or {}))
             return result
+
+
+def resolve_model_checkpoint_path(checkpoint):
+    """vital.utils.saving.resolve_model_checkpoint_path for local files (Comet model-registry lookups are host glue)."""
+    from pathlib import Path
+    path = Path(str(checkpoint))
+    if not path.exists():
+        raise FileNotFoundError(f"checkpoint {checkpoint} not found (only local checkpoint files are supported)")
+    return path
 
 
 def fused_optimizer_cfg(optim_cfg):

@@ -92,7 +92,7 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module: "UNet", x: Tensor, *params: Tensor):
         P = dict(zip(module._pnames, params))
-        logits, feats, ectx = module.engine.forward(P, x, module.bottleneck_out, module.training)
+        logits, feats, ectx = module.engine.forward(P, x, module.bottleneck_out, module.training or module.mc_dropout)
         ctx.module, ctx.ectx = module, ectx
         ctx.save_for_backward(*params)
         if module.bottleneck_out:
@@ -187,6 +187,7 @@ class UNet(nn.Module):
         self.engine = UNetEngine(self.in_channels, self.num_classes, st, f, negative_slope, 1e-5,
                                  _dtype_of(compute_dtype))
         self.drop_block = drop_block
+        self.mc_dropout = False     # True: Dropout2d stays active in eval mode (reference utils/mcdropout.py:89-137)
         if drop_block:
             # reference unet2.py:129-136 (bottleneck) and :302 (`len(in_channels) - i <= 2`: the last two downsamples);
             # both ConvLayers of a block get the Dropout2d (layers.py:231-232)

@@ -66,8 +66,10 @@ class DSNTAleatoric(AleatoricUncertaintyTask):
 
     def predict(self, img, scale=False) -> Tuple:  # noqa: D102
         S, cov = [], []
-        for _ in range(self.hparams.t_e):
-            pixel_coords, pixel_sigma = self.predict_on_batch(img, self.model)
+        self.hparams.t_e = len(self.model) if self.ensembling else self.hparams.t_e
+        for i in range(self.hparams.t_e):
+            model = self.model[i] if self.ensembling else self.model
+            pixel_coords, pixel_sigma = self.predict_on_batch(img, model)
             S.append(pixel_coords)
             cov.append(pixel_sigma)
         S = torch.stack(S).swapaxes(1, 0)          # (N, T_e, K, 2)

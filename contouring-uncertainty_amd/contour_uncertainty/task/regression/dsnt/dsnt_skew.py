@@ -24,6 +24,9 @@ class DSNTSkew(SkewUncertaintyTask):
                  freeze_seg: bool = False, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.save_hyperparameters()
+        if self.ensembling:
+            # the reference fails here too: nn.ModuleList has no confidence_net (dsnt_skew.py:34 after uncertainty.py:58)
+            raise NotImplementedError("ensemble_ckpt is not usable with dsnt-skew (one skew head, many networks)")
         self.skew_block = self.model.confidence_net(len(self.skew_indices) * 2)
         if hasattr(self.model, "engine"):
             self.skew_block.set_compute_dtype(self.model.engine.dtype)
@@ -74,8 +77,10 @@ class DSNTSkew(SkewUncertaintyTask):
 
     def predict(self, img, scale=False) -> Tuple:  # noqa: D102
         S, cov, alpha = [], [], []
-        for _ in range(self.hparams.t_e):
-            m, s, a = self.predict_on_batch(img, self.model)
+        self.hparams.t_e = len(self.model) if self.ensembling else self.hparams.t_e
+        for i in range(self.hparams.t_e):
+            model = self.model[i] if self.ensembling else self.model
+            m, s, a = self.predict_on_batch(img, model)
             S.append(m)
             cov.append(s)
             alpha.append(a)

@@ -1,6 +1,8 @@
 """``contour_uncertainty.task.uncertainty.UncertaintyTask`` (reference task/uncertainty.py:27-150): boilerplate common
 to all uncertainty methods.  Only what the DSNT train/val/predict path uses is kept; MC-dropout patching, ensembling
-checkpoints and figure upload are host-side features outside the accelerated path."""
+figure upload is a host-side feature outside the accelerated path.  ``t_e > 1`` keeps
+Dropout2d active at predict time (MC dropout, reference utils/mcdropout.py:89-137) and ``ensemble_ckpt`` loads one
+network per checkpoint (reference uncertainty.py:55-70)."""
 from __future__ import annotations
 
 from typing import Any, Dict, List, Union
@@ -22,12 +24,28 @@ class UncertaintyTask(SharedStepsTask):
         self.model = self.configure_model()
         self.is_val_step = False
         if ensemble_ckpt is not None:
-            raise NotImplementedError("checkpoint ensembling (reference uncertainty.py:55-70) is out of scope of the "
-                                      "accelerated path")
-        self.ensembling = False
-        if self.hparams.t_e > 1:
-            raise NotImplementedError("t_e > 1 keeps Dropout2d active at predict time (reference utils/mcdropout.py); "
-                                      "drop_block is not enabled on this path yet")
+            from pathlib import Path
+            from torch import nn
+            from contour_uncertainty._compat import resolve_model_checkpoint_path
+            self.ensembling = True
+            if isinstance(ensemble_ckpt, (list, tuple)):
+                files = list(ensemble_ckpt)
+            elif Path(str(ensemble_ckpt)).is_dir():
+                files = sorted(Path(str(ensemble_ckpt)).glob("*.ckpt"))
+            else:
+                raise ValueError("ENSEMBLE not valid")
+            self.model = nn.ModuleList(
+                [self.load_from_checkpoint(resolve_model_checkpoint_path(w), ensemble_ckpt=None).model for w in files])
+            self.hparams.t_e = len(self.model)
+        else:
+            self.ensembling = False
+            if self.hparams.t_e > 1:
+                # keep dropout at test time (reference: patch_module swaps nn.Dropout2d for an always-on layer)
+                if getattr(self.model, "drop_block", False):
+                    self.model.mc_dropout = True
+                else:
+                    import warnings
+                    warnings.warn("No layer was modified by patch_module!", UserWarning)
 
     def forward(self, *args, **kwargs):  # noqa: D102
         return self.model(*args, **kwargs)

@@ -22,15 +22,16 @@ def model_cfg(n_stages, dtype):
             "deep_supervision": False, "compute_dtype": dtype}
 
 
-def make_task(kind, n_stages, size, dtype, **kw):
+def make_task(kind, n_stages, size, dtype, t_e=1, drop_block=False, **kw):
     from contour_uncertainty._compat import DataParameters
     from contour_uncertainty.task.regression.dsnt.dsnt_al import DSNTAleatoric
     from contour_uncertainty.task.regression.dsnt.dsnt_skew import DSNTSkew
     cls = DSNTSkew if kind == "dsnt-skew" else DSNTAleatoric
     optim = {"_target_": "torch.optim.Adam", "lr": 1e-3, "weight_decay": 1e-3}
-    return cls(model=model_cfg(n_stages, dtype), optim=optim, choices={},
+    cfg = dict(model_cfg(n_stages, dtype), drop_block=drop_block)
+    return cls(model=cfg, optim=optim, choices={},
                data_params=DataParameters((1, size, size), (21, 2), [0, 1]), psm_path="camus-cont_psm_11_no_std.npy",
-               seq_psm_path="camus-cont_sequence_psm_11_no_std.npy", t_a=25, t_e=1, covar=True, **kw)
+               seq_psm_path="camus-cont_sequence_psm_11_no_std.npy", t_a=25, t_e=t_e, covar=True, **kw)
 
 
 def hip_kink_masks(model):
@@ -300,3 +301,38 @@ def test_drop_block_matches_oracle_with_shared_masks():
         ev = net(img.to(DEV))
     ref_eval = OU.unet_forward(sd, img, spec)
     assert torch.allclose(ev.cpu(), ref_eval, rtol=1e-3, atol=1e-3)
+
+
+def test_mc_dropout_and_ensemble_predict(tmp_path):
+    """t_e > 1 keeps Dropout2d active at predict time (reference uncertainty.py:71-75 + utils/mcdropout.py:89-137);
+    ensemble_ckpt builds one network per checkpoint and predict() stacks them (uncertainty.py:55-70, dsnt_al.py:133-151)."""
+    img, _ = synthetic_batch(2, 64, 21, seed=8)
+    torch.manual_seed(0)
+    t = make_task("dsnt-al", 6, 64, "f32", t_e=3, drop_block=True).to(DEV).eval()
+    assert t.model.mc_dropout
+    mu, cov = t.predict(img.to(DEV))
+    assert mu.shape == (2, 3, 21, 2) and cov.shape == (2, 3, 21, 2, 2)
+    assert not torch.allclose(mu[:, 0], mu[:, 1])            # different dropout masks per epistemic sample
+    t1 = make_task("dsnt-al", 6, 64, "f32", t_e=1, drop_block=True).to(DEV).eval()
+    a, _ = t1.predict(img.to(DEV))
+    b, _ = t1.predict(img.to(DEV))
+    assert torch.allclose(a, b, rtol=0, atol=1e-4) and a.shape == (2, 1, 21, 2)    # t_e = 1: dropout is off in eval mode
+    with pytest.warns(UserWarning):
+        make_task("dsnt-al", 6, 64, "f32", t_e=2, drop_block=False)
+    # ensemble of two differently initialised networks
+    singles, paths = [], []
+    for i in range(2):
+        torch.manual_seed(10 + i)
+        m = make_task("dsnt-al", 6, 64, "f32").to(DEV).eval()
+        singles.append(m.predict(img.to(DEV)))
+        paths.append(tmp_path / f"m{i}.ckpt")
+        m.save_checkpoint(paths[-1])
+    ens = make_task("dsnt-al", 6, 64, "f32", ensemble_ckpt=[str(p) for p in paths]).to(DEV).eval()
+    assert ens.ensembling and len(ens.model) == 2
+    mu, cov = ens.predict(img.to(DEV))
+    assert ens.hparams.t_e == 2 and mu.shape == (2, 2, 21, 2)
+    for i in range(2):
+        assert torch.allclose(mu[:, i], singles[i][0][:, 0], rtol=1e-5, atol=1e-4)
+        assert torch.allclose(cov[:, i], singles[i][1][:, 0], rtol=1e-4, atol=1e-3)
+    ens_dir = make_task("dsnt-al", 6, 64, "f32", ensemble_ckpt=str(tmp_path))
+    assert len(ens_dir.model) == 2

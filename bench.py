@@ -187,7 +187,7 @@ def main():
         ops.PROFILE_ON[0] = False
     if rank == 0 and not args.no_roofline:
         fam = {}
-        for name, flops, e0, e1 in ops.PROFILE:
+        for name, flops, e0, e1, *_ in ops.PROFILE:
             ms_k = e0.elapsed_time(e1)
             f = fam.setdefault(name, [0.0, 0.0, 0])
             f[0] += flops

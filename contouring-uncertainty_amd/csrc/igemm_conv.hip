@@ -69,7 +69,7 @@ template <> struct Cfg<float> {
 // so a lane owns one pixel and 4 consecutive output channels per register quad -> 8/16-byte epilogue stores.
 //   PLAIN: the sources need no affine / activation (materialised activations): staging is a pure 16-byte copy.
 template <typename T, int MA, int NB, int NX, int NT, bool WRES, bool PLAIN>
-__global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvKArgs p) {
+__global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const ConvKArgs p) {
     using C = Cfg<T>;
     constexpr int CK = C::CK, PIECE = C::PIECE, PPP = C::PPP, WPL = C::WPLANES;
     constexpr int BN = 32 * NB;

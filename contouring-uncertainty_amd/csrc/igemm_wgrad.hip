@@ -30,6 +30,8 @@ struct WgKArgs {
     unsigned mg_shpi, mg_shw, mg_zhpi, mg_zhw; // ceil(2^32/d) magics for the halo index decode
     float slope0, slope1;
     int zsame;                                 // all taps read the same Z pixel
+    unsigned src0_bytes, src1_bytes, z_bytes;  // tensor sizes (LDS-DMA kernel: buffer resources, out-of-range = zero fill)
+    int s_iters, z_iters;                      // LDS-DMA kernel: 4-KiB staging blocks per tile for S / Z
     int dbg;                                   // CU_CONV_DBG bits (timing experiments): 1 no atomics, 2 no MFMA, 4 no commit, 8 no loads
 };
 
@@ -215,43 +217,67 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
         if (!wave_active || (p.dbg & 2)) continue;
 
         const int NK = p.tile_px / KPIX;
-        for (int ks = kpart; ks < NK; ks += KSPLIT) {
-            if constexpr (sizeof(T) == 2) {
-                // lane l = 16g + 4q + pp supplies row q of its group's 4x16 transpose block
-                const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-                const int hh = g >> 1, chalf = g & 1;
+        if constexpr (sizeof(T) == 2) {
+            // Software-pipelined k-loop: the fragments of k-step i+1 are read from LDS while the MFMAs of k-step i run
+            // (ping-pong register buffers).  With one wave per SIMD nothing else hides the LDS latency.
+            // lane l = 16g + 4q + pp supplies row q of its group's 4x16 transpose block
+            const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+            const int hh = g >> 1, chalf = g & 1;
+            const int s_col = (cblk * 32 + 16 * chalf + 4 * pp) * 2, z_col = (nblk * 32 + 16 * chalf + 4 * pp) * 2;
+            const int NKW = NK / KSPLIT;                     // k-steps of this wave: kpart, kpart + KSPLIT, ...
+            constexpr int NA = NTAPS == 4 ? NTAPS : 1;       // only the 2x2 transposed conv shifts Z per tap
+            auto load = [&](int i, bf16x8 (&A)[NA], bf16x8 (&B)[NTAPS]) {
+                const int ks = kpart + (i < NKW ? i : NKW - 1) * KSPLIT;    // clamped: the tail re-reads a valid step
                 int sbase[2], zbase[2];
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int m = ks * 16 + 8 * hh + 4 * half + q;
                     const int tx = m & (TW - 1), ty = (m >> p.twl) & (TH - 1), im = m >> (p.twl + p.thl);
-                    sbase[half] = (im * s_hpi + ty * p.IS * p.SHW + tx * p.IS) * ROWS_B + (cblk * 32 + 16 * chalf + 4 * pp) * 2;
-                    zbase[half] = (im * z_hpi + ty * p.ZS * p.ZHW + tx * p.ZS) * ROWZ_B + (nblk * 32 + 16 * chalf + 4 * pp) * 2;
+                    sbase[half] = (im * s_hpi + ty * p.IS * p.SHW + tx * p.IS) * ROWS_B + s_col;
+                    zbase[half] = (im * z_hpi + ty * p.ZS * p.ZHW + tx * p.ZS) * ROWZ_B + z_col;
                 }
-                bf16x8 af;
-                if (p.zsame) {
-                    const bf16x4 a0 = tr_read(Zs + zbase[0] + p.z_off[0] * ROWZ_B);
-                    const bf16x4 a1 = tr_read(Zs + zbase[1] + p.z_off[0] * ROWZ_B);
-                    af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int t = 0; t < NA; ++t) {
+                    const bf16x4 a0 = tr_read(Zs + zbase[0] + p.z_off[t] * ROWZ_B);
+                    const bf16x4 a1 = tr_read(Zs + zbase[1] + p.z_off[t] * ROWZ_B);
+                    A[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
-                bf16x8 bfr[NTAPS], afr[NTAPS];
 #pragma unroll
                 for (int t = 0; t < NTAPS; ++t) {
-                    if (!p.zsame) {
-                        const bf16x4 a0 = tr_read(Zs + zbase[0] + p.z_off[t] * ROWZ_B);
-                        const bf16x4 a1 = tr_read(Zs + zbase[1] + p.z_off[t] * ROWZ_B);
-                        afr[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    } else {
-                        afr[t] = af;
-                    }
                     const bf16x4 b0 = tr_read(Ss + sbase[0] + p.s_off[t] * ROWS_B);
                     const bf16x4 b1 = tr_read(Ss + sbase[1] + p.s_off[t] * ROWS_B);
-                    bfr[t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    B[t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
+            };
+            auto mma = [&](const bf16x8 (&A)[NA], const bf16x8 (&B)[NTAPS]) {
 #pragma unroll
                 for (int t = 0; t < NTAPS; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[t], bfr[t], acc[t], 0, 0, 0);
-            } else {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[NA == 1 ? 0 : t], B[t], acc[t], 0, 0, 0);
+            };
+            bf16x8 A0[NA], B0[NTAPS], A1[NA], B1[NTAPS];
+            // one pipeline stage: issue the reads of step `nxt` while the MFMAs of the current step run; the group
+            // barriers pin the order "1 MFMA, 2 LDS reads" so that no MFMA waits on a read issued in the same stage
+            auto stage = [&](const bf16x8 (&Ac)[NA], const bf16x8 (&Bc)[NTAPS], int nxt, bf16x8 (&An)[NA], bf16x8 (&Bn)[NTAPS]) {
+                __builtin_amdgcn_sched_barrier(0);
+                load(nxt, An, Bn);
+                mma(Ac, Bc);
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NA, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            load(0, A0, B0);
+            int i = 0;
+            for (; i + 2 <= NKW; i += 2) {
+                stage(A0, B0, i + 1, A1, B1);
+                stage(A1, B1, i + 2, A0, B0);
+            }
+            if (i < NKW) mma(A0, B0);
+        } else {
+            for (int ks = kpart; ks < NK; ks += KSPLIT) {
                 const int r = lane & 31, hh = lane >> 5;
                 const int m = ks * 2 + hh;
                 const int tx = m & (TW - 1), ty = (m >> p.twl) & (TH - 1), im = m >> (p.twl + p.thl);
@@ -280,6 +306,248 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
             if (n < p.CO) unsafeAtomicAdd(p.dw + ((size_t)p.tap_w[t] * p.CO + n) * CI + c, acc[t][i]);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 production variant: staging by LDS-DMA (buffer_load_dwordx4 ... lds), two LDS images, software-pipelined k-loop.
+//   * no staging registers and no commit phase: the DMA of tile i+1 is in flight during the whole k-loop of tile i and
+//     is retired by the vmcnt(0) + barrier at the top of the next tile (one barrier per tile);
+//   * zero padding (image border, ragged tiles, channel tail) comes from the buffer range check: lanes that must read
+//     zeros get an out-of-range offset;
+//   * the LDS image is lane-linear (16-byte slot i <- staging item i).  Items are ordered [32-channel plane][halo pixel]
+//     [4 pieces]: 64-byte rows, so the 4 rows of a transpose read fall on 4 distinct bank quarters without padding or
+//     swizzle, and a wave's block (cblk / nblk) simply selects its plane.
+constexpr int DMA_IMG_BYTES = 78 * 1024;      // per image; two of them per workgroup
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// buffer resource (V#) of a raw byte buffer: out-of-range offsets read zeros
+__device__ __forceinline__ i32x4 make_rsrc(const void* ptr, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+// One LDS-DMA wave instruction: lane l copies 16 bytes from rsrc + voff(l) to LDS byte address lds_base + 16 l.
+// Issued from inline asm on purpose: hipcc orders every later LDS read behind an LDS-DMA it knows about
+// (s_waitcnt vmcnt(0) in front of the first ds_read_tr of the k-loop), which would serialise the copy of tile i+1 with
+// the MFMAs of tile i.  The copies are retired by hand: dma_wait() before the barrier that hands the image over.
+__device__ __forceinline__ void dma16(const i32x4 rsrc, unsigned voff, unsigned lds_base) {
+    unsigned keep;
+    lds_base = __builtin_amdgcn_readfirstlane(lds_base);      // wave-uniform by construction: make it an SGPR
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p);
+}
+
+template <int NBLK, int CBLK, int NTAPS>
+__global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const WgKArgs p) {
+    constexpr int TN = 32 * NBLK, TC = 32 * CBLK;
+    constexpr int NWB = NBLK * CBLK, KSPLIT = 4 / NWB;
+    constexpr int ROW_B = 64;                          // one pixel of one 32-channel plane
+    // Two STATIC images: the compiler orders a ds_read after an in-flight LDS-DMA only when both may touch the same
+    // LDS object, so reads of one image do not wait (vmcnt) for the DMA that fills the other one.
+    __shared__ __attribute__((aligned(16))) unsigned char imgA[DMA_IMG_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char imgB[DMA_IMG_BYTES];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int blk = wave % NWB, kpart = wave / NWB;
+    const int nblk = blk / CBLK, cblk = blk % CBLK;
+    const int TW = 1 << p.twl, TH = 1 << p.thl;
+    const int CI = p.C0 + p.C1;
+    const int ct = blockIdx.x % p.ctiles, nt = blockIdx.x / p.ctiles;
+    const int c_base = ct * TC, n_base = nt * TN;
+    const int s_hpi = p.SHH * p.SHW, z_hpi = p.ZHH * p.ZHW;
+    const bool wave_active = (n_base + nblk * 32 < p.CO) && (c_base + cblk * 32 < CI);
+    const int s_img_bytes = p.s_iters * 4096;
+
+    const i32x4 rs0 = make_rsrc(p.src0, p.src0_bytes);
+    const i32x4 rs1 = make_rsrc(p.src1 ? p.src1 : p.src0, p.src1 ? p.src1_bytes : 0u);
+    const i32x4 rz = make_rsrc(p.z, p.z_bytes);
+    constexpr unsigned OOB = 0x7ffffff0u;
+
+    f32x16 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int slot = tid & 3;       // 256 % 4 == 0: a thread always stages the same 16-byte piece of a pixel
+
+    // staging of one tile = s_iters + z_iters wave-level DMA instructions per wave, issued back to back right after the
+    // barrier (measured: spreading them over the k-steps stalls the MFMA pipeline far more than it hides, 157 -> 191 us)
+    int g_img0 = 0, g_sy0 = 0, g_sx0 = 0, g_zy0 = 0, g_zx0 = 0;
+    auto tile_geo = [&](int tile) {
+        int bx = tile;
+        const int tile_x = bx % p.tiles_x; bx /= p.tiles_x;
+        const int tile_y = bx % p.tiles_y;
+        const int ig = bx / p.tiles_y;
+        const int py0 = tile_y << p.thl, px0 = tile_x << p.twl;
+        g_img0 = ig << p.iml;
+        g_sy0 = py0 * p.IS + p.sdymin; g_sx0 = px0 * p.IS + p.sdxmin;
+        g_zy0 = py0 * p.ZS + p.zdymin; g_zx0 = px0 * p.ZS + p.zdxmin;
+    };
+    auto issue_item = [&](int j, unsigned char* img) {
+        if (j < p.s_iters) {
+            const int i = (tid + j * 256) >> 2;                          // plane-major pixel index
+            const int pl = (CBLK == 2 && i >= p.s_halo) ? 1 : 0;
+            const int hp = i - pl * p.s_halo;
+            const int im = __umulhi((unsigned)hp, p.mg_shpi), rem = hp - im * s_hpi;
+            const int hy = __umulhi((unsigned)rem, p.mg_shw), hx = rem - hy * p.SHW;
+            const int c = c_base + pl * 32 + slot * 8;
+            const int n = g_img0 + im, sy = g_sy0 + hy, sx = g_sx0 + hx;
+            const bool ok = hp < p.s_halo && c < CI && n < p.N && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;
+            const bool s1 = c >= p.C0;
+            const unsigned pix = (unsigned)((n * p.SH + sy) * p.SW + sx);
+            const unsigned off = ok ? (pix * (unsigned)(s1 ? p.C1 : p.C0) + (unsigned)(s1 ? c - p.C0 : c)) * 2u : OOB;
+            const unsigned dst = lds_addr(img) + wave * 1024 + j * 4096;
+            if (s1) dma16(rs1, off, dst);
+            else dma16(rs0, off, dst);
+        } else {
+            const int jz = j - p.s_iters;
+            const int i = (tid + jz * 256) >> 2;
+            const int pl = (NBLK == 2 && i >= p.z_halo) ? 1 : 0;
+            const int hp = i - pl * p.z_halo;
+            const int im = __umulhi((unsigned)hp, p.mg_zhpi), rem = hp - im * z_hpi;
+            const int hy = __umulhi((unsigned)rem, p.mg_zhw), hx = rem - hy * p.ZHW;
+            const int col = n_base + pl * 32 + slot * 8;
+            const int n = g_img0 + im, zy = g_zy0 + hy, zx = g_zx0 + hx;
+            const bool ok = hp < p.z_halo && col < p.CO && n < p.N && zy >= 0 && zy < p.ZH && zx >= 0 && zx < p.ZW;
+            const unsigned pix = (unsigned)((n * p.ZH + zy) * p.ZW + zx);
+            const unsigned off = ok ? (pix * (unsigned)p.ZC + (unsigned)col) * 2u : OOB;
+            dma16(rz, off, lds_addr(img) + s_img_bytes + wave * 1024 + jz * 4096);
+        }
+    };
+    const int n_items = p.s_iters + p.z_iters;
+
+    // lane l = 16g + 4q + pp supplies row q of its group's 4x16 transpose block
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int hh = g >> 1, chalf = g & 1;
+    const int s_col = cblk * p.s_halo * ROW_B + (16 * chalf + 4 * pp) * 2;      // plane base + column inside the row
+    const int z_colb = nblk * p.z_halo * ROW_B + (16 * chalf + 4 * pp) * 2;
+    const int NK = p.tile_px / 16;
+    const int NKW = NK / KSPLIT;
+    constexpr int NA = NTAPS == 4 ? NTAPS : 1;
+
+    // one tile: wait for its image, start the DMA of the next tile into the other image, run the k-loop
+    long long t_wait = 0, t_bar = 0, t_issue = 0, t_loop = 0;     // CU_CONV_DBG bit 16: phase stamps of one workgroup
+    auto run_tile = [&](int tile, const unsigned char* cur, unsigned char* other) {
+        const long long c0 = (p.dbg & 16) ? wall_clock64() : 0;
+        dma_wait();           // this wave's share of the tile has landed ...
+        const long long c1 = (p.dbg & 16) ? wall_clock64() : 0;
+        __syncthreads();      // ... everybody's has, and the other image is no longer being read
+        const long long c2 = (p.dbg & 16) ? wall_clock64() : 0;
+        if (tile + p.splits < p.ntiles && !(p.dbg & 8)) {
+            tile_geo(tile + p.splits);
+            for (int j = 0; j < n_items; ++j) issue_item(j, other);
+        }
+        const long long c3 = (p.dbg & 16) ? wall_clock64() : 0;
+        t_wait += c1 - c0; t_bar += c2 - c1; t_issue += c3 - c2; t_loop -= c3;
+        if (!wave_active || (p.dbg & 2)) return;
+        const unsigned char* Ss = cur;
+        const unsigned char* Zs = cur + s_img_bytes;
+        auto load = [&](int i, bf16x8 (&A)[NA], bf16x8 (&B)[NTAPS]) {
+            const int ks = kpart + (i < NKW ? i : NKW - 1) * KSPLIT;
+            int sbase[2], zbase[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int m = ks * 16 + 8 * hh + 4 * half + q;
+                const int tx = m & (TW - 1), ty = (m >> p.twl) & (TH - 1), im = m >> (p.twl + p.thl);
+                sbase[half] = (im * s_hpi + ty * p.IS * p.SHW + tx * p.IS) * ROW_B + s_col;
+                zbase[half] = (im * z_hpi + ty * p.ZS * p.ZHW + tx * p.ZS) * ROW_B + z_colb;
+            }
+#pragma unroll
+            for (int t = 0; t < NA; ++t) {
+                const bf16x4 a0 = tr_read(Zs + zbase[0] + p.z_off[t] * ROW_B);
+                const bf16x4 a1 = tr_read(Zs + zbase[1] + p.z_off[t] * ROW_B);
+                A[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                const bf16x4 b0 = tr_read(Ss + sbase[0] + p.s_off[t] * ROW_B);
+                const bf16x4 b1 = tr_read(Ss + sbase[1] + p.s_off[t] * ROW_B);
+                B[t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        };
+        auto mma = [&](const bf16x8 (&A)[NA], const bf16x8 (&B)[NTAPS]) {
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[NA == 1 ? 0 : t], B[t], acc[t], 0, 0, 0);
+        };
+        bf16x8 A0[NA], B0[NTAPS], A1[NA], B1[NTAPS];
+        auto stage = [&](const bf16x8 (&Ac)[NA], const bf16x8 (&Bc)[NTAPS], int nxt, bf16x8 (&An)[NA], bf16x8 (&Bn)[NTAPS]) {
+            __builtin_amdgcn_sched_barrier(0);
+            load(nxt, An, Bn);
+            mma(Ac, Bc);
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NA, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        load(0, A0, B0);
+        int i = 0;
+        for (; i + 2 <= NKW; i += 2) {
+            stage(A0, B0, i + 1, A1, B1);
+            stage(A1, B1, i + 2, A0, B0);
+        }
+        if (i < NKW) mma(A0, B0);
+        if (p.dbg & 16) t_loop += wall_clock64();
+    };
+
+    int tile = blockIdx.y;
+    const long long k0 = (p.dbg & 16) ? wall_clock64() : 0;
+    if (tile < p.ntiles) {
+        tile_geo(tile);
+        for (int j = 0; j < n_items; ++j) issue_item(j, imgA);
+    }
+    const long long k1 = (p.dbg & 16) ? wall_clock64() : 0;
+    for (; tile < p.ntiles; tile += 2 * p.splits) {
+        run_tile(tile, imgA, imgB);
+        if (tile + p.splits < p.ntiles) run_tile(tile + p.splits, imgB, imgA);
+    }
+    if ((p.dbg & 16) && blockIdx.x == 0 && blockIdx.y == 0 && (tid & 63) == 0)
+        printf("[wgrad wave %d] 100MHz ticks: first issue %lld, wait %lld, barrier %lld, issue %lld, k-loop %lld, total %lld (tiles %d)\n",
+               wave, k1 - k0, t_wait, t_bar, t_issue, t_loop, wall_clock64() - k0, (p.ntiles - (int)blockIdx.y + p.splits - 1) / p.splits);
+
+    if (!wave_active || (p.dbg & 1)) return;
+    const int r = lane & 31, h2 = lane >> 5;
+    const int c = c_base + cblk * 32 + r;
+    if (c >= CI) return;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int n = n_base + nblk * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+            if (n < p.CO) unsafeAtomicAdd(p.dw + ((size_t)p.tap_w[t] * p.CO + n) * CI + c, acc[t][i]);
+        }
+    }
+}
+
+template <int NBLK, int CBLK, int NTAPS>
+int launch_dma(WgKArgs& a, hipStream_t st) {
+    CU_CHECK_ARG((size_t)(a.s_iters + a.z_iters) * 4096 <= (size_t)DMA_IMG_BYTES, "cu_conv_wgrad: tile image exceeds %d bytes", DMA_IMG_BYTES);
+    auto k = igemm_wgrad_dma_kernel<NBLK, CBLK, NTAPS>;
+    const int CI = a.C0 + a.C1;
+    a.ctiles = cdiv(CI, 32 * CBLK);
+    const int ntn = cdiv(a.CO, 32 * NBLK);
+    if (a.splits <= 0) {
+        // one workgroup per CU is resident (one wave per SIMD): every extra split only re-adds the dW tile atomically
+        int want = cdiv(256, a.ctiles * ntn);
+        a.splits = want < 1 ? 1 : want;
+    }
+    if (a.splits > a.ntiles) a.splits = a.ntiles;
+    hipLaunchKernelGGL(k, dim3(a.ctiles * ntn, a.splits), dim3(256), 0, st, a);
+    CU_LAUNCH_CHECK();
+    return 0;
 }
 
 template <typename T, int NBLK, int CBLK, int NS, int NZ, bool PLAIN, int NTAPS>
@@ -345,11 +613,8 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
     // loop-pixel tile: 128 pixels (64 for stride-2 gathers: 4x the halo), halved until both staged patches fit in LDS
     // Thin blocks (32x32, 64x32) get bigger pixel tiles so that every wave still has >= 8 k-steps between barriers;
     // first pass keeps the patches within 80 KiB (two workgroups per CU), second pass takes what fits.
-    int BM = (d->IS > 1 || d->ZS > 1) ? 64 : 512;
-    size_t lds_cap = 80 * 1024;
-    for (;; BM >>= 1) {
-        if (BM < 128 && lds_cap < 150 * 1024 && d->IS == 1 && d->ZS == 1) { BM = 128; lds_cap = 150 * 1024; }
-        CU_CHECK_ARG(BM >= 16 && BM >= kpix, "cu_conv_wgrad: patches do not fit in LDS");
+    // geometry of a loop-pixel tile of BM pixels (IMGS x TH x TW) and its two halo patches
+    auto geometry = [&](int BM) -> int {
         a.tile_px = BM;
         int tw = d->PW < 32 ? d->PW : 32;
         if (tw > BM) tw = BM;
@@ -387,6 +652,49 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
             a.tap_w[t] = d->tap_w[t];
             if (a.z_off[t] != a.z_off[0]) a.zsame = 0;
         }
+        return 0;
+    };
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool plain = !scale0 && d->slope0 == 1.0f && (d->C1 == 0 || (!scale1 && d->slope1 == 1.0f));
+    CU_CHECK_ARG(d->ntaps == 9 || d->ntaps == 4 || d->ntaps == 1, "cu_conv_wgrad: ntaps must be 9, 4 or 1 (got %d)", d->ntaps);
+    CU_CHECK_ARG(plain || d->ntaps == 9, "cu_conv_wgrad: fused-activation sources are only built for 3x3 taps");
+
+    // ---- bf16 production path: LDS-DMA staging, two LDS images (see igemm_wgrad_dma_kernel)
+    const size_t b0 = (size_t)d->N * d->SH * d->SW * d->C0 * 2, b1 = (size_t)d->N * d->SH * d->SW * d->C1 * 2;
+    const size_t bz = (size_t)d->N * d->ZH * d->ZW * d->ZC * 2;
+    const size_t lim = 0x7fff0000ull;
+    if (d->dtype == CU_BF16 && plain && b0 < lim && b1 < lim && bz < lim && !getenv("CU_WGRAD_NODMA")) {
+        const int spp = wc ? 8 : 4, zpp = wn ? 8 : 4;
+        for (int BM = (d->IS > 1 || d->ZS > 1) ? 64 : 256;; BM >>= 1) {
+            CU_CHECK_ARG(BM >= 16, "cu_conv_wgrad: patches do not fit in LDS");
+            const int rc = geometry(BM);
+            if (rc) return rc;
+            a.s_iters = cdiv(a.s_halo * spp, 256);
+            a.z_iters = cdiv(a.z_halo * zpp, 256);
+            if ((size_t)(a.s_iters + a.z_iters) * 4096 <= (size_t)DMA_IMG_BYTES) break;
+        }
+        CU_CHECK_ARG(d->ntaps == 4 || a.zsame, "cu_conv_wgrad: per-tap Z shifts are only built for 4 taps");
+        a.src0_bytes = (unsigned)b0; a.src1_bytes = (unsigned)b1; a.z_bytes = (unsigned)bz;
+#define CU_WD(NBv, CBv)                                                         \
+    do {                                                                        \
+        if (d->ntaps == 9) return launch_dma<NBv, CBv, 9>(a, st);               \
+        if (d->ntaps == 4) return launch_dma<NBv, CBv, 4>(a, st);               \
+        return launch_dma<NBv, CBv, 1>(a, st);                                  \
+    } while (0)
+        if (wn && wc) CU_WD(2, 2);
+        if (wn) CU_WD(2, 1);
+        if (wc) CU_WD(1, 2);
+        CU_WD(1, 1);
+#undef CU_WD
+    }
+
+    int BM = (d->IS > 1 || d->ZS > 1) ? 64 : 512;
+    size_t lds_cap = 80 * 1024;
+    for (;; BM >>= 1) {
+        if (BM < 128 && lds_cap < 150 * 1024 && d->IS == 1 && d->ZS == 1) { BM = 128; lds_cap = 150 * 1024; }
+        CU_CHECK_ARG(BM >= 16 && BM >= kpix, "cu_conv_wgrad: patches do not fit in LDS");
+        const int rc = geometry(BM);
+        if (rc) return rc;
         const int spp = (wc ? 64 : 32) / piece_elems, zpp = (wn ? 64 : 32) / piece_elems;
         if (d->IS > 1 || d->ZS > 1) lds_cap = 150 * 1024;
         if ((size_t)a.s_halo * rows_b + (size_t)a.z_halo * rowz_b <= lds_cap && a.s_halo * spp <= 256 * ns_big &&
@@ -396,10 +704,7 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
     const int spp_f = (wc ? 64 : 32) / piece_elems, zpp_f = (wn ? 64 : 32) / piece_elems;
     const bool small = a.s_halo * spp_f <= 256 * ns_small && a.z_halo * zpp_f <= 256 * nz_small;
 
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const bool plain = !scale0 && d->slope0 == 1.0f && (d->C1 == 0 || (!scale1 && d->slope1 == 1.0f));
-    CU_CHECK_ARG(d->ntaps == 9 || d->ntaps == 4 || d->ntaps == 1, "cu_conv_wgrad: ntaps must be 9, 4 or 1 (got %d)", d->ntaps);
-    CU_CHECK_ARG(plain || d->ntaps == 9, "cu_conv_wgrad: fused-activation sources are only built for 3x3 taps");
+    CU_CHECK_ARG(d->ntaps == 4 || a.zsame, "cu_conv_wgrad: per-tap Z shifts are only built for 4 taps");
 #define CU_WT(T, NBv, CBv, NSv, NZv)                                                   \
     do {                                                                               \
         if (!plain) return launch_k<T, NBv, CBv, NSv, NZv, false, 9>(a, st);           \

@@ -48,8 +48,8 @@ TRACE = bool(_os.environ.get("CU_TRACE"))    # debugging aid: synchronise and pr
 
 
 class _Prof:
-    def __init__(self, family: str, flops: float = 0.0):
-        self.family, self.flops = family, flops
+    def __init__(self, family: str, flops: float = 0.0, note: str = "", nbytes: float = 0.0):
+        self.family, self.flops, self.note, self.nbytes = family, flops, note, nbytes
 
     def __enter__(self):
         if PROFILE_ON[0]:
@@ -61,7 +61,7 @@ class _Prof:
     def __exit__(self, *exc):
         if PROFILE_ON[0]:
             self.e1.record()
-            PROFILE.append((self.family, self.flops, self.e0, self.e1))
+            PROFILE.append((self.family, self.flops, self.e0, self.e1, self.note, self.nbytes))
         if TRACE:
             torch.cuda.synchronize()
             print(f"[cu_trace] {self.family} flops={self.flops:.3g}", flush=True)
@@ -112,7 +112,11 @@ def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: T
     d.out_nchw_f32 = int(out_nchw)
     assert w.dtype == t0.dtype and w.shape[-1] == d.C0 + d.C1 and w.shape[-2] == d.CO, (w.shape, d.CO, d.C0, d.C1)
     flops = 2.0 * d.N * d.PH * d.PW * d.ntaps * (d.C0 + d.C1) * (d.DC0 if out_nchw else d.CO)
-    with _Prof("igemm_conv", flops):
+    esz = t0.element_size()
+    nbytes = (d.N * d.SH * d.SW * (d.C0 + d.C1) * esz if d.IS == 1 else d.N * d.PH * d.PW * d.ntaps * (d.C0 + d.C1) * esz) \
+        + d.N * d.PH * d.PW * d.CO * (4 if out_nchw else esz) * (2 if any(accum) else 1)
+    note = f"N{d.N} {d.PH}x{d.PW} IS{d.IS} OS{d.OS} C{d.C0}+{d.C1}->{d.CO} t{d.ntaps}"
+    with _Prof("igemm_conv", flops, note, nbytes):
         rc = lib.cu_conv_gemm(d, L.ptr(t0), L.ptr(sc0), L.ptr(sh0), L.ptr(t1), L.ptr(sc1), L.ptr(sh1), L.ptr(w),
                               L.ptr(bias), L.ptr(dst0), L.ptr(dsts[1]) if len(dsts) > 1 else None, L.stream_ptr())
     L.check(rc, "cu_conv_gemm")
@@ -142,7 +146,10 @@ def conv_wgrad(srcs: Sequence[Act], z: Tensor, dwk: Tensor, *, grid: Tuple[int, 
     d.splits = splits
     assert dwk.dtype == torch.float32 and z.dtype == t0.dtype
     flops = 2.0 * d.N * d.PH * d.PW * d.ntaps * (d.C0 + d.C1) * d.CO
-    with _Prof("igemm_wgrad", flops):
+    esz = t0.element_size()
+    nbytes = d.N * d.SH * d.SW * (d.C0 + d.C1) * esz + d.N * d.ZH * d.ZW * d.ZC * esz
+    note = f"N{d.N} {d.PH}x{d.PW} IS{d.IS} ZS{d.ZS} C{d.C0}+{d.C1}->{d.CO} t{d.ntaps}"
+    with _Prof("igemm_wgrad", flops, note, nbytes):
         rc = lib.cu_conv_wgrad(d, L.ptr(t0), L.ptr(sc0), L.ptr(sh0), L.ptr(t1), L.ptr(sc1), L.ptr(sh1), L.ptr(z),
                                L.ptr(dwk), L.stream_ptr())
     L.check(rc, "cu_conv_wgrad")

@@ -463,6 +463,9 @@ static int pick_chunk(int N, int HW, int rows, int* nchunks) {
     int want = cdiv(2048, N);
     if (want < 1) want = 1;
     int chunk = cdiv(HW, want);
+    // at least 16 pixels per thread: every workgroup ends in one atomic per channel and partial sum, and on the small
+    // feature maps (16x16 x 480 channels: 2048 workgroups of 8 pixels) those atomics were the whole run time
+    if (chunk < 16 * rows) chunk = 16 * rows;
     chunk = cdiv(chunk, rows) * rows;
     if (chunk < rows) chunk = rows;
     *nchunks = cdiv(HW, chunk);

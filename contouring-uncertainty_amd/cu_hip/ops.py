@@ -173,7 +173,7 @@ def instnorm_stats(z: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], e
     n, h, w_, c = z.shape
     stats = torch.empty((4, n, c), dtype=torch.float32, device=z.device)
     ws = torch.empty((n, c, 2), dtype=torch.float32, device=z.device)
-    with _Prof("instnorm_stats"):
+    with _Prof("instnorm_stats", 0.0, f"N{n} {h}x{w_} C{c}", z.numel() * z.element_size()):
         L.check(L.load().cu_instnorm_stats(L.dtype_code(z.dtype), n, h * w_, c, L.ptr(z), L.ptr(gamma), L.ptr(beta), eps,
                                            L.ptr(stats), L.ptr(ws), L.stream_ptr()), "cu_instnorm_stats")
     return stats
@@ -183,7 +183,7 @@ def instnorm_apply(act: Act) -> Tensor:
     """Materialise LeakyReLU(z*scale + shift) and attach it to the Act."""
     n, h, w_, c = act.z.shape
     out = torch.empty_like(act.z)
-    with _Prof("instnorm_apply"):
+    with _Prof("instnorm_apply", 0.0, f"N{n} {h}x{w_} C{c}", 2 * act.z.numel() * act.z.element_size()):
         L.check(L.load().cu_instnorm_apply(L.dtype_code(act.z.dtype), n, h * w_, c, L.ptr(act.z), L.ptr(act.stats),
                                            act.slope, L.ptr(out), L.stream_ptr()), "cu_instnorm_apply")
     act.a = out
@@ -194,7 +194,7 @@ def instnorm_lrelu_bwd(g: Tensor, act: Act, gamma: Optional[Tensor], dgamma, dbe
     """In place: g (dL/d activated) -> dL/dz."""
     n, h, w_, c = g.shape
     ws = torch.empty((n, c, 2), dtype=torch.float32, device=g.device)
-    with _Prof("instnorm_bwd"):
+    with _Prof("instnorm_bwd", 0.0, f"N{n} {h}x{w_} C{c}", 5 * g.numel() * g.element_size()):
         L.check(L.load().cu_instnorm_lrelu_bwd(L.dtype_code(g.dtype), n, h * w_, c, L.ptr(g), L.ptr(act.z),
                                                L.ptr(act.stats), L.ptr(gamma), act.slope, L.ptr(dgamma), L.ptr(dbeta),
                                                L.ptr(dbias), L.ptr(ws), L.stream_ptr()), "cu_instnorm_lrelu_bwd")

@@ -49,7 +49,8 @@ tot = sum(r[3] for r in rows)
 print(f"# {n} launches/step, {tot:.2f} ms profiled")
 print("# idx family note us TFLOP/s GB/s(algorithmic)")
 for k, fam, note, ms, flops, nbytes in rows:
-    if fam in ("igemm_conv", "igemm_wgrad"):
+    want = sys.argv[4].split(",") if len(sys.argv) > 4 else ("igemm_conv", "igemm_wgrad")
+    if fam in want:
         print(f"{k:4d} {fam:12s} {note:44s} {ms*1e3:8.1f} {flops/ms/1e9:7.1f} {nbytes/ms/1e6:7.0f}")
 fam_ms = {}
 for r in rows:

@@ -354,6 +354,147 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(T* __restrict__ g, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ small feature maps
+// HW <= 1024 (32x32 and below): one workgroup owns ALL pixels of one image for a slice of 8 pieces (32 pixel rows x 8
+// pieces), so the statistics / the backward sums never leave the workgroup: one launch instead of memset + partial +
+// finalize (forward) or memset + reduce + apply (backward), and no atomics on the per-(image, channel) sums.
+constexpr int SG = 8;             // pieces per workgroup
+constexpr int SR = NT / SG;       // pixel rows per workgroup (32)
+
+template <typename T>
+__global__ __launch_bounds__(NT) void stats_small_kernel(const T* __restrict__ z, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps,
+                                                         float* __restrict__ stats, int N, int HW, int C) {
+    constexpr int PIECE = Elem<T>::PIECE;
+    __shared__ float lds[(NT / 64) * SG * 2 * PIECE];
+    const int n = blockIdx.x;
+    const int pl = threadIdx.x & (SG - 1), prow = threadIdx.x / SG;
+    const int piece = blockIdx.y * SG + pl;
+    const bool active = piece * PIECE < C;
+    float acc[2][PIECE], k[PIECE];
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) acc[0][e] = acc[1][e] = k[e] = 0.f;
+    if (active) {
+        const T* base = z + (size_t)n * HW * C + piece * PIECE;
+        load_piece<T>(base, k);   // shift by the image's first pixel: avoids E[x^2]-E[x]^2 cancellation
+        for (int p = prow; p < HW; p += SR) {
+            float v[PIECE];
+            load_piece<T>(base + (size_t)p * C, v);
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) {
+                const float d = v[e] - k[e];
+                acc[0][e] += d;
+                acc[1][e] += d * d;
+            }
+        }
+    }
+    reduce_rows<2, PIECE>(acc, lds, pl, prow, SR, SG, true);
+    if (active && prow == 0) {
+        const size_t NC = (size_t)N * C;
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+            const int c = piece * PIECE + e;
+            const size_t i = (size_t)n * C + c;
+            const float m1 = acc[0][e] * inv, m2 = acc[1][e] * inv;
+            const float mean = k[e] + m1;
+            const float rstd = 1.f / sqrtf(fmaxf(m2 - m1 * m1, 0.f) + eps);
+            const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+            stats[i] = mean;
+            stats[NC + i] = rstd;
+            stats[2 * NC + i] = g * rstd;
+            stats[3 * NC + i] = b - mean * g * rstd;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void bwd_small_kernel(T* __restrict__ g, const T* __restrict__ z,
+                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       float slope, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                       float* __restrict__ dbias, int N, int HW, int C) {
+    constexpr int PIECE = Elem<T>::PIECE;
+    __shared__ float lds[(NT / 64) * SG * 2 * PIECE];
+    __shared__ float sums[SG][2 * PIECE];
+    const int n = blockIdx.x;
+    const int pl = threadIdx.x & (SG - 1), prow = threadIdx.x / SG;
+    const int piece = blockIdx.y * SG + pl;
+    const bool active = piece * PIECE < C;
+    const size_t NC = (size_t)N * C;
+    const size_t sidx = (size_t)n * C + (active ? piece : 0) * PIECE;
+    const size_t base = (size_t)n * HW * C + (active ? piece : 0) * PIECE;
+    float mean[PIECE], rstd[PIECE], sc[PIECE], sh[PIECE];
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) {
+        mean[e] = stats[sidx + e]; rstd[e] = stats[NC + sidx + e];
+        sc[e] = stats[2 * NC + sidx + e]; sh[e] = stats[3 * NC + sidx + e];
+    }
+    float acc[2][PIECE];
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) acc[0][e] = acc[1][e] = 0.f;
+    if (active) {
+        for (int p = prow; p < HW; p += SR) {
+            float zv[PIECE], gv[PIECE];
+            load_piece<T>(z + base + (size_t)p * C, zv);
+            load_piece<T>(g + base + (size_t)p * C, gv);
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) {
+                const float y = zv[e] * sc[e] + sh[e];
+                const float gl = y > 0.f ? gv[e] : gv[e] * slope;
+                acc[0][e] += gl;
+                acc[1][e] += gl * (zv[e] - mean[e]) * rstd[e];
+            }
+        }
+    }
+    reduce_rows<2, PIECE>(acc, lds, pl, prow, SR, SG, true);
+    if (prow == 0) {
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+            sums[pl][2 * e] = acc[0][e];
+            sums[pl][2 * e + 1] = acc[1][e];
+            if (active) {
+                if (dbeta) unsafeAtomicAdd(dbeta + piece * PIECE + e, acc[0][e]);
+                if (dgamma) unsafeAtomicAdd(dgamma + piece * PIECE + e, acc[1][e]);
+            }
+        }
+    }
+    __syncthreads();
+    float db[1][PIECE];
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) db[0][e] = 0.f;
+    if (active) {
+        const float inv = 1.f / (float)HW;
+        float a1[PIECE], a2[PIECE], gr[PIECE];
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+            a1[e] = sums[pl][2 * e] * inv; a2[e] = sums[pl][2 * e + 1] * inv;
+            gr[e] = (gamma ? gamma[piece * PIECE + e] : 1.f) * rstd[e];
+        }
+        for (int p = prow; p < HW; p += SR) {
+            float zv[PIECE], gv[PIECE];
+            load_piece<T>(z + base + (size_t)p * C, zv);
+            load_piece<T>(g + base + (size_t)p * C, gv);
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) {
+                const float y = zv[e] * sc[e] + sh[e];
+                const float gl = y > 0.f ? gv[e] : gv[e] * slope;
+                const float xh = (zv[e] - mean[e]) * rstd[e];
+                gv[e] = gr[e] * (gl - a1[e] - xh * a2[e]);
+                db[0][e] += gv[e];
+            }
+            store_piece<T>(g + base + (size_t)p * C, gv);
+        }
+    }
+    if (dbias) {
+        __syncthreads();
+        reduce_rows<1, PIECE>(db, lds, pl, prow, SR, SG, true);
+        if (active && prow == 0) {
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) unsafeAtomicAdd(dbias + piece * PIECE + e, db[0][e]);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void act_bwd_kernel(T* __restrict__ g, const T* __restrict__ z, float slope,
                                                      float* __restrict__ dbias, int HW, int C, int tpp, int rows,
@@ -489,6 +630,15 @@ extern "C" int cu_instnorm_stats(int dtype, int N, int HW, int C, const void* z,
                                  float eps, float* stats, float* ws, void* stream) {
     NORM_COMMON_CHECKS("cu_instnorm_stats");
     CU_CHECK_ARG(z && stats && ws, "cu_instnorm_stats: null pointer");
+    if (HW <= 1024) {       // small feature maps: one fused launch
+        dim3 sgrid(N, cdiv(C / PIECE, SG));
+        if (dtype == CU_BF16)
+            hipLaunchKernelGGL(stats_small_kernel<bf16_t>, sgrid, dim3(NT), 0, st, (const bf16_t*)z, gamma, beta, eps, stats, N, HW, C);
+        else
+            hipLaunchKernelGGL(stats_small_kernel<float>, sgrid, dim3(NT), 0, st, (const float*)z, gamma, beta, eps, stats, N, HW, C);
+        CU_LAUNCH_CHECK();
+        return 0;
+    }
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)N * C, st);
     CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_stats: memset failed: %s", hipGetErrorString(e));
     const size_t lds = sizeof(float) * (size_t)rm.rows * rm.tpp * 2 * PIECE;
@@ -529,6 +679,17 @@ extern "C" int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, c
                                      float* ws, void* stream) {
     NORM_COMMON_CHECKS("cu_instnorm_lrelu_bwd");
     CU_CHECK_ARG(g && z && stats && ws, "cu_instnorm_lrelu_bwd: null pointer");
+    if (HW <= 1024) {       // small feature maps: one fused launch
+        dim3 sgrid(N, cdiv(C / PIECE, SG));
+        if (dtype == CU_BF16)
+            hipLaunchKernelGGL(bwd_small_kernel<bf16_t>, sgrid, dim3(NT), 0, st, (bf16_t*)g, (const bf16_t*)z, stats, gamma, slope,
+                               dgamma, dbeta, dbias, N, HW, C);
+        else
+            hipLaunchKernelGGL(bwd_small_kernel<float>, sgrid, dim3(NT), 0, st, (float*)g, (const float*)z, stats, gamma, slope,
+                               dgamma, dbeta, dbias, N, HW, C);
+        CU_LAUNCH_CHECK();
+        return 0;
+    }
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)N * C, st);
     CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_lrelu_bwd: memset failed: %s", hipGetErrorString(e));
     const size_t lds = sizeof(float) * (size_t)rm.rows * rm.tpp * 2 * PIECE;

@@ -93,6 +93,34 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- LDS-DMA helpers (gfx950: buffer_load_dwordx4 ... lds) ----------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// buffer resource (V#) of a raw byte buffer: out-of-range offsets read zeros
+__device__ __forceinline__ i32x4 make_rsrc(const void* ptr, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+// One LDS-DMA wave instruction: lane l copies 16 bytes from rsrc + voff(l) to LDS byte address lds_base + 16 l.
+// Issued from inline asm on purpose: hipcc orders every later LDS read behind an LDS-DMA it knows about
+// (s_waitcnt vmcnt(0) in front of the first ds_read_tr of the k-loop), which would serialise the copy of tile i+1 with
+// the MFMAs of tile i.  The copies are retired by hand: dma_wait() before the barrier that hands the image over.
+__device__ __forceinline__ void dma16(const i32x4 rsrc, unsigned voff, unsigned lds_base) {
+    unsigned keep;
+    lds_base = __builtin_amdgcn_readfirstlane(lds_base);      // wave-uniform by construction: make it an SGPR
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p);
+}
+
 static inline int ilog2_exact(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

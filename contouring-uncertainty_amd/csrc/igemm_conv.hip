@@ -474,6 +474,202 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide layers (bf16, 3x3 stride-1 gathers, weights too large to stay in LDS): 8 waves, tile = 512 pixels x 128 columns.
+//   * the weight slice of a 32-channel chunk (9 x 128 x 64 B = 72 KiB) is streamed once per 512 pixels (the 4-wave
+//     kernel above re-streams it per 256: on these layers its run time is the L2 traffic of the weights);
+//   * staging is LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, so a wave needs < 256 VGPRs and two waves
+//     share a SIMD - one wave's MFMAs cover the other wave's LDS latency and DMA issue;
+//   * LDS images are lane-linear rows of 64 bytes ([pixel][4 pieces] and [tap][column][4 pieces]); slot s of row i
+//     holds piece s ^ ((i >> 2) & 3), which makes the ds_read_b128 fragment reads of 32 consecutive rows conflict-free
+//     (lane groups of ds_read_b128: MI355X_MICROARCH.md, LDS); zero padding comes from the buffer range check.
+constexpr int DW = 8;                 // waves
+constexpr int DMA_MAXX = 7;           // halo items per thread: halo_px * 4 <= 512 * 7
+template <int NTAPS>
+__global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs p, unsigned src0_bytes, unsigned src1_bytes,
+                                                                 unsigned w_bytes) {
+    constexpr int MA = 2, NB = 4, BN = 128, CK = 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int TW = 1 << p.twl, TH = 1 << p.thl;
+    const int n0 = blockIdx.y * BN;
+    const int CI = p.C0 + p.C1;
+    const int hpi = p.HH * p.HW;
+    const unsigned x_base = lds_addr(smem);
+    const unsigned w_base = x_base + (unsigned)p.halo_px * 64u;     // host rounds halo_px up to a multiple of 16 rows
+    const i32x4 rs0 = make_rsrc(p.src0, src0_bytes);
+    const i32x4 rs1 = make_rsrc(p.src1 ? p.src1 : p.src0, p.src1 ? src1_bytes : 0u);
+    const i32x4 rw = make_rsrc(p.w, w_bytes);
+    constexpr unsigned OOB = 0x7ffffff0u;
+
+    // ---- tile origin (one tile per workgroup)
+    const int tile = blockIdx.x;
+    const int tile_x = tile & ((1 << p.txl) - 1), tile_y = (tile >> p.txl) & ((1 << p.tyl) - 1);
+    const int img0 = (tile >> (p.txl + p.tyl)) << p.iml;
+    const int py0 = tile_y << p.thl, px0 = tile_x << p.twl;
+
+    // ---- halo staging items of this thread: pixel (tid >> 2) + 128 j, slot tid & 3
+    const int slot = tid & 3;
+    unsigned xoff[DMA_MAXX];          // byte offset of the pixel inside a source with 1 channel (x Cs later), or OOB
+    int xpiece[DMA_MAXX];
+#pragma unroll
+    for (int j = 0; j < DMA_MAXX; ++j) {
+        const int hp = (tid >> 2) + 128 * j;
+        const int im = hp / hpi, rem = hp - im * hpi;
+        const int hy = rem / p.HW, hx = rem - hy * p.HW;
+        const int n = img0 + im, sy = py0 + p.dymin + hy, sx = px0 + p.dxmin + hx;
+        const bool ok = hp < p.imgs * hpi && n < p.N && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;
+        xoff[j] = ok ? (unsigned)((n * p.SH + sy) * p.SW + sx) : 0xffffffffu;
+        xpiece[j] = slot ^ ((hp >> 2) & 3);
+    }
+    // ---- weight staging items: tap j, column tid >> 2, slot tid & 3
+    const int wcol = tid >> 2;
+    const bool wok = n0 + wcol < p.CO;
+    const int wpiece = slot ^ ((wcol >> 2) & 3);
+
+    // ---- fragment geometry: this lane's pixel in each of its MA blocks; weight rows of its NB column blocks
+    int hpA[MA], ptx[MA], pty[MA], pim[MA];
+#pragma unroll
+    for (int a = 0; a < MA; ++a) {
+        const int m = wave * 32 * MA + a * 32 + r;
+        ptx[a] = m & (TW - 1); pty[a] = (m >> p.twl) & (TH - 1); pim[a] = m >> (p.twl + p.thl);
+        hpA[a] = pim[a] < p.imgs ? pim[a] * hpi + pty[a] * p.HW + ptx[a] : 0;
+    }
+    const int wsw = (r >> 2) & 3;     // swizzle of weight row (b * 32 + r): ((b * 32 + r) >> 2) & 3
+
+    f32x16 acc[MA][NB];
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    const bf16_t* X16 = reinterpret_cast<const bf16_t*>(smem);
+    const bf16_t* W16 = reinterpret_cast<const bf16_t*>(smem + (size_t)p.halo_px * 64);
+
+    for (int c0 = 0; c0 < CI; c0 += CK) {
+        __syncthreads();              // the previous chunk's fragment reads are done
+        {
+            const bool s1 = c0 >= p.C0;
+            const unsigned Cs = (unsigned)(s1 ? p.C1 : p.C0);
+            const unsigned cc = (unsigned)(s1 ? c0 - p.C0 : c0);
+#pragma unroll
+            for (int j = 0; j < DMA_MAXX; ++j) {
+                if (j * 128 < p.halo_px) {       // uniform
+                    const unsigned off = xoff[j] == 0xffffffffu ? OOB : (xoff[j] * Cs + cc + (unsigned)xpiece[j] * 8u) * 2u;
+                    const unsigned dst = x_base + (unsigned)(j * 8192 + wave * 1024);
+                    if (s1) dma16(rs1, off, dst);
+                    else dma16(rs0, off, dst);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NTAPS; ++j) {
+                const unsigned off = wok ? (unsigned)(((p.tap_w[j] * p.CO + n0 + wcol) * CI + c0 + wpiece * 8)) * 2u : OOB;
+                dma16(rw, off, w_base + (unsigned)(j * 8192 + wave * 1024));
+            }
+        }
+        dma_wait();
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            int xrow[MA], xsw[MA];
+#pragma unroll
+            for (int a = 0; a < MA; ++a) {
+                xrow[a] = hpA[a] + p.tap_off[t];
+                xsw[a] = (xrow[a] >> 2) & 3;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[MA], bfr[NB];
+#pragma unroll
+                for (int a = 0; a < MA; ++a)
+                    af[a] = *reinterpret_cast<const bf16x8*>(X16 + ((size_t)xrow[a] * 4 + ((2 * kk + h) ^ xsw[a])) * 8);
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    bfr[b] = *reinterpret_cast<const bf16x8*>(
+                        W16 + ((size_t)(t * 128 + b * 32 + r) * 4 + ((2 * kk + h) ^ wsw)) * 8);
+#pragma unroll
+                for (int a = 0; a < MA; ++a)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue (same register -> channel mapping as igemm_conv_kernel)
+#pragma unroll
+    for (int a = 0; a < MA; ++a) {
+        const int n = img0 + pim[a];
+        const int py = py0 + pty[a], px = px0 + ptx[a];
+        const bool pvalid = !(pim[a] >= p.imgs || n >= p.N || py >= p.PH || px >= p.PW);
+        const int oy = py * p.OS + p.OY0, ox = px * p.OS + p.OX0;
+        const size_t opix = pvalid ? ((size_t)n * p.OH + oy) * p.OW + ox : 0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int colb = n0 + b * 32;
+            if (colb >= p.CO) continue;                       // uniform
+            const bool d1 = colb >= p.D0;
+            const int accum = d1 ? p.accum1 : p.accum0;
+            const int DC = d1 ? p.DC1 : p.DC0;
+            bf16_t* dstp = reinterpret_cast<bf16_t*>(d1 ? p.dst1 : p.dst0);
+            if (!accum) {
+                unsigned q[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e];
+                    if (p.bias) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + colb + 8 * g + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                    }
+                    q[g][0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    q[g][1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                }
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2) {
+                    auto r02 = __builtin_amdgcn_permlane32_swap(q[0][w2], q[2][w2], false, false);
+                    q[0][w2] = r02[0]; q[2][w2] = r02[1];
+                    auto r13 = __builtin_amdgcn_permlane32_swap(q[1][w2], q[3][w2], false, false);
+                    q[1][w2] = r13[0]; q[3][w2] = r13[1];
+                }
+                if (pvalid) {
+                    const int dcol = (d1 ? colb - p.D0 : colb) + 16 * h;
+                    bf16_t* o = dstp + opix * DC + dcol;
+                    *reinterpret_cast<u32x4*>(o) = u32x4{q[0][0], q[0][1], q[2][0], q[2][1]};
+                    *reinterpret_cast<u32x4*>(o + 8) = u32x4{q[1][0], q[1][1], q[3][0], q[3][1]};
+                }
+                continue;
+            }
+            if (!pvalid) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = colb + 8 * g + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e];
+                if (p.bias) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                }
+                bf16_t* o = dstp + opix * DC + (d1 ? col - p.D0 : col);
+                const u32x2 old = *reinterpret_cast<const u32x2*>(o);
+                v[0] += __uint_as_float(old[0] << 16); v[1] += __uint_as_float(old[0] & 0xffff0000u);
+                v[2] += __uint_as_float(old[1] << 16); v[3] += __uint_as_float(old[1] & 0xffff0000u);
+                u32x2 pk;
+                pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                *reinterpret_cast<u32x2*>(o) = pk;
+            }
+        }
+    }
+}
+
 template <typename T, int MA, int NB, int NX, int NT, bool WRES, bool PLAIN>
 int launch(const ConvKArgs& a, size_t lds, int grid_x, int grid_y, hipStream_t st) {
     auto k = igemm_conv_kernel<T, MA, NB, NX, NT, WRES, PLAIN>;
@@ -521,6 +717,53 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
     a.out_nchw = d->out_nchw_f32;
     const int CI = d->C0 + d->C1;
     { const char* e = getenv("CU_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
+
+    // ---- wide bf16 3x3 stride-1 layers whose weight slice cannot stay in LDS: 8-wave LDS-DMA kernel
+    {
+        const bool plain0 = !scale0 && d->slope0 == 1.0f && (d->C1 == 0 || (!scale1 && d->slope1 == 1.0f));
+        const size_t b0 = (size_t)d->N * d->SH * d->SW * d->C0 * 2, b1 = (size_t)d->N * d->SH * d->SW * d->C1 * 2;
+        const size_t bw = (size_t)9 * d->CO * CI * 2, lim = 0x7fff0000ull;
+        const long px_all = (long)d->N * d->PH * d->PW;
+        if (bf && plain0 && d->IS == 1 && d->ntaps == 9 && !d->out_nchw_f32 && d->CO >= 128 && CI >= 128 && d->C0 % 32 == 0 &&
+            d->D0 % 32 == 0 && d->CO % 16 == 0 && b0 < lim && b1 < lim && bw < lim && (px_all / 512) * cdiv(d->CO, 128) >= 128 &&
+            !getenv("CU_CONV_NODMA")) {
+            int tw = d->PW < 32 ? d->PW : 32;
+            int th = 512 / tw;
+            if (th > d->PH) th = d->PH;
+            int imgs = 512 / (tw * th);
+            a.twl = ilog2_exact(tw); a.thl = ilog2_exact(th); a.iml = ilog2_exact(imgs);
+            int dymin = 1 << 20, dxmin = 1 << 20, dymax = -(1 << 20), dxmax = -(1 << 20);
+            for (int t = 0; t < 9; ++t) {
+                dymin = d->tap_dy[t] < dymin ? d->tap_dy[t] : dymin; dymax = d->tap_dy[t] > dymax ? d->tap_dy[t] : dymax;
+                dxmin = d->tap_dx[t] < dxmin ? d->tap_dx[t] : dxmin; dxmax = d->tap_dx[t] > dxmax ? d->tap_dx[t] : dxmax;
+            }
+            a.dymin = dymin; a.dxmin = dxmin;
+            a.HH = (th - 1) + (dymax - dymin) + 1; a.HW = (tw - 1) + (dxmax - dxmin) + 1;
+            const int halo = imgs * a.HH * a.HW;
+            const int halo_pad = cdiv(halo, 128) * 128;          // whole 8-KiB staging rounds (128 rows of 64 B)
+            const size_t lds = (size_t)halo_pad * 64 + (size_t)9 * 128 * 64;
+            if (a.twl >= 0 && a.thl >= 0 && a.iml >= 0 && d->PW % tw == 0 && d->PH % th == 0 && halo_pad <= 128 * DMA_MAXX &&
+                lds <= 160 * 1024 && ilog2_exact(d->PW / tw) >= 0 && ilog2_exact(d->PH / th) >= 0) {
+                a.imgs = imgs; a.halo_px = halo_pad;
+                a.tiles_x = d->PW / tw; a.tiles_y = d->PH / th;
+                a.txl = ilog2_exact(a.tiles_x); a.tyl = ilog2_exact(a.tiles_y);
+                a.ntiles = a.tiles_x * a.tiles_y * cdiv(d->N, imgs);
+                for (int t = 0; t < 9; ++t) {
+                    a.tap_off[t] = (d->tap_dy[t] - dymin) * a.HW + (d->tap_dx[t] - dxmin);
+                    a.tap_w[t] = d->tap_w[t];
+                    CU_CHECK_ARG(d->tap_w[t] >= 0, "cu_conv_gemm: negative weight tap index");
+                }
+                auto k = igemm_conv_dma_kernel<9>;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                CU_CHECK_ARG(e == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                hipLaunchKernelGGL(k, dim3(a.ntiles, cdiv(d->CO, 128)), dim3(64 * DW), lds,
+                                   reinterpret_cast<hipStream_t>(stream), a, (unsigned)b0, (unsigned)b1, (unsigned)bw);
+                CU_LAUNCH_CHECK();
+                return 0;
+            }
+        }
+    }
 
     // ---- column tile: the widest of {128, 96, 64, 32} that divides the work without waste
     int nb;

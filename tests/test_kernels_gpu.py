@@ -334,3 +334,57 @@ def test_linear(golden_dir):
     gw, gb = torch.zeros_like(w), torch.zeros_like(b)
     gx = ops.linear_bwd(x, w, go, gw, gb)
     assert rel_err(gx, xr.grad) < 1e-5 and rel_err(gw, wr.grad) < 1e-5 and rel_err(gb, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("case", [
+    # n, cin0, cin1, cout, size, (d0 = split of the destination columns or None), accum of the second destination
+    (64, 256, 0, 256, 32, None, 0),       # encoder 32x32
+    (40, 128, 128, 128, 64, None, 0),     # decoder concat at 64x64, ragged image count
+    (64, 480, 0, 480, 16, None, 0),       # 480 columns: last 128-column tile is partial; two images per tile
+    (64, 480, 0, 960, 16, 480, 1),        # input gradient of a decoder conv: two destinations, the second accumulated
+])
+def test_conv_wide_dma_kernel(case):
+    """bf16 3x3 stride-1 layers with >= 128 channels take the 8-wave LDS-DMA kernel (igemm_conv_dma_kernel): compare
+    with F.conv2d and with the 4-wave register-staged kernel (CU_CONV_NODMA=1), which sums in the same order."""
+    import os
+    ops = _ops()
+    from cu_hip.engine import TAPS3
+    n, c0, c1, co, size, d0, acc1 = case
+    dtype = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(3)
+    srcs, refs = [], []
+    for c in (c0, c1):
+        if c:
+            x = torch.randn(n, c, size, size, device=DEV, generator=g)
+            a, r = make_act(x, dtype, False, 1.0, g)
+            srcs.append(a)
+            refs.append(r)
+    w = torch.randn(co, c0 + c1, 3, 3, device=DEV, generator=g) / math.sqrt(9 * (c0 + c1))
+    b = torch.randn(co, device=DEV, generator=g) * 0.1
+    wf, _ = ops.weight_prep(w, "conv", dtype)
+    ref = F.conv2d(torch.cat(refs, 1), rq(w, dtype), b, padding=1)
+
+    def run():
+        if d0 is None:
+            z = torch.empty(n, size, size, co, device=DEV, dtype=dtype)
+            ops.conv_gemm(srcs, wf, b, grid=(size, size), in_stride=1, taps=TAPS3, dsts=[z], dst_cols=[co])
+            return [z]
+        za = torch.empty(n, size, size, d0, device=DEV, dtype=dtype)
+        zb = torch.ones(n, size, size, co - d0, device=DEV, dtype=dtype)
+        ops.conv_gemm(srcs, wf, b, grid=(size, size), in_stride=1, taps=TAPS3, dsts=[za, zb], dst_cols=[d0, co - d0],
+                      accum=(0, acc1))
+        return [za, zb]
+
+    out = run()
+    os.environ["CU_CONV_NODMA"] = "1"
+    try:
+        old = run()
+    finally:
+        del os.environ["CU_CONV_NODMA"]
+    for a, o in zip(out, old):
+        assert torch.equal(a, o)
+    got = torch.cat([nchw(t) for t in out], 1)
+    if d0 is not None and acc1:
+        ref = ref.clone()
+        ref[:, d0:] += 1.0
+    assert rel_err(got, ref) < tol(dtype)

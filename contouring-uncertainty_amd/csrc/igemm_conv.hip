@@ -775,6 +775,16 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
     if (!bf && nb > 2) nb = (d->CO % 64 == 0) ? 2 : 1;   // keep the f32 weight tile within LDS
     { const char* e = getenv("CU_CONV_NBMAX"); const int cap = e ? atoi(e) : 4;
       while (nb > cap) nb = (nb == 4) ? 2 : (nb == 3 ? 1 : 1); }
+    // small feature maps: few pixel tiles, and every workgroup walks all channel chunks one L2 round trip at a time --
+    // narrower column tiles put more CUs on the same work (4x4 x 480 channels: 20 workgroups with 96 columns each)
+    if (!getenv("CU_CONV_NO_NARROW")) {
+        const long px_tiles = ((long)d->N * d->PH * d->PW + 127) / 128;
+        while (nb > 1 && px_tiles * cdiv(d->CO, 32 * nb) < 192) {
+            const int nn = (nb == 4) ? 2 : 1;
+            if (d->D0 != d->CO && d->D0 % (32 * nn) != 0) break;
+            nb = nn;
+        }
+    }
     const int coltiles = cdiv(d->CO, 32 * nb);
     a.WP = 32 * nb + 2;
 

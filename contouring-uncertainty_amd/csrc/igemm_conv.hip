@@ -35,6 +35,7 @@ struct ConvKArgs {
     int tiles_x, tiles_y;
     float slope0, slope1;
     int accum0, accum1, out_nchw;
+    int par_co;                 // > 0: column group g = col / par_co goes to destination parity (g >> 1, g & 1)
     int imgs;                   // images per tile (TW*TH*imgs <= 128*MA; rows beyond are idle)
     int txl, tyl, ntiles;       // log2 of tiles per row / column, total pixel tiles
     int tap_lds;                // byte offset of the tap table inside the dynamic LDS
@@ -380,11 +381,17 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
             const int py = py0 + pty[a], px = px0 + ptx[a];
             const bool pvalid = !(pim[a] >= p.imgs || n >= p.N || py >= p.PH || px >= p.PW || (p.dbg & 1));
             const int oy = py * p.OS + p.OY0, ox = px * p.OS + p.OX0;
-            const size_t opix = pvalid ? ((size_t)n * p.OH + oy) * p.OW + ox : 0;
+            const size_t opix0 = pvalid ? ((size_t)n * p.OH + oy) * p.OW + ox : 0;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const int colb = n0 + b * 32;
+                int colb = n0 + b * 32;
                 if (colb >= p.CO) continue;                       // uniform
+                size_t opix = opix0;
+                if (p.par_co > 0) {          // transposed conv: column group -> output parity
+                    const int par = colb / p.par_co;
+                    colb -= par * p.par_co;
+                    if (pvalid) opix += (size_t)(par >> 1) * p.OW + (par & 1);
+                }
                 const bool d1 = colb >= p.D0;
                 const int accum = d1 ? p.accum1 : p.accum0;
                 if constexpr (sizeof(T) == 2) {
@@ -715,6 +722,11 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
     a.DC0 = d->DC0; a.DC1 = d->DC1; a.ntaps = d->ntaps;
     a.slope0 = d->slope0; a.slope1 = d->slope1; a.accum0 = d->accum0; a.accum1 = d->accum1;
     a.out_nchw = d->out_nchw_f32;
+    a.par_co = d->par_co;
+    CU_CHECK_ARG(d->par_co == 0 || (d->par_co > 0 && d->par_co % 32 == 0 && d->CO == 4 * d->par_co && d->D0 == d->CO &&
+                                    d->OS == 2 && d->OY0 == 0 && d->OX0 == 0 && !d->out_nchw_f32 && !d->accum0 &&
+                                    (d->PH - 1) * 2 + 1 < d->OH && (d->PW - 1) * 2 + 1 < d->OW),
+                 "cu_conv_gemm: bad parity-column mode (par_co=%d)", d->par_co);
     const int CI = d->C0 + d->C1;
     { const char* e = getenv("CU_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
 

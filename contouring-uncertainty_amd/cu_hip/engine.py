@@ -148,10 +148,9 @@ class UNetEngine:
         n, h, w_, _ = src.z.shape
         co = w.shape[1]
         u = torch.empty((n, 2 * h, 2 * w_, co), dtype=self.dtype, device=w.device)
-        for dy in range(2):
-            for dx in range(2):
-                ops.conv_gemm([src], wf, None, grid=(h, w_), in_stride=1, taps=[(0, 0, dy * 2 + dx)], dsts=[u],
-                              dst_cols=[co], out_stride=2, out_off=(dy, dx))
+        # all four output parities in one pass over the source: W[4][CO][CI] viewed as 4*CO GEMM columns
+        ops.conv_gemm([src], wf.view(1, 4 * co, wf.shape[2]), None, grid=(h, w_), in_stride=1, taps=[(0, 0, 0)], dsts=[u],
+                      dst_cols=[co], out_stride=2, n_cols=4 * co, parity_cols=co)
         out = Act(u, None, 1.0)
         ctx.ups.append(_UpRec(prefix, src, out))
         return out

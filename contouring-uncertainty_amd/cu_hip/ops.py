@@ -80,7 +80,7 @@ def _taps(desc, dys, dxs, ws, zys=None, zxs=None):
 def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: Tuple[int, int], in_stride: int,
               taps: Sequence[Tuple[int, int, int]], dsts: Sequence[Tensor], dst_cols: Sequence[int],
               out_stride: int = 1, out_off: Tuple[int, int] = (0, 0), accum: Sequence[int] = (0, 0),
-              out_nchw: bool = False, n_cols: Optional[int] = None):
+              out_nchw: bool = False, n_cols: Optional[int] = None, parity_cols: int = 0):
     """D[p, n] = bias[n] + sum_t sum_c act(S[p*IS + off_t, c]) W[tap_w[t]][n][c]  (cu_conv_gemm)."""
     lib = L.load()
     s0 = srcs[0]
@@ -104,12 +104,13 @@ def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: T
     d.OS = out_stride
     d.OY0, d.OX0 = out_off
     d.CO = n_cols if n_cols is not None else sum(dst_cols)
-    d.D0 = dst_cols[0]
+    d.D0 = d.CO if parity_cols else dst_cols[0]
     _taps(d, [t[0] for t in taps], [t[1] for t in taps], [t[2] for t in taps])
     d.slope0 = sl0
     d.slope1 = sl1
     d.accum0, d.accum1 = int(accum[0]), int(accum[1]) if len(accum) > 1 else 0
     d.out_nchw_f32 = int(out_nchw)
+    d.par_co = parity_cols
     assert w.dtype == t0.dtype and w.shape[-1] == d.C0 + d.C1 and w.shape[-2] == d.CO, (w.shape, d.CO, d.C0, d.C1)
     flops = 2.0 * d.N * d.PH * d.PW * d.ntaps * (d.C0 + d.C1) * (d.DC0 if out_nchw else d.CO)
     esz = t0.element_size()

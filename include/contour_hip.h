@@ -56,6 +56,9 @@ typedef struct {
     float slope0, slope1;   /* LeakyReLU slope applied to source 0/1 after the affine; 1.0f = none */
     int accum0, accum1;     /* 1: dst += result */
     int out_nchw_f32;       /* 1: dst0 is NCHW f32 with DC0 planes (the logits); columns >= DC0 are dropped */
+    int par_co;             /* > 0: the CO columns are 4 groups of par_co, group g -> channels [0,par_co) of destination
+                               pixel p*OS + (g >> 1, g & 1): all four output parities of a 2x2 stride-2 transposed conv
+                               (W viewed as [1][4*par_co][C]) in ONE pass over the source.  Needs D0 == CO, OY0 = OX0 = 0 */
 } cu_conv_desc;
 
 int cu_conv_gemm(const cu_conv_desc* d,

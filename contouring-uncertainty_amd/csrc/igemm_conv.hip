@@ -492,10 +492,11 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
 //     (lane groups of ds_read_b128: MI355X_MICROARCH.md, LDS); zero padding comes from the buffer range check.
 constexpr int DW = 8;                 // waves
 constexpr int DMA_MAXX = 7;           // halo items per thread: halo_px * 4 <= 512 * 7
-template <int NTAPS>
+template <int NTAPS, int NB>
 __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs p, unsigned src0_bytes, unsigned src1_bytes,
                                                                  unsigned w_bytes) {
-    constexpr int MA = 2, NB = 4, BN = 128, CK = 32;
+    constexpr int MA = 2, BN = 32 * NB, CK = 32;
+    constexpr int WROWS = NTAPS * BN, WROUNDS = (WROWS + 127) / 128;     // 128 weight rows of 64 B per staging round
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -530,10 +531,11 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs
         xoff[j] = ok ? (unsigned)((n * p.SH + sy) * p.SW + sx) : 0xffffffffu;
         xpiece[j] = slot ^ ((hp >> 2) & 3);
     }
-    // ---- weight staging items: tap j, column tid >> 2, slot tid & 3
-    const int wcol = tid >> 2;
+    // ---- weight staging items: row (tid >> 2) + 128 j of the [tap][column] image, slot tid & 3
+    const int wrow0 = tid >> 2;
+    const int wcol = wrow0 & (BN - 1);
     const bool wok = n0 + wcol < p.CO;
-    const int wpiece = slot ^ ((wcol >> 2) & 3);
+    const int wpiece = slot ^ ((wrow0 >> 2) & 3);          // 128 and BN are multiples of 16: the swizzle is round-invariant
 
     // ---- fragment geometry: this lane's pixel in each of its MA blocks; weight rows of its NB column blocks
     int hpA[MA], ptx[MA], pty[MA], pim[MA];
@@ -572,8 +574,17 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs
                 }
             }
 #pragma unroll
-            for (int j = 0; j < NTAPS; ++j) {
-                const unsigned off = wok ? (unsigned)(((p.tap_w[j] * p.CO + n0 + wcol) * CI + c0 + wpiece * 8)) * 2u : OOB;
+            for (int j = 0; j < WROUNDS; ++j) {
+                // tap of row wrow0 + 128 j: static indices only (a runtime index would spill the argument block)
+                int tw;
+                if constexpr (NB == 4) {
+                    tw = p.tap_w[j < NTAPS ? j : 0];
+                } else {
+                    const int T0 = 2 * j < NTAPS ? 2 * j : 0, T1 = 2 * j + 1 < NTAPS ? 2 * j + 1 : 0;   // constants after unrolling
+                    tw = (tid >> 8) ? p.tap_w[T1] : p.tap_w[T0];
+                }
+                const bool ok = wok && wrow0 + 128 * j < WROWS;
+                const unsigned off = ok ? (unsigned)(((tw * p.CO + n0 + wcol) * CI + c0 + wpiece * 8)) * 2u : OOB;
                 dma16(rw, off, w_base + (unsigned)(j * 8192 + wave * 1024));
             }
         }
@@ -596,7 +607,7 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
                     bfr[b] = *reinterpret_cast<const bf16x8*>(
-                        W16 + ((size_t)(t * 128 + b * 32 + r) * 4 + ((2 * kk + h) ^ wsw)) * 8);
+                        W16 + ((size_t)(t * BN + b * 32 + r) * 4 + ((2 * kk + h) ^ wsw)) * 8);
 #pragma unroll
                 for (int a = 0; a < MA; ++a)
 #pragma unroll
@@ -736,9 +747,10 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
         const size_t b0 = (size_t)d->N * d->SH * d->SW * d->C0 * 2, b1 = (size_t)d->N * d->SH * d->SW * d->C1 * 2;
         const size_t bw = (size_t)9 * d->CO * CI * 2, lim = 0x7fff0000ull;
         const long px_all = (long)d->N * d->PH * d->PW;
+        const int dnb = d->CO % 128 == 0 || d->CO > 256 ? 4 : 2;       // 128-column tiles unless that wastes half a tile
         if (bf && plain0 && d->IS == 1 && d->ntaps == 9 && !d->out_nchw_f32 && d->CO >= 128 && CI >= 128 && d->C0 % 32 == 0 &&
-            d->D0 % 32 == 0 && d->CO % 16 == 0 && b0 < lim && b1 < lim && bw < lim && (px_all / 512) * cdiv(d->CO, 128) >= 128 &&
-            !getenv("CU_CONV_NODMA")) {
+            d->D0 % 32 == 0 && d->CO % 16 == 0 && !d->par_co && b0 < lim && b1 < lim && bw < lim &&
+            (px_all / 512) * cdiv(d->CO, 32 * dnb) >= 128 && !getenv("CU_CONV_NODMA")) {
             int tw = d->PW < 32 ? d->PW : 32;
             int th = 512 / tw;
             if (th > d->PH) th = d->PH;
@@ -753,7 +765,7 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
             a.HH = (th - 1) + (dymax - dymin) + 1; a.HW = (tw - 1) + (dxmax - dxmin) + 1;
             const int halo = imgs * a.HH * a.HW;
             const int halo_pad = cdiv(halo, 128) * 128;          // whole 8-KiB staging rounds (128 rows of 64 B)
-            const size_t lds = (size_t)halo_pad * 64 + (size_t)9 * 128 * 64;
+            const size_t lds = (size_t)halo_pad * 64 + (size_t)cdiv(9 * 32 * dnb, 128) * 8192;
             if (a.twl >= 0 && a.thl >= 0 && a.iml >= 0 && d->PW % tw == 0 && d->PH % th == 0 && halo_pad <= 128 * DMA_MAXX &&
                 lds <= 160 * 1024 && ilog2_exact(d->PW / tw) >= 0 && ilog2_exact(d->PH / th) >= 0) {
                 a.imgs = imgs; a.halo_px = halo_pad;
@@ -765,11 +777,11 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
                     a.tap_w[t] = d->tap_w[t];
                     CU_CHECK_ARG(d->tap_w[t] >= 0, "cu_conv_gemm: negative weight tap index");
                 }
-                auto k = igemm_conv_dma_kernel<9>;
+                auto k = dnb == 4 ? igemm_conv_dma_kernel<9, 4> : igemm_conv_dma_kernel<9, 2>;
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 CU_CHECK_ARG(e == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-                hipLaunchKernelGGL(k, dim3(a.ntiles, cdiv(d->CO, 128)), dim3(64 * DW), lds,
+                hipLaunchKernelGGL(k, dim3(a.ntiles, cdiv(d->CO, 32 * dnb)), dim3(64 * DW), lds,
                                    reinterpret_cast<hipStream_t>(stream), a, (unsigned)b0, (unsigned)b1, (unsigned)bw);
                 CU_LAUNCH_CHECK();
                 return 0;

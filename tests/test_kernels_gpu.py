@@ -342,6 +342,8 @@ def test_linear(golden_dir):
     (40, 128, 128, 128, 64, None, 0),     # decoder concat at 64x64, ragged image count
     (64, 480, 0, 480, 16, None, 0),       # 480 columns: last 128-column tile is partial; two images per tile
     (64, 480, 0, 960, 16, 480, 1),        # input gradient of a decoder conv: two destinations, the second accumulated
+    (32, 64, 0, 128, 128, 64, 0),         # 64 input channels (two chunks), two destinations of 64 columns
+    (32, 128, 0, 192, 64, None, 0),       # 192 columns: the 64-column variant (two taps per staging round)
 ])
 def test_conv_wide_dma_kernel(case):
     """bf16 3x3 stride-1 layers with >= 128 channels take the 8-wave LDS-DMA kernel (igemm_conv_dma_kernel): compare

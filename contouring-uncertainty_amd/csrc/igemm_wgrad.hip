@@ -319,15 +319,18 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
 //     swizzle, and a wave's block (cblk / nblk) simply selects its plane.
 constexpr int DMA_IMG_BYTES = 78 * 1024;      // per image; two of them per workgroup
 
-template <int NBLK, int CBLK, int NTAPS>
-__global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const WgKArgs p) {
+// NW = 8 waves: two waves per SIMD own the SAME 32x32 block and split the k-steps; while one is blocked issuing its
+// DMA instructions (the queue drains at L2 speed, ~4 us per tile) the other keeps the MFMA pipe busy.  The k-split
+// partial sums are combined through LDS before the atomics, so the atomic traffic does not grow with the wave count.
+template <int NBLK, int CBLK, int NTAPS, int NW>
+__global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs p) {
     constexpr int TN = 32 * NBLK, TC = 32 * CBLK;
-    constexpr int NWB = NBLK * CBLK, KSPLIT = 4 / NWB;
+    constexpr int NWB = NBLK * CBLK, KSPLIT = NW / NWB;
+    constexpr int NTHR = 64 * NW, BLK_B = NTHR * 16;   // threads; bytes of one staging round
     constexpr int ROW_B = 64;                          // one pixel of one 32-channel plane
-    // Two STATIC images: the compiler orders a ds_read after an in-flight LDS-DMA only when both may touch the same
-    // LDS object, so reads of one image do not wait (vmcnt) for the DMA that fills the other one.
-    __shared__ __attribute__((aligned(16))) unsigned char imgA[DMA_IMG_BYTES];
-    __shared__ __attribute__((aligned(16))) unsigned char imgB[DMA_IMG_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char img2[2 * DMA_IMG_BYTES];
+    unsigned char* imgA = img2;
+    unsigned char* imgB = img2 + DMA_IMG_BYTES;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int blk = wave % NWB, kpart = wave / NWB;
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const WgKArgs p) {
     const int c_base = ct * TC, n_base = nt * TN;
     const int s_hpi = p.SHH * p.SHW, z_hpi = p.ZHH * p.ZHW;
     const bool wave_active = (n_base + nblk * 32 < p.CO) && (c_base + cblk * 32 < CI);
-    const int s_img_bytes = p.s_iters * 4096;
+    const int s_img_bytes = p.s_iters * BLK_B;
 
     const i32x4 rs0 = make_rsrc(p.src0, p.src0_bytes);
     const i32x4 rs1 = make_rsrc(p.src1 ? p.src1 : p.src0, p.src1 ? p.src1_bytes : 0u);
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const WgKArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    const int slot = tid & 3;       // 256 % 4 == 0: a thread always stages the same 16-byte piece of a pixel
+    const int slot = tid & 3;       // NTHR % 4 == 0: a thread always stages the same 16-byte piece of a pixel
 
     // staging of one tile = s_iters + z_iters wave-level DMA instructions per wave, issued back to back right after the
     // barrier (measured: spreading them over the k-steps stalls the MFMA pipeline far more than it hides, 157 -> 191 us)
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const WgKArgs p) {
     };
     auto issue_item = [&](int j, unsigned char* img) {
         if (j < p.s_iters) {
-            const int i = (tid + j * 256) >> 2;                          // plane-major pixel index
+            const int i = (tid + j * NTHR) >> 2;                         // plane-major pixel index
             const int pl = (CBLK == 2 && i >= p.s_halo) ? 1 : 0;
             const int hp = i - pl * p.s_halo;
             const int im = __umulhi((unsigned)hp, p.mg_shpi), rem = hp - im * s_hpi;
@@ -379,12 +382,12 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const WgKArgs p) {
             const bool s1 = c >= p.C0;
             const unsigned pix = (unsigned)((n * p.SH + sy) * p.SW + sx);
             const unsigned off = ok ? (pix * (unsigned)(s1 ? p.C1 : p.C0) + (unsigned)(s1 ? c - p.C0 : c)) * 2u : OOB;
-            const unsigned dst = lds_addr(img) + wave * 1024 + j * 4096;
+            const unsigned dst = lds_addr(img) + wave * 1024 + j * BLK_B;
             if (s1) dma16(rs1, off, dst);
             else dma16(rs0, off, dst);
         } else {
             const int jz = j - p.s_iters;
-            const int i = (tid + jz * 256) >> 2;
+            const int i = (tid + jz * NTHR) >> 2;
             const int pl = (NBLK == 2 && i >= p.z_halo) ? 1 : 0;
             const int hp = i - pl * p.z_halo;
             const int im = __umulhi((unsigned)hp, p.mg_zhpi), rem = hp - im * z_hpi;
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const WgKArgs p) {
             const bool ok = hp < p.z_halo && col < p.CO && n < p.N && zy >= 0 && zy < p.ZH && zx >= 0 && zx < p.ZW;
             const unsigned pix = (unsigned)((n * p.ZH + zy) * p.ZW + zx);
             const unsigned off = ok ? (pix * (unsigned)p.ZC + (unsigned)col) * 2u : OOB;
-            dma16(rz, off, lds_addr(img) + s_img_bytes + wave * 1024 + jz * 4096);
+            dma16(rz, off, lds_addr(img) + s_img_bytes + wave * 1024 + jz * BLK_B);
         }
     };
     const int n_items = p.s_iters + p.z_iters;
@@ -416,9 +419,13 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const WgKArgs p) {
         const long long c1 = (p.dbg & 16) ? wall_clock64() : 0;
         __syncthreads();      // ... everybody's has, and the other image is no longer being read
         const long long c2 = (p.dbg & 16) ? wall_clock64() : 0;
-        if (tile + p.splits < p.ntiles && !(p.dbg & 8)) {
+        const bool more = tile + p.splits < p.ntiles && !(p.dbg & 8);
+        int item = 0;
+        if (more) {
             tile_geo(tile + p.splits);
-            for (int j = 0; j < n_items; ++j) issue_item(j, other);
+            // all DMA instructions now: spreading them over the k-steps was slower with one wave per SIMD (it stalls
+            // the software pipeline, 157 -> 191 us) and with two (157 -> 181 us)
+            for (; item < n_items; ++item) issue_item(item, other);
         }
         const long long c3 = (p.dbg & 16) ? wall_clock64() : 0;
         t_wait += c1 - c0; t_bar += c2 - c1; t_issue += c3 - c2; t_loop -= c3;
@@ -453,26 +460,34 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const WgKArgs p) {
             for (int t = 0; t < NTAPS; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[NA == 1 ? 0 : t], B[t], acc[t], 0, 0, 0);
         };
-        bf16x8 A0[NA], B0[NTAPS], A1[NA], B1[NTAPS];
-        auto stage = [&](const bf16x8 (&Ac)[NA], const bf16x8 (&Bc)[NTAPS], int nxt, bf16x8 (&An)[NA], bf16x8 (&Bn)[NTAPS]) {
-            __builtin_amdgcn_sched_barrier(0);
-            load(nxt, An, Bn);
-            mma(Ac, Bc);
+        if constexpr (NW == 4) {      // one wave per SIMD: software pipeline (ping-pong fragment registers)
+            bf16x8 A0[NA], B0[NTAPS], A1[NA], B1[NTAPS];
+            auto stage = [&](const bf16x8 (&Ac)[NA], const bf16x8 (&Bc)[NTAPS], int nxt, bf16x8 (&An)[NA], bf16x8 (&Bn)[NTAPS]) {
+                __builtin_amdgcn_sched_barrier(0);
+                load(nxt, An, Bn);
+                mma(Ac, Bc);
 #pragma unroll
-            for (int t = 0; t < NTAPS; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                for (int t = 0; t < NTAPS; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NA, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            load(0, A0, B0);
+            int i = 0;
+            for (; i + 2 <= NKW; i += 2) {
+                stage(A0, B0, i + 1, A1, B1);
+                stage(A1, B1, i + 2, A0, B0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NA, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        load(0, A0, B0);
-        int i = 0;
-        for (; i + 2 <= NKW; i += 2) {
-            stage(A0, B0, i + 1, A1, B1);
-            stage(A1, B1, i + 2, A0, B0);
+            if (i < NKW) mma(A0, B0);
+        } else {                      // two waves per SIMD cover each other's LDS latency: keep the register count low
+            for (int i = 0; i < NKW; ++i) {
+                bf16x8 A0[NA], B0[NTAPS];
+                load(i, A0, B0);
+                mma(A0, B0);
+            }
         }
-        if (i < NKW) mma(A0, B0);
         if (p.dbg & 16) t_loop += wall_clock64();
     };
 
@@ -491,7 +506,32 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const WgKArgs p) {
         printf("[wgrad wave %d] 100MHz ticks: first issue %lld, wait %lld, barrier %lld, issue %lld, k-loop %lld, total %lld (tiles %d)\n",
                wave, k1 - k0, t_wait, t_bar, t_issue, t_loop, wall_clock64() - k0, (p.ntiles - (int)blockIdx.y + p.splits - 1) / p.splits);
 
-    if (!wave_active || (p.dbg & 1)) return;
+    // ---- combine the k-split partial sums of one block through LDS (tree over kpart), then one set of atomics
+    if constexpr (KSPLIT > 1) {
+        float* red = reinterpret_cast<float*>(img2);
+        constexpr int REG_F = NTAPS * 16 * 64;            // floats of one wave's accumulators
+        static_assert((size_t)(KSPLIT / 2) * NWB * REG_F * 4 <= 2 * (size_t)DMA_IMG_BYTES, "reduction scratch exceeds the images");
+#pragma unroll
+        for (int sp = KSPLIT / 2; sp >= 1; sp >>= 1) {
+            __syncthreads();
+            if (kpart >= sp && kpart < 2 * sp) {
+                float* d = red + (size_t)((kpart - sp) * NWB + blk) * REG_F + lane;
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) d[(t * 16 + i) * 64] = acc[t][i];
+            }
+            __syncthreads();
+            if (kpart < sp) {
+                const float* d = red + (size_t)(kpart * NWB + blk) * REG_F + lane;
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[t][i] += d[(t * 16 + i) * 64];
+            }
+        }
+    }
+    if (!wave_active || kpart != 0 || (p.dbg & 1)) return;
     const int r = lane & 31, h2 = lane >> 5;
     const int c = c_base + cblk * 32 + r;
     if (c >= CI) return;
@@ -505,10 +545,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(const WgKArgs p) {
     }
 }
 
-template <int NBLK, int CBLK, int NTAPS>
+template <int NBLK, int CBLK, int NTAPS, int NW>
 int launch_dma(WgKArgs& a, hipStream_t st) {
-    CU_CHECK_ARG((size_t)(a.s_iters + a.z_iters) * 4096 <= (size_t)DMA_IMG_BYTES, "cu_conv_wgrad: tile image exceeds %d bytes", DMA_IMG_BYTES);
-    auto k = igemm_wgrad_dma_kernel<NBLK, CBLK, NTAPS>;
+    CU_CHECK_ARG((size_t)(a.s_iters + a.z_iters) * 1024 * NW <= (size_t)DMA_IMG_BYTES, "cu_conv_wgrad: tile image exceeds %d bytes", DMA_IMG_BYTES);
+    auto k = igemm_wgrad_dma_kernel<NBLK, CBLK, NTAPS, NW>;
     const int CI = a.C0 + a.C1;
     a.ctiles = cdiv(CI, 32 * CBLK);
     const int ntn = cdiv(a.CO, 32 * NBLK);
@@ -518,7 +558,7 @@ int launch_dma(WgKArgs& a, hipStream_t st) {
         a.splits = want < 1 ? 1 : want;
     }
     if (a.splits > a.ntiles) a.splits = a.ntiles;
-    hipLaunchKernelGGL(k, dim3(a.ctiles * ntn, a.splits), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k, dim3(a.ctiles * ntn, a.splits), dim3(64 * NW), 0, st, a);
     CU_LAUNCH_CHECK();
     return 0;
 }
@@ -638,27 +678,41 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
     const size_t lim = 0x7fff0000ull;
     if (d->dtype == CU_BF16 && plain && b0 < lim && b1 < lim && bz < lim && !getenv("CU_WGRAD_NODMA")) {
         const int spp = wc ? 8 : 4, zpp = wn ? 8 : 4;
+        const char* nwe = getenv("CU_WGRAD_NW");
+        int dma_nw = nwe ? atoi(nwe) : 8;
+        CU_CHECK_ARG(dma_nw == 4 || dma_nw == 8, "CU_WGRAD_NW must be 4 or 8");
+        {   // every wave needs at least one k-step of the smallest tile this shape may end up with
+            const int nwb = (wn ? 2 : 1) * (wc ? 2 : 1);
+            const int min_nk = ((d->IS > 1 || d->ZS > 1) ? 64 : 256) / 16 / 4;      // the tile loop may halve BM twice
+            if (dma_nw / nwb > min_nk) dma_nw = 4;
+        }
         for (int BM = (d->IS > 1 || d->ZS > 1) ? 64 : 256;; BM >>= 1) {
             CU_CHECK_ARG(BM >= 16, "cu_conv_wgrad: patches do not fit in LDS");
             const int rc = geometry(BM);
             if (rc) return rc;
-            a.s_iters = cdiv(a.s_halo * spp, 256);
-            a.z_iters = cdiv(a.z_halo * zpp, 256);
-            if ((size_t)(a.s_iters + a.z_iters) * 4096 <= (size_t)DMA_IMG_BYTES) break;
+            a.s_iters = cdiv(a.s_halo * spp, 64 * dma_nw);
+            a.z_iters = cdiv(a.z_halo * zpp, 64 * dma_nw);
+            if ((size_t)(a.s_iters + a.z_iters) * 1024 * dma_nw <= (size_t)DMA_IMG_BYTES) break;
         }
         CU_CHECK_ARG(d->ntaps == 4 || a.zsame, "cu_conv_wgrad: per-tap Z shifts are only built for 4 taps");
         a.src0_bytes = (unsigned)b0; a.src1_bytes = (unsigned)b1; a.z_bytes = (unsigned)bz;
+#define CU_WDN(NBv, CBv, NWv)                                                   \
+    do {                                                                        \
+        if (d->ntaps == 9) return launch_dma<NBv, CBv, 9, NWv>(a, st);          \
+        if (d->ntaps == 4) return launch_dma<NBv, CBv, 4, NWv>(a, st);          \
+        return launch_dma<NBv, CBv, 1, NWv>(a, st);                             \
+    } while (0)
 #define CU_WD(NBv, CBv)                                                         \
     do {                                                                        \
-        if (d->ntaps == 9) return launch_dma<NBv, CBv, 9>(a, st);               \
-        if (d->ntaps == 4) return launch_dma<NBv, CBv, 4>(a, st);               \
-        return launch_dma<NBv, CBv, 1>(a, st);                                  \
+        if (dma_nw == 8) CU_WDN(NBv, CBv, 8);                                   \
+        CU_WDN(NBv, CBv, 4);                                                    \
     } while (0)
         if (wn && wc) CU_WD(2, 2);
         if (wn) CU_WD(2, 1);
         if (wc) CU_WD(1, 2);
         CU_WD(1, 1);
 #undef CU_WD
+#undef CU_WDN
     }
 
     int BM = (d->IS > 1 || d->ZS > 1) ? 64 : 512;

@@ -130,6 +130,68 @@ __global__ __launch_bounds__(256) void grad_unprep_kernel(const float* __restric
     }
 }
 
+// ---- batched forms: every conv layer of the network in ONE launch (45 + 45 tiny launches per step otherwise) -----------
+__device__ __forceinline__ const cu_prep_item* find_item(const cu_prep_item* items, int n, int blk) {
+    int i = 0;
+    while (i + 1 < n && items[i + 1].blk0 <= blk) ++i;       // n <= a few dozen, blk0 ascending
+    return items + i;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const cu_prep_item* __restrict__ items, int n) {
+    __shared__ float tile[32][33];
+    const cu_prep_item* it = find_item(items, n, blockIdx.x);
+    int b = blockIdx.x - it->blk0;
+    const int tci = b % it->tiles_ci; b /= it->tiles_ci;
+    const int tco = b % it->tiles_co;
+    const int t = b / it->tiles_co;
+    const int CO = it->CO, CI = it->CI, COP = it->COP;
+    const long long s_co = it->s_co, s_ci = it->s_ci;
+    const float* m = it->master;
+    T* wf = reinterpret_cast<T*>(it->w_fwd);
+    T* wd = reinterpret_cast<T*>(it->w_dgrad);
+    const int co0 = tco * 32, ci0 = tci * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int co = co0 + ty + 8 * k, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < CO && ci < CI) v = m[(size_t)co * s_co + (size_t)ci * s_ci + t];
+        if (co < COP && ci < CI && wf) Elem<T>::st(wf + ((size_t)t * COP + co) * CI + ci, v);
+        tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+    if (wd) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ci = ci0 + ty + 8 * k, co = co0 + tx;
+            if (co < COP && ci < CI) Elem<T>::st(wd + ((size_t)t * CI + ci) * COP + co, tile[tx][ty + 8 * k]);
+        }
+    }
+}
+
+// items[i].master = the logical gradient (written), items[i].w_fwd = dWk (read, f32 [T][COP][CI])
+__global__ __launch_bounds__(256) void grad_unprep_batch_kernel(const cu_prep_item* __restrict__ items, int n, int accumulate) {
+    const cu_prep_item* it = find_item(items, n, blockIdx.x);
+    int b = blockIdx.x - it->blk0;
+    const int tci = b % it->tiles_ci; b /= it->tiles_ci;
+    const int tco = b % it->tiles_co;
+    const int t = b / it->tiles_co;
+    const float* dwk = reinterpret_cast<const float*>(it->w_fwd);
+    float* g = const_cast<float*>(it->master);
+    const int co0 = tco * 32, ci0 = tci * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int co = co0 + ty + 8 * k, ci = ci0 + tx;
+        if (co < it->CO && ci < it->CI) {
+            const float v = dwk[((size_t)t * it->COP + co) * it->CI + ci];
+            float* o = g + (size_t)co * it->s_co + (size_t)ci * it->s_ci + t;
+            *o = accumulate ? *o + v : v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- Adam
 // torch.optim.Adam (no amsgrad, weight_decay folded into the gradient) -- reference vital/vital/system.py:82-115 with
 // vital/vital/config/task/optim/adam.yaml:1-4.  One 16-byte-per-lane streaming pass over the flat parameter buffer.
@@ -237,6 +299,26 @@ extern "C" int cu_adam_step(size_t n, float* p, const float* g, float* m, float*
     const size_t blocks = (n + 1023) / 1024;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, p, g, m,
                        v, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_weight_prep_batch(int dtype, int n_items, const cu_prep_item* items, int total_blocks, void* stream) {
+    CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_weight_prep_batch: bad dtype");
+    CU_CHECK_ARG(n_items > 0 && items && total_blocks > 0, "cu_weight_prep_batch: bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL(weight_prep_batch_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, items, n_items);
+    else
+        hipLaunchKernelGGL(weight_prep_batch_kernel<float>, dim3(total_blocks), dim3(256), 0, st, items, n_items);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_grad_unprep_batch(int n_items, const cu_prep_item* items, int total_blocks, int accumulate, void* stream) {
+    CU_CHECK_ARG(n_items > 0 && items && total_blocks > 0, "cu_grad_unprep_batch: bad argument");
+    hipLaunchKernelGGL(grad_unprep_batch_kernel, dim3(total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       items, n_items, accumulate);
     CU_LAUNCH_CHECK();
     return 0;
 }

@@ -83,6 +83,8 @@ class UNetEngine:
         self.drop_p = 0.5
         self.drop_mask_fn: Optional[Callable[[str, int, int, torch.device], Tensor]] = None   # tests inject masks
         self.debug: Optional[Dict[str, Tensor]] = None    # tests/tools: set to {} to capture per-layer gradients (NHWC)
+        self._pending_unprep: Optional[list] = None
+        self._prep_state = None     # (pointer key, item table, blocks, names) of the batched operand preparation
 
     # ------------------------------------------------------------------------------------------ operand copies
     def _operands(self, name: str, w: Tensor, kind: str, cop: Optional[int] = None):
@@ -93,6 +95,38 @@ class UNetEngine:
         wf, wd = ops.weight_prep(w.detach(), kind, self.dtype, cop)
         self._opcache[name] = (key, wf, wd)
         return wf, wd
+
+    def _prep_all(self, P: Dict[str, Tensor]):
+        """Refresh the bf16/f32 operand copies of EVERY conv / transposed-conv weight in one launch when the parameters
+        changed since the last call (optimizer step, load_state_dict, ...)."""
+        names = [k for k, v in P.items() if v.dim() == 4 and v.shape[1] > 1 and
+                 (k.endswith(".conv.weight") or k.endswith("transp_conv.weight"))]
+        if not names:
+            return
+        ptr_key = (self.dtype, tuple((k, P[k].data_ptr(), tuple(P[k].shape)) for k in names))
+        st = self._prep_state
+        if st is None or st[0] != ptr_key:
+            entries, bufs = [], {}
+            for k in names:
+                w = P[k]
+                kind = "convT" if k.endswith("transp_conv.weight") else "conv"
+                cop = 32 if k == "output_block.conv.weight" else None
+                t, co, ci, _, _ = ops._layout(w.shape, kind)
+                cp = cop or co
+                wf = torch.empty((t, cp, ci), dtype=self.dtype, device=w.device)
+                wd = torch.empty((t, ci, cp), dtype=self.dtype, device=w.device)
+                bufs[k] = (wf, wd)
+                entries.append((w.detach(), wf, wd, kind, cop))
+            table, blocks = ops.prep_table(entries, P[names[0]].device)
+            st = self._prep_state = (ptr_key, table, blocks, names, bufs)
+        ver_key = (ops.PARAM_EPOCH[0], tuple(P[k]._version for k in names))
+        if getattr(self, "_prep_ver", None) == (ptr_key, ver_key):
+            return
+        ops.weight_prep_batch(st[1], len(names), st[2], self.dtype)
+        self._prep_ver = (ptr_key, ver_key)
+        for k in names:
+            wf, wd = st[4][k]
+            self._opcache[k] = ((P[k].data_ptr(), P[k]._version, ops.PARAM_EPOCH[0]), wf, wd)
 
     # ------------------------------------------------------------------------------------------ forward pieces
     def _conv_layer_fwd(self, P, ctx: UNetCtx, prefix: str, srcs: List[Act], stride: int) -> Act:
@@ -165,6 +199,7 @@ class UNetEngine:
             self._last_ctx = ctx
         st = self.strides
         assert st[0] == 1
+        self._prep_all(P)
         a = self._first_layer_fwd(P, ctx, "input_block.conv1", img)
         a = self._conv_layer_fwd(P, ctx, "input_block.conv2", [a], 1)
         ctx.enc = [a]
@@ -196,6 +231,21 @@ class UNetEngine:
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(prefix)
 
+    def _unprep(self, dwk: Tensor, grad: Tensor, kind: str, prefix: str):
+        """kernel-layout dWk -> logical gradient.  With a gradient hook (DDP buckets) right away, so that the layer's
+        gradients are final when the hook fires; otherwise all layers in ONE launch at the end of the backward."""
+        if self.grad_ready_hook is not None or self._pending_unprep is None:
+            ops.grad_unprep(dwk, grad, kind, accumulate=True)
+            self._ready(prefix)
+        else:
+            self._pending_unprep.append((grad, dwk, None, kind, dwk.shape[1]))
+
+    def _flush_unprep(self):
+        pend, self._pending_unprep = self._pending_unprep, None
+        if pend:
+            table, blocks = ops.prep_table(pend, pend[0][0].device)
+            ops.grad_unprep_batch(table, len(pend), blocks, accumulate=True)
+
     def _conv_layer_bwd(self, P, G, ctx: UNetCtx, prefix: str, g: Tensor,
                         dsrc: Optional[List[Tuple[Tensor, int]]]):
         """g: dL/d(activated output), overwritten with dL/dz.  dsrc: [(tensor, accumulate)] per source or None."""
@@ -215,14 +265,12 @@ class UNetEngine:
         if rec.first:
             dw9 = torch.zeros((9, co), dtype=torch.float32, device=g.device)
             ops.conv_c1_wgrad(ctx.img, g, dw9)
-            ops.grad_unprep(dw9.view(9, co, 1), G[f"{prefix}.conv.weight"], "conv", accumulate=True)
-            self._ready(prefix)
+            self._unprep(dw9.view(9, co, 1), G[f"{prefix}.conv.weight"], "conv", prefix)
             return
         ci = w.shape[1]
         dwk = torch.zeros((9, co, ci), dtype=torch.float32, device=g.device)
         ops.conv_wgrad(rec.srcs, g, dwk, grid=(oh, ow), in_stride=rec.stride, z_stride=1, taps=TAPS3_W, n_cols=co)
-        ops.grad_unprep(dwk, G[f"{prefix}.conv.weight"], "conv", accumulate=True)
-        self._ready(prefix)
+        self._unprep(dwk, G[f"{prefix}.conv.weight"], "conv", prefix)
         if dsrc is None:
             return
         _, wd = self._operands(f"{prefix}.conv.weight", w, "conv")
@@ -248,8 +296,7 @@ class UNetEngine:
         dwk = torch.zeros((4, co, ci), dtype=torch.float32, device=du.device)
         taps = [(0, 0, dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)]
         ops.conv_wgrad([rec.src], du, dwk, grid=(h, w_), in_stride=1, z_stride=2, taps=taps, n_cols=co)
-        ops.grad_unprep(dwk, G[f"{rec.prefix}.weight"], "convT", accumulate=True)
-        self._ready(rec.prefix)
+        self._unprep(dwk, G[f"{rec.prefix}.weight"], "convT", rec.prefix)
         _, wd = self._operands(f"{rec.prefix}.weight", w, "convT")
         ops.conv_gemm([Act(du, None, 1.0)], wd, None, grid=(h, w_), in_stride=2,
                       taps=[(dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)], dsts=[d_in], dst_cols=[ci],
@@ -262,13 +309,13 @@ class UNetEngine:
         dt = self.dtype
         last = ctx.last
         n, h, w_, c_last = last.z.shape
+        self._pending_unprep = []
         # ---- 1x1 output conv
         dl = ops.nchw_f32_to_nhwc(dlogits.contiguous(), dt, cp=32)
         w = P["output_block.conv.weight"]
         dwk = torch.zeros((1, 32, c_last), dtype=torch.float32, device=dl.device)
         ops.conv_wgrad([last], dl, dwk, grid=(h, w_), in_stride=1, z_stride=1, taps=[(0, 0, 0, 0, 0)], n_cols=32)
-        ops.grad_unprep(dwk, G["output_block.conv.weight"], "conv", accumulate=True)
-        self._ready("output_block")
+        self._unprep(dwk, G["output_block.conv.weight"], "conv", "output_block")
         _, wd = self._operands("output_block.conv.weight", w, "conv", cop=32)
         g = torch.empty_like(last.z)
         ops.conv_gemm([Act(dl, None, 1.0)], wd, None, grid=(h, w_), in_stride=1, taps=[(0, 0, 0)], dsts=[g],
@@ -313,6 +360,7 @@ class UNetEngine:
         g_c1 = torch.empty_like(c1.out.z)
         self._conv_layer_bwd(P, G, ctx, "input_block.conv2", g, [(g_c1, 0)])
         self._conv_layer_bwd(P, G, ctx, "input_block.conv1", g_c1, None)
+        self._flush_unprep()
 
 
 class ConfidenceEngine:

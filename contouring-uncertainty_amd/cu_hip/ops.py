@@ -339,6 +339,57 @@ def grad_unprep(dwk: Tensor, grad: Tensor, kind: str, accumulate: bool = False):
                                         L.stream_ptr()), "cu_grad_unprep")
 
 
+_PREP_ITEM = None
+
+
+def _prep_item_dtype():
+    global _PREP_ITEM
+    if _PREP_ITEM is None:
+        import numpy as np
+        _PREP_ITEM = np.dtype([("master", "<u8"), ("w_fwd", "<u8"), ("w_dgrad", "<u8"), ("T", "<i4"), ("CO", "<i4"),
+                               ("CI", "<i4"), ("COP", "<i4"), ("s_co", "<i8"), ("s_ci", "<i8"), ("blk0", "<i4"),
+                               ("tiles_ci", "<i4"), ("tiles_co", "<i4"), ("pad", "<i4")])
+        assert _PREP_ITEM.itemsize == 72
+    return _PREP_ITEM
+
+
+def _layout(shape, kind: str):
+    if kind == "conv":
+        co, ci, kh, kw = shape
+        t = kh * kw
+        return t, co, ci, ci * t, t
+    ci, co, kh, kw = shape
+    t = kh * kw
+    return t, co, ci, t, co * t
+
+
+def prep_table(entries, device) -> Tuple[Tensor, int]:
+    """entries: [(logical tensor, w_fwd | dWk, w_dgrad | None, kind, cop)] -> (device item table, total blocks)."""
+    import numpy as np
+    arr = np.zeros(len(entries), dtype=_prep_item_dtype())
+    blk = 0
+    for i, (logical, a, b, kind, cop) in enumerate(entries):
+        t, co, ci, s_co, s_ci = _layout(logical.shape, kind)
+        cop = cop or co
+        tiles_ci, tiles_co = (ci + 31) // 32, (cop + 31) // 32
+        arr[i] = (logical.data_ptr(), a.data_ptr() if a is not None else 0, b.data_ptr() if b is not None else 0, t, co,
+                  ci, cop, s_co, s_ci, blk, tiles_ci, tiles_co, 0)
+        blk += t * tiles_ci * tiles_co
+    return torch.from_numpy(arr.view(np.uint8)).to(device), blk
+
+
+def weight_prep_batch(table: Tensor, n: int, blocks: int, dtype: torch.dtype):
+    with _Prof("weight_prep"):
+        L.check(L.load().cu_weight_prep_batch(L.dtype_code(dtype), n, L.ptr(table), blocks, L.stream_ptr()),
+                "cu_weight_prep_batch")
+
+
+def grad_unprep_batch(table: Tensor, n: int, blocks: int, accumulate: bool = True):
+    with _Prof("weight_prep"):
+        L.check(L.load().cu_grad_unprep_batch(n, L.ptr(table), blocks, int(accumulate), L.stream_ptr()),
+                "cu_grad_unprep_batch")
+
+
 # Raw-pointer kernels do not bump tensor._version: operand caches key on this epoch as well.
 PARAM_EPOCH = [0]
 

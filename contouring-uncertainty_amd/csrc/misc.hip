@@ -137,57 +137,86 @@ __device__ __forceinline__ const cu_prep_item* find_item(const cu_prep_item* ite
     return items + i;
 }
 
+// One workgroup = a 32 x 32 block of (co, ci) with ALL its taps.  The logical layouts keep the taps innermost, so along
+// the slower channel dimension a block is 32 rows of 32*T contiguous floats: coalesced on the logical side, and the
+// kernel layouts are written / read in 64- or 128-byte rows.  (A per-tap version read every logical line T times with
+// 4 useful bytes per 36: 0.5 ms per pass over the 25 M weights; it survives as the non-batched entry point.)
+constexpr int PREP_MAXT = 9;
+
 template <typename T>
 __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const cu_prep_item* __restrict__ items, int n) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[32 * (32 * PREP_MAXT + 1)];
     const cu_prep_item* it = find_item(items, n, blockIdx.x);
-    int b = blockIdx.x - it->blk0;
-    const int tci = b % it->tiles_ci; b /= it->tiles_ci;
-    const int tco = b % it->tiles_co;
-    const int t = b / it->tiles_co;
-    const int CO = it->CO, CI = it->CI, COP = it->COP;
-    const long long s_co = it->s_co, s_ci = it->s_ci;
-    const float* m = it->master;
-    T* wf = reinterpret_cast<T*>(it->w_fwd);
-    T* wd = reinterpret_cast<T*>(it->w_dgrad);
+    const int b = blockIdx.x - it->blk0;
+    const int tci = b % it->tiles_ci, tco = b / it->tiles_ci;
+    const int NT = it->T, CO = it->CO, CI = it->CI, COP = it->COP;
+    const int pitch = 32 * NT + 1;
+    const bool co_rows = it->s_co > it->s_ci;        // conv: rows = co (stride CI*T); transposed conv: rows = ci
     const int co0 = tco * 32, ci0 = tci * 32;
+    const int R0 = co_rows ? co0 : ci0, C0 = co_rows ? ci0 : co0;
+    const int RN = co_rows ? CO : CI, CN = co_rows ? CI : CO;
+    const long long s_r = co_rows ? it->s_co : it->s_ci;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int co = co0 + ty + 8 * k, ci = ci0 + tx;
-        float v = 0.f;
-        if (co < CO && ci < CI) v = m[(size_t)co * s_co + (size_t)ci * s_ci + t];
-        if (co < COP && ci < CI && wf) Elem<T>::st(wf + ((size_t)t * COP + co) * CI + ci, v);
-        tile[ty + 8 * k][tx] = v;
+    const int cvalid = min(32, CN - C0) * NT;                 // valid floats of a slab row
+    for (int r = ty; r < 32; r += 8) {
+        const float* src = it->master + (size_t)(R0 + r) * s_r + (size_t)C0 * NT;
+        for (int k = tx; k < 32 * NT; k += 32)
+            tile[r * pitch + k] = (R0 + r < RN && k < cvalid) ? src[k] : 0.f;
     }
     __syncthreads();
-    if (wd) {
+    T* wf = reinterpret_cast<T*>(it->w_fwd);
+    T* wd = reinterpret_cast<T*>(it->w_dgrad);
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int ci = ci0 + ty + 8 * k, co = co0 + tx;
-            if (co < COP && ci < CI) Elem<T>::st(wd + ((size_t)t * CI + ci) * COP + co, tile[tx][ty + 8 * k]);
+            const int a = ty + 8 * k;                // slow index of the output row, tx = fast index
+            if (wf) {                                // wf[t][co][ci]: co = a, ci = tx
+                const int co = co0 + a, ci = ci0 + tx;
+                const float v = co_rows ? tile[a * pitch + tx * NT + t] : tile[tx * pitch + a * NT + t];
+                if (co < COP && ci < CI) Elem<T>::st(wf + ((size_t)t * COP + co) * CI + ci, v);
+            }
+            if (wd) {                                // wd[t][ci][co]: ci = a, co = tx
+                const int ci = ci0 + a, co = co0 + tx;
+                const float v = co_rows ? tile[tx * pitch + a * NT + t] : tile[a * pitch + tx * NT + t];
+                if (co < COP && ci < CI) Elem<T>::st(wd + ((size_t)t * CI + ci) * COP + co, v);
+            }
         }
     }
 }
 
 // items[i].master = the logical gradient (written), items[i].w_fwd = dWk (read, f32 [T][COP][CI])
 __global__ __launch_bounds__(256) void grad_unprep_batch_kernel(const cu_prep_item* __restrict__ items, int n, int accumulate) {
+    __shared__ float tile[32 * (32 * PREP_MAXT + 1)];
     const cu_prep_item* it = find_item(items, n, blockIdx.x);
-    int b = blockIdx.x - it->blk0;
-    const int tci = b % it->tiles_ci; b /= it->tiles_ci;
-    const int tco = b % it->tiles_co;
-    const int t = b / it->tiles_co;
-    const float* dwk = reinterpret_cast<const float*>(it->w_fwd);
-    float* g = const_cast<float*>(it->master);
+    const int b = blockIdx.x - it->blk0;
+    const int tci = b % it->tiles_ci, tco = b / it->tiles_ci;
+    const int NT = it->T, CO = it->CO, CI = it->CI, COP = it->COP;
+    const int pitch = 32 * NT + 1;
+    const bool co_rows = it->s_co > it->s_ci;
     const int co0 = tco * 32, ci0 = tci * 32;
+    const float* dwk = reinterpret_cast<const float*>(it->w_fwd);
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int co = co0 + ty + 8 * k, ci = ci0 + tx;
-        if (co < it->CO && ci < it->CI) {
-            const float v = dwk[((size_t)t * it->COP + co) * it->CI + ci];
-            float* o = g + (size_t)co * it->s_co + (size_t)ci * it->s_ci + t;
-            *o = accumulate ? *o + v : v;
+        for (int k = 0; k < 4; ++k) {
+            const int co = co0 + ty + 8 * k, ci = ci0 + tx;
+            const float v = (co < CO && ci < CI) ? dwk[((size_t)t * COP + co) * CI + ci] : 0.f;
+            if (co_rows) tile[(ty + 8 * k) * pitch + tx * NT + t] = v;
+            else tile[tx * pitch + (ty + 8 * k) * NT + t] = v;
+        }
+    }
+    __syncthreads();
+    const int R0 = co_rows ? co0 : ci0, C0 = co_rows ? ci0 : co0;
+    const int RN = co_rows ? CO : CI, CN = co_rows ? CI : CO;
+    const long long s_r = co_rows ? it->s_co : it->s_ci;
+    const int cvalid = min(32, CN - C0) * NT;
+    float* g = const_cast<float*>(it->master);
+    for (int r = ty; r < 32; r += 8) {
+        if (R0 + r >= RN) continue;
+        float* dst = g + (size_t)(R0 + r) * s_r + (size_t)C0 * NT;
+        for (int k = tx; k < cvalid; k += 32) {
+            const float v = tile[r * pitch + k];
+            dst[k] = accumulate ? dst[k] + v : v;
         }
     }
 }

@@ -374,7 +374,8 @@ def prep_table(entries, device) -> Tuple[Tensor, int]:
         tiles_ci, tiles_co = (ci + 31) // 32, (cop + 31) // 32
         arr[i] = (logical.data_ptr(), a.data_ptr() if a is not None else 0, b.data_ptr() if b is not None else 0, t, co,
                   ci, cop, s_co, s_ci, blk, tiles_ci, tiles_co, 0)
-        blk += t * tiles_ci * tiles_co
+        assert t <= 9 and (s_co == t or s_ci == t)      # taps innermost (PREP_MAXT)
+        blk += tiles_ci * tiles_co
     return torch.from_numpy(arr.view(np.uint8)).to(device), blk
 
 

@@ -165,7 +165,8 @@ int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_ci, const f
                    void* stream);
 
 /* Batched forms: one launch for every conv layer of the network.  `items` is a DEVICE array (blk0 ascending, blk0 of
- * item i = number of 256-thread blocks of items 0..i-1; an item has T * tiles_co * tiles_ci blocks of 32 x 32 weights).
+ * item i = number of 256-thread blocks of items 0..i-1; an item has tiles_co * tiles_ci blocks of 32 x 32 x T weights,
+ * T <= 9 and the taps innermost in the logical layout).
  * cu_weight_prep_batch: master -> w_fwd / w_dgrad of element type `dtype` (either may be NULL).
  * cu_grad_unprep_batch: w_fwd holds the kernel-layout f32 gradient dWk [T][COP][CI], master is the logical gradient. */
 typedef struct {

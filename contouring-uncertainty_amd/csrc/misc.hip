@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void grad_unprep_kernel(const float* __restric
     }
 }
 
-// ---- batched forms: every conv layer of the network in ONE launch (45 + 45 tiny launches per step otherwise) -----------
+// ---- batched form: the operand copies of every conv layer of the network in ONE launch ---------------------------------
 __device__ __forceinline__ const cu_prep_item* find_item(const cu_prep_item* items, int n, int blk) {
     int i = 0;
     while (i + 1 < n && items[i + 1].blk0 <= blk) ++i;       // n <= a few dozen, blk0 ascending
@@ -180,43 +180,6 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const cu_prep_it
                 const float v = co_rows ? tile[tx * pitch + a * NT + t] : tile[a * pitch + tx * NT + t];
                 if (co < COP && ci < CI) Elem<T>::st(wd + ((size_t)t * CI + ci) * COP + co, v);
             }
-        }
-    }
-}
-
-// items[i].master = the logical gradient (written), items[i].w_fwd = dWk (read, f32 [T][COP][CI])
-__global__ __launch_bounds__(256) void grad_unprep_batch_kernel(const cu_prep_item* __restrict__ items, int n, int accumulate) {
-    __shared__ float tile[32 * (32 * PREP_MAXT + 1)];
-    const cu_prep_item* it = find_item(items, n, blockIdx.x);
-    const int b = blockIdx.x - it->blk0;
-    const int tci = b % it->tiles_ci, tco = b / it->tiles_ci;
-    const int NT = it->T, CO = it->CO, CI = it->CI, COP = it->COP;
-    const int pitch = 32 * NT + 1;
-    const bool co_rows = it->s_co > it->s_ci;
-    const int co0 = tco * 32, ci0 = tci * 32;
-    const float* dwk = reinterpret_cast<const float*>(it->w_fwd);
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int co = co0 + ty + 8 * k, ci = ci0 + tx;
-            const float v = (co < CO && ci < CI) ? dwk[((size_t)t * COP + co) * CI + ci] : 0.f;
-            if (co_rows) tile[(ty + 8 * k) * pitch + tx * NT + t] = v;
-            else tile[tx * pitch + (ty + 8 * k) * NT + t] = v;
-        }
-    }
-    __syncthreads();
-    const int R0 = co_rows ? co0 : ci0, C0 = co_rows ? ci0 : co0;
-    const int RN = co_rows ? CO : CI, CN = co_rows ? CI : CO;
-    const long long s_r = co_rows ? it->s_co : it->s_ci;
-    const int cvalid = min(32, CN - C0) * NT;
-    float* g = const_cast<float*>(it->master);
-    for (int r = ty; r < 32; r += 8) {
-        if (R0 + r >= RN) continue;
-        float* dst = g + (size_t)(R0 + r) * s_r + (size_t)C0 * NT;
-        for (int k = tx; k < cvalid; k += 32) {
-            const float v = tile[r * pitch + k];
-            dst[k] = accumulate ? dst[k] + v : v;
         }
     }
 }
@@ -340,14 +303,6 @@ extern "C" int cu_weight_prep_batch(int dtype, int n_items, const cu_prep_item* 
         hipLaunchKernelGGL(weight_prep_batch_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, items, n_items);
     else
         hipLaunchKernelGGL(weight_prep_batch_kernel<float>, dim3(total_blocks), dim3(256), 0, st, items, n_items);
-    CU_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int cu_grad_unprep_batch(int n_items, const cu_prep_item* items, int total_blocks, int accumulate, void* stream) {
-    CU_CHECK_ARG(n_items > 0 && items && total_blocks > 0, "cu_grad_unprep_batch: bad argument");
-    hipLaunchKernelGGL(grad_unprep_batch_kernel, dim3(total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       items, n_items, accumulate);
     CU_LAUNCH_CHECK();
     return 0;
 }

@@ -109,8 +109,9 @@ class GradSync:
         sizes = [params[n].numel() for n in names]
         self.ranges = prefix_ranges(names, sizes)
         self.bar = BucketedAllReduce(sum(sizes), bucket_elems, group)
-        self.model.engine.grad_ready_hook = self._ready
-        self.model.flat_grad_hook = self.bar.begin
+        if self.world > 1:      # a single rank has nothing to exchange: the engine then un-prepares all gradients at once
+            self.model.engine.grad_ready_hook = self._ready
+            self.model.flat_grad_hook = self.bar.begin
         self._skew_work = None
 
     def broadcast_parameters(self):
@@ -129,6 +130,8 @@ class GradSync:
 
     def finish(self):
         """Call after ``loss.backward()`` and before the optimizer step."""
+        if self.world == 1:
+            return
         if self.skew is not None and self.skew.last_flat_grad is not None and self.world > 1:
             dist.all_reduce(self.skew.last_flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         self.bar.finish()

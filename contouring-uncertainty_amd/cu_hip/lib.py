@@ -68,7 +68,6 @@ _SIGS = {
     "cu_grad_unprep": (C.c_int, [C.c_int] * 4 + [C.c_long, C.c_long] + [_P] * 2 + [C.c_int, _P]),
     "cu_psm_sample_gauss": (C.c_int, [C.c_int] * 3 + [_P] * 6 + [C.c_int, _P, C.c_int] + [_P] * 4 + [C.c_uint64, _P, _P]),
     "cu_weight_prep_batch": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P]),
-    "cu_grad_unprep_batch": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P]),
     "cu_psm_record_floats": (C.c_int, [C.c_int, _P, _P]),
     "cu_psm_setup": (C.c_int, [C.c_int] * 2 + [_P] * 5 + [C.c_int, _P, _P, _P, C.c_int, _P]),
     "cu_psm_sample_skew": (C.c_int, [C.c_int] * 3 + [_P] * 3 + [C.c_float, C.c_uint64, _P, C.c_int, _P, _P, C.c_int, _P,

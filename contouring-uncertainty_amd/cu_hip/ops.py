@@ -385,12 +385,6 @@ def weight_prep_batch(table: Tensor, n: int, blocks: int, dtype: torch.dtype):
                 "cu_weight_prep_batch")
 
 
-def grad_unprep_batch(table: Tensor, n: int, blocks: int, accumulate: bool = True):
-    with _Prof("weight_prep"):
-        L.check(L.load().cu_grad_unprep_batch(n, L.ptr(table), blocks, int(accumulate), L.stream_ptr()),
-                "cu_grad_unprep_batch")
-
-
 # Raw-pointer kernels do not bump tensor._version: operand caches key on this epoch as well.
 PARAM_EPOCH = [0]
 

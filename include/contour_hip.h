@@ -164,11 +164,10 @@ int cu_weight_prep(int dtype, int T, int CO, int CI, int COP, long s_co, long s_
 int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_ci, const float* dwk, float* grad, int accumulate,
                    void* stream);
 
-/* Batched forms: one launch for every conv layer of the network.  `items` is a DEVICE array (blk0 ascending, blk0 of
+/* Batched form: one launch for every conv layer of the network.  `items` is a DEVICE array (blk0 ascending, blk0 of
  * item i = number of 256-thread blocks of items 0..i-1; an item has tiles_co * tiles_ci blocks of 32 x 32 x T weights,
  * T <= 9 and the taps innermost in the logical layout).
- * cu_weight_prep_batch: master -> w_fwd / w_dgrad of element type `dtype` (either may be NULL).
- * cu_grad_unprep_batch: w_fwd holds the kernel-layout f32 gradient dWk [T][COP][CI], master is the logical gradient. */
+ * cu_weight_prep_batch: master -> w_fwd / w_dgrad of element type `dtype` (either may be NULL). */
 typedef struct {
     const float* master;
     void* w_fwd;
@@ -178,7 +177,7 @@ typedef struct {
     int blk0, tiles_ci, tiles_co, pad;
 } cu_prep_item;
 int cu_weight_prep_batch(int dtype, int n_items, const cu_prep_item* items, int total_blocks, void* stream);
-int cu_grad_unprep_batch(int n_items, const cu_prep_item* items, int total_blocks, int accumulate, void* stream);
+
 /* torch.optim.Adam(lr, betas, eps, weight_decay) semantics (vital/vital/config/task/optim/adam.yaml:1-4):
  * g += wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps). */
 int cu_adam_step(size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,

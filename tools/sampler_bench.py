@@ -1,0 +1,71 @@
+"""Secondary metric (BASELINE config c5): MC contour sampler throughput, frames/s at S samples per frame.
+
+    python tools/sampler_bench.py [frames] [samples] > gpurun_out/sampler_bench.json
+
+Gaussian PSM sampler (cu_psm_sample_gauss), skew-normal grid sampler (cu_psm_setup + cu_psm_sample_skew) and the ED/ES
+sequence samplers, against the CPU oracle (the reference's algorithm, PyTorch-CPU) on a bounded sample.
+"""
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "contouring-uncertainty_amd"))
+import numpy as np
+import torch
+
+from contour_uncertainty.sampler.posterior_shape_model.psm import PosteriorShapeModelSampler
+from contour_uncertainty.sampler.posterior_shape_model.psm_skew import SkewPosteriorShapeModelSampler
+from contour_uncertainty.sampler.posterior_shape_model.psm_skew_sequence import SequenceSkewPSMSampler
+from contour_uncertainty.sampler.posterior_shape_model.sequence_sampler import SequencePSMSampler
+from oracle import sampler as S
+
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+NS = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+G = ROOT / "tests" / "golden"
+psm_path, seq_path = G / "camus-cont_psm_11_no_std.npz", G / "camus-cont_sequence_psm_11_no_std.npz"
+psm, seq = dict(np.load(psm_path)), dict(np.load(seq_path))
+g = torch.Generator().manual_seed(0)
+idx = torch.randint(0, psm["X_val"].shape[0], (F,), generator=g)
+mu = torch.stack([torch.tensor(psm["X_val"][i] + psm["scaler_mean"]).float().reshape(21, 2) for i in idx.tolist()])
+a = torch.randn(F, 21, 2, 2, generator=g)
+cov = a @ a.transpose(-1, -2) * 6.0 + torch.eye(2) * 2.0
+alpha = torch.randn(F, 21, 2, generator=g) * 2.0
+mu, cov, alpha = mu.cuda(), cov.cuda(), alpha.cuda()
+
+
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+res = {"frames": F, "samples_per_frame": NS, "unit": "frames/s"}
+gs = PosteriorShapeModelSampler(psm_path)
+dt = timeit(lambda: gs.sample_batch(mu, cov, n=NS, seed=1))
+res["gauss_psm"] = {"frames_per_s": round(F / dt, 1), "ms": round(dt * 1e3, 3)}
+sk = SkewPosteriorShapeModelSampler(psm_path)
+dt = timeit(lambda: sk.sample_batch(mu, cov, alpha, n=NS, seed=1), reps=3)
+res["skew_psm"] = {"frames_per_s": round(F / dt, 1), "ms": round(dt * 1e3, 3)}
+pair_mu = torch.tensor(seq["X_val"][3] + seq["scaler_mean"]).float().reshape(2, 21, 2).cuda()
+sq = SequencePSMSampler(psm_path, seq_path)
+dt = timeit(lambda: sq(pair_mu, cov[:2], n=NS), reps=3)
+res["sequence_gauss (1 ED/ES pair)"] = {"pairs_per_s": round(1 / dt, 2), "ms": round(dt * 1e3, 3)}
+ss = SequenceSkewPSMSampler(psm_path, seq_path)
+dt = timeit(lambda: ss(pair_mu, cov[:2], alpha[:2], n=NS), reps=3)
+res["sequence_skew (1 ED/ES pair)"] = {"pairs_per_s": round(1 / dt, 2), "ms": round(dt * 1e3, 3)}
+
+# CPU oracle on a bounded sample (1 frame, a few samples), same algorithm as the reference
+torch.set_num_threads(16)
+og = S.GaussianPSMSamplerOracle(psm)
+t0 = time.perf_counter(); og(mu[0].cpu(), cov[0].cpu(), n=32); dt = time.perf_counter() - t0
+res["cpu_oracle_gauss"] = {"frames_per_s_at_S": round(1 / (dt / 32 * NS), 4), "sample": "1 frame x 32 samples"}
+os_ = S.SkewPSMSamplerOracle(psm)
+e3, u = torch.randn(1, 4, 21, 3), torch.rand(1, 4, 21)
+t0 = time.perf_counter(); os_(mu[:1].cpu(), cov[:1].cpu(), alpha[:1].cpu(), 4, e3, u); dt = time.perf_counter() - t0
+res["cpu_oracle_skew"] = {"frames_per_s_at_S": round(1 / (dt / 4 * NS), 5), "sample": "1 frame x 4 samples"}
+print(json.dumps(res))

@@ -203,7 +203,10 @@ def main():
             famrec = json.loads(pmc.read_text())["families"].get(name)
             if famrec:
                 traffic = round(famrec["bytes_per_launch"])
-        result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
+        symbols = {"igemm_conv": "igemm_conv_kernel<*> + igemm_conv_dma_kernel<*> (all instantiations)",
+                   "igemm_wgrad": "igemm_wgrad_kernel<*> + igemm_wgrad_dma_kernel<*> (all instantiations)"}
+        result["roofline"] = {"bound": "mfma", "kernel": name, "kernel_symbols": symbols.get(name, name),
+                              "achieved": round(achieved, 2),
                               "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
                               "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": traffic,
                               "traffic_source": "profiles/r01_pmc_hbm_traffic.json (HBM bytes per launch, PMC)" if traffic else None,

@@ -1,4 +1,6 @@
 // Small kernels of libcontour_hip.so: first-layer direct conv (Cin = 1), operand-copy preparation, fused Adam.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -126,6 +128,37 @@ __global__ __launch_bounds__(256) void grad_unprep_kernel(const float* __restric
             const float v = dwk[((size_t)t * COP + co) * CI + ci];
             float* o = g + (size_t)co * s_co + (size_t)ci * s_ci + t;
             *o = accumulate ? *o + v : v;
+        }
+    }
+}
+
+// The same for logical layouts with the taps innermost (every conv / transposed-conv weight): one workgroup gathers an
+// 8 x 32 block of (slow channel, fast channel) with ALL its taps in LDS and writes the logical gradient in contiguous
+// rows of 32*T floats (the per-tap kernel above touches every logical line T times, 4 useful bytes per 36).
+constexpr int UNPREP_MAXT = 9;
+__global__ __launch_bounds__(256) void grad_unprep_rows_kernel(const float* __restrict__ dwk, float* __restrict__ g, int NT,
+                                                               int CO, int CI, int COP, long s_co, long s_ci, int accumulate) {
+    __shared__ float tile[8 * (32 * UNPREP_MAXT + 1)];
+    const bool co_rows = s_co > s_ci;                  // conv: rows = co, columns = ci; transposed conv: the other way
+    const int r0 = blockIdx.y * 8, c0 = blockIdx.x * 32;
+    const int RN = co_rows ? CO : CI, CN = co_rows ? CI : CO;
+    const int pitch = 32 * NT + 1;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // column tx of row ty
+    {
+        const int r = r0 + ty, c = c0 + tx;
+        const int co = co_rows ? r : c, ci = co_rows ? c : r;
+        const bool ok = r < RN && c < CN;
+        for (int t = 0; t < NT; ++t)
+            tile[ty * pitch + tx * NT + t] = ok ? dwk[((size_t)t * COP + co) * CI + ci] : 0.f;
+    }
+    __syncthreads();
+    const long s_r = co_rows ? s_co : s_ci;
+    const int cvalid = min(32, CN - c0) * NT;
+    if (r0 + ty < RN) {
+        float* dst = g + (size_t)(r0 + ty) * s_r + (size_t)c0 * NT;
+        for (int k = tx; k < cvalid; k += 32) {
+            const float v = tile[ty * pitch + k];
+            dst[k] = accumulate ? dst[k] + v : v;
         }
     }
 }
@@ -276,6 +309,14 @@ extern "C" int cu_weight_prep(int dtype, int T, int CO, int CI, int COP, long s_
 extern "C" int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_ci, const float* dwk, float* grad,
                               int accumulate, void* stream) {
     CU_CHECK_ARG(T > 0 && CO > 0 && CI > 0 && COP >= CO && dwk && grad, "cu_grad_unprep: bad argument");
+    const bool co_rows = s_co > s_ci;
+    if (T <= UNPREP_MAXT && ((co_rows && s_ci == T) || (!co_rows && s_co == T))) {
+        dim3 grid(cdiv(co_rows ? CI : CO, 32), cdiv(co_rows ? CO : CI, 8));
+        hipLaunchKernelGGL(grad_unprep_rows_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dwk, grad, T,
+                           CO, CI, COP, s_co, s_ci, accumulate);
+        CU_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid(cdiv(CI, 32), cdiv(CO, 32), T);
     hipLaunchKernelGGL(grad_unprep_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dwk, grad, CO, CI,
                        COP, s_co, s_ci, accumulate);

@@ -390,3 +390,27 @@ def test_conv_wide_dma_kernel(case):
         ref = ref.clone()
         ref[:, d0:] += 1.0
     assert rel_err(got, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_transpose_single_pass_matches_four_parity_launches(dtype):
+    """parity-column mode of cu_conv_gemm (W[4][CO][CI] viewed as 4*CO GEMM columns, one pass over the source) vs the
+    four per-parity launches and vs F.conv_transpose2d."""
+    ops = _ops()
+    n, ci, co, size = 3, 64, 32, 16
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(n, ci, size, size, device=DEV, generator=g)
+    a, r = make_act(x, dtype, False, 1.0, g)
+    w = torch.randn(ci, co, 2, 2, device=DEV, generator=g) / math.sqrt(ci)
+    wf, _ = ops.weight_prep(w, "convT", dtype)
+    one = torch.empty(n, 2 * size, 2 * size, co, device=DEV, dtype=dtype)
+    ops.conv_gemm([a], wf.view(1, 4 * co, ci), None, grid=(size, size), in_stride=1, taps=[(0, 0, 0)], dsts=[one],
+                  dst_cols=[co], out_stride=2, n_cols=4 * co, parity_cols=co)
+    four = torch.empty_like(one)
+    for dy in range(2):
+        for dx in range(2):
+            ops.conv_gemm([a], wf, None, grid=(size, size), in_stride=1, taps=[(0, 0, dy * 2 + dx)], dsts=[four],
+                          dst_cols=[co], out_stride=2, out_off=(dy, dx))
+    assert torch.equal(one, four)
+    ref = F.conv_transpose2d(r, rq(w, dtype), stride=2)
+    assert rel_err(nchw(one), ref) < tol(dtype)

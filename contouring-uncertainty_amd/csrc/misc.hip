@@ -8,32 +8,55 @@ namespace {
 // ---------------------------------------------------------------------------------------- first conv, Cin = 1
 // reference: input_block.conv1.conv = nn.Conv2d(1, 32, 3, 1, 1) (models/nnUnet/unet2.py:113-119, layers.py:192).
 // 0.13 % of the network's MACs and HBM-bound on its 64-byte/pixel store, so plain VALU FMAs.
+// One thread = one 16-byte piece of channels for C1_PX consecutive pixels of a row: the 9 x PIECE weights are loaded once
+// per thread and the 3 x (C1_PX + 2) image window slides (the first version reloaded 72 weights per output piece).
+constexpr int C1_PX = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                           const float* __restrict__ bias, T* __restrict__ dst, int N,
                                                           int H, int W, int CO) {
     constexpr int PIECE = Elem<T>::PIECE;
     const int ppp = CO / PIECE;
+    const int wgroups = (W + C1_PX - 1) / C1_PX;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t total = (size_t)N * H * W * ppp;
+    const size_t total = (size_t)N * H * wgroups * ppp;
     if (i >= total) return;
     const int piece = i % ppp;
-    const size_t pix = i / ppp;
-    const int x = pix % W;
-    const int y = (pix / W) % H;
-    const int n = pix / ((size_t)W * H);
-    float acc[PIECE];
+    size_t r = i / ppp;
+    const int x0 = (int)(r % wgroups) * C1_PX; r /= wgroups;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    float wr[9][PIECE], b[PIECE];
 #pragma unroll
-    for (int e = 0; e < PIECE; ++e) acc[e] = bias ? bias[piece * PIECE + e] : 0.f;
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int sy = y + t / 3 - 1, sx = x + t % 3 - 1;
-        if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
-        const float v = img[((size_t)n * H + sy) * W + sx];
+        for (int e = 0; e < PIECE; ++e) wr[t][e] = w[t * CO + piece * PIECE + e];
 #pragma unroll
-        for (int e = 0; e < PIECE; ++e) acc[e] += v * w[t * CO + piece * PIECE + e];
+    for (int e = 0; e < PIECE; ++e) b[e] = bias ? bias[piece * PIECE + e] : 0.f;
+    float win[3][C1_PX + 2];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int sy = y + dy - 1;
+#pragma unroll
+        for (int k = 0; k < C1_PX + 2; ++k) {
+            const int sx = x0 + k - 1;
+            win[dy][k] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? img[((size_t)n * H + sy) * W + sx] : 0.f;
+        }
     }
-    store_piece<T>(dst + pix * CO + piece * PIECE, acc);
+#pragma unroll
+    for (int k = 0; k < C1_PX; ++k) {
+        if (x0 + k >= W) break;
+        float acc[PIECE];
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) acc[e] = b[e];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float v = win[t / 3][k + t % 3];
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) acc[e] += v * wr[t][e];
+        }
+        store_piece<T>(dst + (((size_t)n * H + y) * W + x0 + k) * CO + piece * PIECE, acc);
+    }
 }
 
 template <typename T>
@@ -258,7 +281,7 @@ extern "C" int cu_conv_c1_fwd(int dtype, int N, int H, int W, int CO, const floa
     CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_conv_c1_fwd: bad dtype");
     const int PIECE = dtype == CU_BF16 ? 8 : 4;
     CU_CHECK_ARG(N > 0 && H > 0 && W > 0 && CO > 0 && CO % PIECE == 0 && img && w && dst, "cu_conv_c1_fwd: bad argument");
-    const size_t total = (size_t)N * H * W * (CO / PIECE);
+    const size_t total = (size_t)N * H * ((W + C1_PX - 1) / C1_PX) * (CO / PIECE);
     const unsigned blocks = (unsigned)((total + 255) / 256);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == CU_BF16)

@@ -747,7 +747,9 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
         const size_t b0 = (size_t)d->N * d->SH * d->SW * d->C0 * 2, b1 = (size_t)d->N * d->SH * d->SW * d->C1 * 2;
         const size_t bw = (size_t)9 * d->CO * CI * 2, lim = 0x7fff0000ull;
         const long px_all = (long)d->N * d->PH * d->PW;
-        const int dnb = d->CO % 128 == 0 || d->CO > 256 ? 4 : 2;       // 128-column tiles unless that wastes half a tile
+        int dnb = d->CO % 128 == 0 || d->CO > 256 ? 4 : 2;             // 128-column tiles unless that wastes half a tile
+        if (dnb == 4 && (px_all / 512) * cdiv(d->CO, 128) < 256)
+            dnb = 2;                                                     // ... or leaves CUs without a workgroup
         if (bf && plain0 && d->IS == 1 && d->ntaps == 9 && !d->out_nchw_f32 && d->CO >= 128 && CI >= 128 && d->C0 % 32 == 0 &&
             d->D0 % 32 == 0 && d->CO % 16 == 0 && !d->par_co && b0 < lim && b1 < lim && bw < lim &&
             (px_all / 512) * cdiv(d->CO, 32 * dnb) >= 128 && !getenv("CU_CONV_NODMA")) {

@@ -414,3 +414,27 @@ def test_conv_transpose_single_pass_matches_four_parity_launches(dtype):
     assert torch.equal(one, four)
     ref = F.conv_transpose2d(r, rq(w, dtype), stride=2)
     assert rel_err(nchw(one), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_weight_prep_batch_matches_per_layer(dtype):
+    """cu_weight_prep_batch (every layer in one launch) vs cu_weight_prep, conv and transposed-conv layouts, padded COP."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(7)
+    layers = [(torch.randn(64, 32, 3, 3, device=DEV, generator=g), "conv", None),
+              (torch.randn(480, 256, 3, 3, device=DEV, generator=g), "conv", None),
+              (torch.randn(128, 64, 2, 2, device=DEV, generator=g), "convT", None),
+              (torch.randn(21, 32, 1, 1, device=DEV, generator=g), "conv", 32)]
+    entries, outs = [], []
+    for w, kind, cop in layers:
+        t, co, ci, _, _ = ops._layout(w.shape, kind)
+        cp = cop or co
+        wf = torch.full((t, cp, ci), 7.0, device=DEV).to(dtype)
+        wd = torch.full((t, ci, cp), 7.0, device=DEV).to(dtype)
+        entries.append((w, wf, wd, kind, cop))
+        outs.append((wf, wd))
+    table, blocks = ops.prep_table(entries, torch.device(DEV))
+    ops.weight_prep_batch(table, len(entries), blocks, dtype)
+    for (w, kind, cop), (wf, wd) in zip(layers, outs):
+        rf, rd = ops.weight_prep(w, kind, dtype, cop)
+        assert torch.equal(wf, rf) and torch.equal(wd, rd)

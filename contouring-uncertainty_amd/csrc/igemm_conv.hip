@@ -482,7 +482,8 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Wide layers (bf16, 3x3 stride-1 gathers, weights too large to stay in LDS): 8 waves, tile = 512 pixels x 128 columns.
+// Wide layers (bf16, 3x3 stride-1 / stride-2 gathers, weights too large to stay in LDS): 8 waves, tile = 512 (256 for
+// stride 2) pixels x 128 columns.
 //   * the weight slice of a 32-channel chunk (9 x 128 x 64 B = 72 KiB) is streamed once per 512 pixels (the 4-wave
 //     kernel above re-streams it per 256: on these layers its run time is the L2 traffic of the weights);
 //   * staging is LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, so a wave needs < 256 VGPRs and two waves
@@ -491,11 +492,13 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
 //     holds piece s ^ ((i >> 2) & 3), which makes the ds_read_b128 fragment reads of 32 consecutive rows conflict-free
 //     (lane groups of ds_read_b128: MI355X_MICROARCH.md, LDS); zero padding comes from the buffer range check.
 constexpr int DW = 8;                 // waves
-constexpr int DMA_MAXX = 7;           // halo items per thread: halo_px * 4 <= 512 * 7
-template <int NTAPS, int NB>
+constexpr int DMA_MAXX = 9;           // halo items per thread: halo_px * 4 <= 512 * 9 (stride-2 gathers: 17 x 65 pixels)
+// MA = 32-pixel blocks per wave (tile = 256 * MA pixels): 2 for stride-1 gathers, 1 for stride-2 gathers, whose halo patch
+// is four times larger per pixel.
+template <int NTAPS, int NB, int MA>
 __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs p, unsigned src0_bytes, unsigned src1_bytes,
                                                                  unsigned w_bytes) {
-    constexpr int MA = 2, BN = 32 * NB, CK = 32;
+    constexpr int BN = 32 * NB, CK = 32;
     constexpr int WROWS = NTAPS * BN, WROUNDS = (WROWS + 127) / 128;     // 128 weight rows of 64 B per staging round
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs
         const int hp = (tid >> 2) + 128 * j;
         const int im = hp / hpi, rem = hp - im * hpi;
         const int hy = rem / p.HW, hx = rem - hy * p.HW;
-        const int n = img0 + im, sy = py0 + p.dymin + hy, sx = px0 + p.dxmin + hx;
+        const int n = img0 + im, sy = py0 * p.IS + p.dymin + hy, sx = px0 * p.IS + p.dxmin + hx;
         const bool ok = hp < p.imgs * hpi && n < p.N && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;
         xoff[j] = ok ? (unsigned)((n * p.SH + sy) * p.SW + sx) : 0xffffffffu;
         xpiece[j] = slot ^ ((hp >> 2) & 3);
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs
     for (int a = 0; a < MA; ++a) {
         const int m = wave * 32 * MA + a * 32 + r;
         ptx[a] = m & (TW - 1); pty[a] = (m >> p.twl) & (TH - 1); pim[a] = m >> (p.twl + p.thl);
-        hpA[a] = pim[a] < p.imgs ? pim[a] * hpi + pty[a] * p.HW + ptx[a] : 0;
+        hpA[a] = pim[a] < p.imgs ? pim[a] * hpi + pty[a] * p.IS * p.HW + ptx[a] * p.IS : 0;
     }
     const int wsw = (r >> 2) & 3;     // swizzle of weight row (b * 32 + r): ((b * 32 + r) >> 2) & 3
 
@@ -747,16 +750,19 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
         const size_t b0 = (size_t)d->N * d->SH * d->SW * d->C0 * 2, b1 = (size_t)d->N * d->SH * d->SW * d->C1 * 2;
         const size_t bw = (size_t)9 * d->CO * CI * 2, lim = 0x7fff0000ull;
         const long px_all = (long)d->N * d->PH * d->PW;
+        const int dbm = d->IS == 1 ? 512 : 256;                        // loop pixels per tile
         int dnb = d->CO % 128 == 0 || d->CO > 256 ? 4 : 2;             // 128-column tiles unless that wastes half a tile
-        if (dnb == 4 && (px_all / 512) * cdiv(d->CO, 128) < 256)
+        if (dnb == 4 && (px_all / dbm) * cdiv(d->CO, 128) < 256)
             dnb = 2;                                                     // ... or leaves CUs without a workgroup
-        if (bf && plain0 && d->IS == 1 && d->ntaps == 9 && !d->out_nchw_f32 && d->CO >= 128 && CI >= 128 && d->C0 % 32 == 0 &&
+        if (d->IS == 2) dnb = 4;
+        if (bf && plain0 && (d->IS == 1 || (d->IS == 2 && d->CO % 128 == 0)) && d->ntaps == 9 &&
+            !d->out_nchw_f32 && d->CO >= 128 && CI >= (d->IS == 1 ? 128 : 64) && d->C0 % 32 == 0 &&
             d->D0 % 32 == 0 && d->CO % 16 == 0 && !d->par_co && b0 < lim && b1 < lim && bw < lim &&
-            (px_all / 512) * cdiv(d->CO, 32 * dnb) >= 128 && !getenv("CU_CONV_NODMA")) {
+            (px_all / dbm) * cdiv(d->CO, 32 * dnb) >= 128 && !getenv("CU_CONV_NODMA")) {
             int tw = d->PW < 32 ? d->PW : 32;
-            int th = 512 / tw;
+            int th = dbm / tw;
             if (th > d->PH) th = d->PH;
-            int imgs = 512 / (tw * th);
+            int imgs = dbm / (tw * th);
             a.twl = ilog2_exact(tw); a.thl = ilog2_exact(th); a.iml = ilog2_exact(imgs);
             int dymin = 1 << 20, dxmin = 1 << 20, dymax = -(1 << 20), dxmax = -(1 << 20);
             for (int t = 0; t < 9; ++t) {
@@ -764,7 +770,7 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
                 dxmin = d->tap_dx[t] < dxmin ? d->tap_dx[t] : dxmin; dxmax = d->tap_dx[t] > dxmax ? d->tap_dx[t] : dxmax;
             }
             a.dymin = dymin; a.dxmin = dxmin;
-            a.HH = (th - 1) + (dymax - dymin) + 1; a.HW = (tw - 1) + (dxmax - dxmin) + 1;
+            a.HH = (th - 1) * d->IS + (dymax - dymin) + 1; a.HW = (tw - 1) * d->IS + (dxmax - dxmin) + 1;
             const int halo = imgs * a.HH * a.HW;
             const int halo_pad = cdiv(halo, 128) * 128;          // whole 8-KiB staging rounds (128 rows of 64 B)
             const size_t lds = (size_t)halo_pad * 64 + (size_t)cdiv(9 * 32 * dnb, 128) * 8192;
@@ -779,7 +785,8 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
                     a.tap_w[t] = d->tap_w[t];
                     CU_CHECK_ARG(d->tap_w[t] >= 0, "cu_conv_gemm: negative weight tap index");
                 }
-                auto k = dnb == 4 ? igemm_conv_dma_kernel<9, 4> : igemm_conv_dma_kernel<9, 2>;
+                auto k = d->IS == 2 ? igemm_conv_dma_kernel<9, 4, 1>
+                                    : (dnb == 4 ? igemm_conv_dma_kernel<9, 4, 2> : igemm_conv_dma_kernel<9, 2, 2>);
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 CU_CHECK_ARG(e == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));

@@ -438,3 +438,36 @@ def test_weight_prep_batch_matches_per_layer(dtype):
     for (w, kind, cop), (wf, wd) in zip(layers, outs):
         rf, rd = ops.weight_prep(w, kind, dtype, cop)
         assert torch.equal(wf, rf) and torch.equal(wd, rd)
+
+
+@pytest.mark.parametrize("case", [(64, 64, 128, 64), (40, 128, 256, 32), (64, 256, 512, 16)])
+def test_conv_wide_dma_kernel_stride2(case):
+    """stride-2 3x3 forward on the 8-wave LDS-DMA kernel (256-pixel tiles, 17 x 65 halo) vs the register-staged kernel
+    (same summation order) and F.conv2d."""
+    import os
+    ops = _ops()
+    from cu_hip.engine import TAPS3
+    n, ci, co, size = case
+    dtype = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(n, ci, size, size, device=DEV, generator=g)
+    a, r = make_act(x, dtype, False, 1.0, g)
+    w = torch.randn(co, ci, 3, 3, device=DEV, generator=g) / math.sqrt(9 * ci)
+    b = torch.randn(co, device=DEV, generator=g) * 0.1
+    wf, _ = ops.weight_prep(w, "conv", dtype)
+    os_ = size // 2
+
+    def run():
+        z = torch.empty(n, os_, os_, co, device=DEV, dtype=dtype)
+        ops.conv_gemm([a], wf, b, grid=(os_, os_), in_stride=2, taps=TAPS3, dsts=[z], dst_cols=[co])
+        return z
+
+    out = run()
+    os.environ["CU_CONV_NODMA"] = "1"
+    try:
+        old = run()
+    finally:
+        del os.environ["CU_CONV_NODMA"]
+    assert torch.equal(out, old)
+    ref = F.conv2d(r, rq(w, dtype), b, stride=2, padding=1)
+    assert rel_err(nchw(out), ref) < tol(dtype)

@@ -151,7 +151,7 @@ def main():
         out = step(i)
     fence()
     dt = time.perf_counter() - t0
-    loss = float(out["loss"])
+    loss = float(out["loss"].detach())
     if world > 1:
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -163,8 +163,7 @@ def main():
         value = args.batch * world * args.steps / dt
         flops_step_img, _ = conv_flops_per_image(n_stages, args.size)
         result = {
-            "metric": "train images/sec, dsnt-skew 256x256 bf16" if (args.task == "dsnt-skew" and args.size == 256)
-            else f"train images/sec, {args.task} {args.size}x{args.size} {args.dtype}",
+            "metric": f"train images/sec, {args.task} {args.size}x{args.size} {args.dtype}",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",

@@ -219,7 +219,9 @@ def main():
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         print("[bench] timing the CPU oracle baseline ...", file=sys.stderr, flush=True)
-        result["cpu_baseline"] = cpu_baseline(args.size, n_stages, task_name, 4 if args.size >= 256 else 8, 2)
+        # bounded sample of the same workload: ~15 s of host work (24 steps of batch 4 at 256x256)
+        result["cpu_baseline"] = cpu_baseline(args.size, n_stages, task_name, 4 if args.size >= 256 else 8,
+                                              24 if args.size >= 256 else 60)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -336,3 +336,42 @@ def test_mc_dropout_and_ensemble_predict(tmp_path):
         assert torch.allclose(cov[:, i], singles[i][1][:, 0], rtol=1e-4, atol=1e-3)
     ens_dir = make_task("dsnt-al", 6, 64, "f32", ensemble_ckpt=str(tmp_path))
     assert len(ens_dir.model) == 2
+
+
+@pytest.mark.parametrize("kind,seq", [("dsnt-al", False), ("dsnt-al", True), ("dsnt-skew", False), ("dsnt-skew", True)])
+def test_predict_step_sampling_fanout(golden_dir, kind, seq):
+    """predict() -> sample() -> _predict_step / predict_step on the batched GPU samplers (Gaussian,
+    skew-normal, and the ED/ES sequence variants: the batch is then one pair).  Mask rasterisation is host code of the
+    datamodule (8f): a stub stands in."""
+    from contour_uncertainty._compat import ContourTags, Tags
+    n, size, k, t_a = 2, 64, 21, 6
+    img, contour = synthetic_batch(n, size, k, seed=3)
+    torch.manual_seed(1)
+    t = make_task(kind, 6, size, "f32", sequence_sampler=seq).to(DEV).eval()
+    t.hparams.psm_path = str(golden_dir / "camus-cont_psm_11_no_std.npz")
+    t.hparams.seq_psm_path = str(golden_dir / "camus-cont_sequence_psm_11_no_std.npz")
+    t.hparams.t_a = t_a
+
+    def to_mask(c, shape, labels, apply_argmax=True):
+        m = np.zeros((1,) + tuple(shape), dtype=np.float32)
+        ij = np.clip(np.round(c).astype(int), 0, shape[0] - 1)
+        m[0, ij[:, 1], ij[:, 0]] = 1.0
+        return m
+
+    t.contour_to_mask_fn = to_mask
+    t.umap_fn = lambda mu, cov, labels: np.zeros((size, size), dtype=np.float32)
+    t.skew_umap_fn = lambda mu, cov, alpha, labels: (mu, np.zeros((size, size), dtype=np.float32))
+    batch = {Tags.img: img.to(DEV), ContourTags.contour: contour.to(DEV), Tags.id: ["a", "b"]}
+    out = t.predict(img.to(DEV))
+    mu, cov = out[0], out[1]
+    assert mu.shape == (n, 1, k, 2) and cov.shape == (n, 1, k, 2, 2)
+    samples = t.sample(*out, t_a) if kind == "dsnt-al" else t.sample(out[0], out[1], out[2], t_a)
+    assert samples.shape == (n, 1, t_a, k, 2) and np.isfinite(samples).all()
+    # samples scatter around the predicted means (random-init network: wide distributions, so a loose bound)
+    assert np.abs(samples.mean(axis=2) - mu.numpy()).max() < size
+    res = t.predict_step(batch, 0)
+    cs = res.contour_samples
+    assert cs.shape[0] == n and cs.shape[-2:] == (k, 2) and np.isfinite(cs).all()
+    assert res.mu.shape == (n, k, 2) and res.cov.shape == (n, k, 2, 2)
+    assert res.post_mu.shape[-2:] == (k, 2) and np.isfinite(res.post_cov).all()
+    assert set(res.point_uncertainty) >= {"cov_xx", "cov_yy", "cov_det", "cov_eigval_sum"}

@@ -337,7 +337,18 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     const int nblk = blk / CBLK, cblk = blk % CBLK;
     const int TW = 1 << p.twl, TH = 1 << p.thl;
     const int CI = p.C0 + p.C1;
-    const int ct = blockIdx.x % p.ctiles, nt = blockIdx.x / p.ctiles;
+    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Workgroups of the
+    // same pixel split read the same S / Z tiles, so when the split count allows it all (n, c) tiles of a split are put
+    // on one XCD: hardware id h -> xcd = h % 8, slot = h / 8; that XCD owns splits xcd, xcd + 8, ...
+    int bxi = blockIdx.x, byi = blockIdx.y;
+    if ((p.splits & 7) == 0 && !(p.dbg & 64)) {
+        const int gx = gridDim.x;
+        const int hid = blockIdx.x + gx * blockIdx.y;
+        const int xcd = hid & 7, slot = hid >> 3;
+        bxi = slot % gx;
+        byi = xcd + 8 * (slot / gx);
+    }
+    const int ct = bxi % p.ctiles, nt = bxi / p.ctiles;
     const int c_base = ct * TC, n_base = nt * TN;
     const int s_hpi = p.SHH * p.SHW, z_hpi = p.ZHH * p.ZHW;
     const bool wave_active = (n_base + nblk * 32 < p.CO) && (c_base + cblk * 32 < CI);
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
         if (p.dbg & 16) t_loop += wall_clock64();
     };
 
-    int tile = blockIdx.y;
+    int tile = byi;
     const long long k0 = (p.dbg & 16) ? wall_clock64() : 0;
     if (tile < p.ntiles) {
         tile_geo(tile);
@@ -502,9 +513,9 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
         run_tile(tile, imgA, imgB);
         if (tile + p.splits < p.ntiles) run_tile(tile + p.splits, imgB, imgA);
     }
-    if ((p.dbg & 16) && blockIdx.x == 0 && blockIdx.y == 0 && (tid & 63) == 0)
+    if ((p.dbg & 16) && bxi == 0 && byi == 0 && (tid & 63) == 0)
         printf("[wgrad wave %d] 100MHz ticks: first issue %lld, wait %lld, barrier %lld, issue %lld, k-loop %lld, total %lld (tiles %d)\n",
-               wave, k1 - k0, t_wait, t_bar, t_issue, t_loop, wall_clock64() - k0, (p.ntiles - (int)blockIdx.y + p.splits - 1) / p.splits);
+               wave, k1 - k0, t_wait, t_bar, t_issue, t_loop, wall_clock64() - k0, (p.ntiles - byi + p.splits - 1) / p.splits);
 
     // ---- combine the k-split partial sums of one block through LDS (tree over kpart), then one set of atomics
     if constexpr (KSPLIT > 1) {

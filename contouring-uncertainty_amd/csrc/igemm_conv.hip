@@ -292,17 +292,24 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
         if constexpr (!WRES) store_w(wreg, 0);
     };
 
-    int tile = blockIdx.x;
-    if (tile < ntiles) {
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (own L2 each), so logical tile L -> tile
+    // (L % 8) * ntiles/8 + L / 8: the workgroups running on one XCD at a time walk one contiguous eighth of the tiles and
+    // the halo rows shared by vertically adjacent tiles are L2 hits instead of second HBM reads.
+    const bool xcd_order = (ntiles & 7) == 0 && (gridDim.x & 7) == 0 && !(p.dbg & 64);
+    auto tile_of = [&](int l) { return xcd_order ? (l & 7) * (ntiles >> 3) + (l >> 3) : l; };
+    int ltile = blockIdx.x;
+    int tile = tile_of(ltile);
+    if (ltile < ntiles) {
         tile_geometry(tile);
         prefetch(0);
     }
-    while (tile < ntiles) {
+    while (ltile < ntiles) {
         // origin of the tile being computed (the staging state may move on to the next tile before the epilogue)
         const int cur_tile_x = tile & ((1 << txl) - 1), cur_tile_y = (tile >> txl) & ((1 << tyl) - 1);
         const int cur_img0 = (tile >> (txl + tyl)) << p.iml;
         const int py0 = cur_tile_y << p.thl, px0 = cur_tile_x << p.twl;
-        const int next = tile + gridDim.x;
+        const int lnext = ltile + gridDim.x;
+        const int next = tile_of(lnext);
 
         f32x16 acc[MA][NB];
 #pragma unroll
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
             if (!(p.dbg & 8)) {
             if (c0 + CK < CI) {
                 prefetch(c0 + CK);
-            } else if (next < ntiles) {   // cross-tile prefetch: the next tile's first chunk flies under these MFMAs
+            } else if (lnext < ntiles) {  // cross-tile prefetch: the next tile's first chunk flies under these MFMAs
                 tile_geometry(next);
                 prefetch(0);
             }
@@ -478,6 +485,7 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
             }
         }
         tile = next;
+        ltile = lnext;
     }
 }
 

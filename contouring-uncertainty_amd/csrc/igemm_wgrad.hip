@@ -370,8 +370,12 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     // staging of one tile = s_iters + z_iters wave-level DMA instructions per wave, issued back to back right after the
     // barrier (measured: spreading them over the k-steps stalls the MFMA pipeline far more than it hides, 157 -> 191 us)
     int g_img0 = 0, g_sy0 = 0, g_sx0 = 0, g_zy0 = 0, g_zx0 = 0;
-    auto tile_geo = [&](int tile) {
-        int bx = tile;
+    // logical tile L -> tile (L % 8) * ntiles/8 + L / 8: the workgroups of one XCD walk a contiguous eighth of the pixel
+    // tiles at a time, so the halo rows shared by neighbouring tiles are L2 hits (thin layers: splits = 256 workgroups
+    // with consecutive logical tiles)
+    const bool xcd_tiles = (p.ntiles & 7) == 0 && !(p.dbg & 64);
+    auto tile_geo = [&](int ltile) {
+        int bx = xcd_tiles ? (ltile & 7) * (p.ntiles >> 3) + (ltile >> 3) : ltile;
         const int tile_x = bx % p.tiles_x; bx /= p.tiles_x;
         const int tile_y = bx % p.tiles_y;
         const int ig = bx / p.tiles_y;

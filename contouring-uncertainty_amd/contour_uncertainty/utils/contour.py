@@ -1,10 +1,34 @@
-"""Contour -> mask rasterisation used by the validation Dice (reference utils/contour.py:43-53 ``linear_reconstruction``:
-``skimage.draw.line`` between consecutive rounded points incl. the closing edge, clip, ``binary_fill_holes``).
-skimage is not required: lines are drawn with an integer Bresenham walk that visits the same pixels."""
+"""Contour -> mask rasterisation (reference contour_uncertainty/utils/contour.py).
+
+``reconstruction`` / ``reconstruction_batch`` (reference utils/contour.py:28-40: interpolating cubic spline at 1000
+parameters, round, upper clip, closing line, ``binary_fill_holes``) run on the GPU: one workgroup per contour in
+``cu_contour_masks`` (csrc/masks.hip), so the thousands of MC-sampled contours of a predict step become masks without
+leaving the device.  ``linear_reconstruction`` (reference utils/contour.py:43-53, used by the validation Dice) is host
+NumPy: ``skimage.draw.line`` between consecutive rounded points incl. the closing edge, clip, ``binary_fill_holes``;
+skimage is not required, lines are drawn with an integer Bresenham walk that visits the same pixels."""
 from __future__ import annotations
 
 import numpy as np
+import torch
 from scipy.ndimage import binary_fill_holes
+
+
+def reconstruction_batch(contours, height: int, width: int, round_landmarks: bool = False, packed: bool = False):
+    """contours (M, K, 2) as (x, y) pixels, tensor or array -> uint8 cuda tensor (M, H, W) of 0/1
+    (and, with ``packed``, the (M, H, 8) int32 bit-packed masks that ``cu_mask_entropy`` reduces)."""
+    from cu_hip import ops
+    c = torch.as_tensor(contours, dtype=torch.float32)
+    if c.ndim != 3 or c.shape[-1] != 2:
+        raise ValueError(f"contours must be (M, K, 2), got {tuple(c.shape)}")
+    if not c.is_cuda:
+        c = c.cuda()
+    pk, masks = ops.contour_masks(c, int(height), int(width), round_landmarks=round_landmarks, packed=packed)
+    return (masks, pk) if packed else masks
+
+
+def reconstruction(points: np.ndarray, height: int, width: int) -> np.ndarray:
+    """reference utils/contour.py:28-40 for one contour (K, 2); returns an int array (H, W) like the reference."""
+    return reconstruction_batch(np.asarray(points)[None], height, width)[0].cpu().numpy().astype(int)
 
 
 def _line(r0: int, c0: int, r1: int, c1: int):
@@ -47,6 +71,6 @@ def linear_reconstruction(contour: np.ndarray, shape) -> np.ndarray:
 
 def contour_to_mask(contour: np.ndarray, shape, labels=None, apply_argmax: bool = True,
                     reconstruction_type: str = "linear") -> np.ndarray:
-    """Single-structure (LV endocardium) stand-in for the datamodule's ``contour_to_mask_fn``."""
+    """Host-only single-structure converter (linear reconstruction), kept for callers without a datamodule."""
     m = linear_reconstruction(contour, shape)
     return m.astype(np.int64) if apply_argmax else m.astype(np.float32)[None]

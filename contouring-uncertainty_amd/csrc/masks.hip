@@ -1,0 +1,355 @@
+// Sampled contour -> filled mask -> entropy map, one workgroup per contour.
+//
+// Replaces, for batches of contours that are already on the GPU (the MC samplers' output):
+//   contour_spline / reconstruction   reference contour_uncertainty/utils/contour.py:9-40
+//       scipy splprep(k=3, s=0) + splev at 1000 parameters -> round -> set pixels (upper clip only: negative indices wrap
+//       like numpy's), closing skimage.draw.line from the last to the first landmark, scipy.ndimage.binary_fill_holes;
+//   USContourToMask (LV-only branch)  reference contour_uncertainty/data/camus/utils.py:31-45   (landmarks rounded first);
+//   UncertaintyTask.sample_entropy    reference contour_uncertainty/task/uncertainty.py:107-133 (cu_mask_entropy).
+// The interpolating spline is FITPACK's (parcur, s = 0): chord-length parameters, knots u[0] x4, u[2..m-3], u[m-1] x4,
+// collocation solve (banded, f64), de Boor evaluation in f64.  Duplicate consecutive landmarks make scipy raise and the
+// reference fall back to the raw landmarks; so does this kernel.  binary_fill_holes = the complement of a 4-connected
+// flood fill of the background from outside the image: bit-parallel here (a row of <= 256 pixels is four 64-bit words,
+// a whole run is filled by one carry chain), alternating row fills with column fills on the transposed bitmap until
+// nothing changes.
+#include "common.h"
+
+namespace {
+
+constexpr int MT = 256;          // threads = max rows = max columns
+constexpr int MAXK = 32;
+typedef unsigned long long u64;
+
+struct Row { u64 w[4]; };
+
+__device__ __forceinline__ Row row_and(const Row& a, const Row& b) { return Row{{a.w[0] & b.w[0], a.w[1] & b.w[1], a.w[2] & b.w[2], a.w[3] & b.w[3]}}; }
+__device__ __forceinline__ Row row_or(const Row& a, const Row& b) { return Row{{a.w[0] | b.w[0], a.w[1] | b.w[1], a.w[2] | b.w[2], a.w[3] | b.w[3]}}; }
+__device__ __forceinline__ bool row_ne(const Row& a, const Row& b) { return ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3])) != 0; }
+
+// seeds r (subset of m) spread towards higher bit positions through the runs of m: one carry chain
+__device__ __forceinline__ Row fill_up(const Row& r, const Row& m) {
+    Row o;
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u64 s1 = m.w[i] + r.w[i];
+        const u64 c1 = s1 < m.w[i] ? 1ull : 0ull;
+        const u64 s2 = s1 + carry;
+        const u64 c2 = s2 < s1 ? 1ull : 0ull;
+        o.w[i] = ((s2 ^ m.w[i]) & m.w[i]) | r.w[i];
+        carry = c1 | c2;
+    }
+    return o;
+}
+__device__ __forceinline__ Row row_rev(const Row& a) {
+    return Row{{__brevll(a.w[3]), __brevll(a.w[2]), __brevll(a.w[1]), __brevll(a.w[0])}};
+}
+__device__ __forceinline__ Row fill_both(const Row& r, const Row& m) {
+    const Row up = fill_up(r, m);
+    const Row dn = row_rev(fill_up(row_rev(up), row_rev(m)));
+    return row_or(up, dn);
+}
+
+// thread c gathers column c of a bitmap stored as rows of 8 x u32 in LDS (bit x of row y = pixel (y, x)); rows >= nrows
+// must hold zeros or be masked by the caller
+__device__ __forceinline__ Row gather_column(const unsigned* bm, int c) {
+    Row o;
+    const unsigned* src = bm + (c >> 5);
+    const unsigned sh = c & 31;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int y = 0; y < 32; ++y) {
+            lo |= __builtin_amdgcn_ubfe(src[(64 * q + y) * 8], sh, 1u) << y;
+            hi |= __builtin_amdgcn_ubfe(src[(64 * q + 32 + y) * 8], sh, 1u) << y;
+        }
+        o.w[q] = (u64)lo | ((u64)hi << 32);
+    }
+    return o;
+}
+__device__ __forceinline__ double bcast(double v, int lane) {      // lane is wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ void store_row(unsigned* bm, int y, const Row& r) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bm[y * 8 + 2 * i] = (unsigned)r.w[i];
+        bm[y * 8 + 2 * i + 1] = (unsigned)(r.w[i] >> 32);
+    }
+}
+__device__ __forceinline__ Row load_row(const unsigned* bm, int y) {
+    Row r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.w[i] = (u64)bm[y * 8 + 2 * i] | ((u64)bm[y * 8 + 2 * i + 1] << 32);
+    return r;
+}
+__device__ __forceinline__ Row low_bits(int n) {      // bits [0, n)
+    Row r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = n - 64 * i;
+        r.w[i] = k >= 64 ? ~0ull : (k <= 0 ? 0ull : ((1ull << k) - 1ull));
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, const float* __restrict__ contours,
+                                                          int round_landmarks, unsigned* __restrict__ packed,
+                                                          unsigned char* __restrict__ bytes, int dbg) {
+    __shared__ unsigned bmA[MT * 8];        // the drawn curve, then the reached background (rows)
+    __shared__ unsigned bmB[MT * 8];        // transposed bitmaps
+    __shared__ double px[MAXK], py[MAXK], u[MAXK], t[MAXK + 4], cx[MAXK], cy[MAXK];
+    __shared__ int fallback;
+    const int tid = threadIdx.x;
+    const size_t m = blockIdx.x;
+    const float* pts = contours + m * K * 2;
+    for (int i = tid; i < MT * 8; i += MT) bmA[i] = 0u;
+    if (tid < K) {
+        float x = pts[2 * tid], y = pts[2 * tid + 1];
+        if (round_landmarks) { x = rintf(x); y = rintf(y); }      // numpy round: half to even
+        px[tid] = x; py[tid] = y;
+    }
+    __syncthreads();
+
+    // ---- FITPACK interpolation set-up by wave 0, lane i = landmark i (K <= 32)
+    if (tid < 64) {
+        const int i = tid;
+        double d = 1.0;
+        if (i >= 1 && i < K) d = sqrt((px[i] - px[i - 1]) * (px[i] - px[i - 1]) + (py[i] - py[i - 1]) * (py[i] - py[i - 1]));
+        const int bad = (K < 4 || __ballot(!(d > 0.0)) != 0) ? 1 : 0;
+        double tot = 0.0, ui = 0.0;
+        for (int j = 1; j < K; ++j) {          // sequential sum, like FITPACK's running u[i] = u[i-1] + dist
+            tot += bcast(d, j);
+            if (i == j) ui = tot;
+        }
+        ui = i == K - 1 ? 1.0 : ui / tot;
+        if (i == 0) fallback = bad | (dbg & 1);
+        if (!bad) {
+            if (i < K) u[i] = ui;
+            if (i < 4) { t[i] = 0.0; t[K + i] = 1.0; }
+            if (i >= 2 && i <= K - 3) t[i + 2] = ui;
+        }
+    }
+    __syncthreads();
+    // non-zero cubic B-splines at x: span l (t[l] <= x < t[l+1], clamped to [3, K-1]), values N[0..3] of B_{l-3..l}
+    auto basis = [&](double x, double (&N)[4]) -> int {
+        int l = 3;
+        while (l < K - 1 && x >= t[l + 1]) ++l;
+        N[0] = 1.0; N[1] = N[2] = N[3] = 0.0;
+#pragma unroll
+        for (int deg = 1; deg < 4; ++deg) {
+            double saved = 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                if (r < deg) {
+                    const double tr = t[l + r + 1], tl = t[l + 1 - deg + r];
+                    const double term = N[r] / (tr - tl);
+                    N[r] = saved + (tr - x) * term;
+                    saved = (x - tl) * term;
+                }
+            }
+            N[deg] = saved;
+        }
+        return l - 3;
+    };
+    // collocation solve in wave 0: lane i holds row i of the band, B[d] = A(i, i - 3 + d).  Gaussian elimination without
+    // pivoting (the collocation matrix of an interpolating spline is totally positive); the pivot row travels by readlane.
+    if (tid < 64 && !fallback) {
+        const int i = tid;
+        double B[7] = {0, 0, 0, 0, 0, 0, 0}, rx = 0.0, ry = 0.0;
+        if (i < K) {
+            double N[4];
+            const int j = basis(u[i], N);
+#pragma unroll
+            for (int dd = 0; dd < 7; ++dd) {
+                const int e = dd + i - 3 - j;
+                B[dd] = e == 0 ? N[0] : e == 1 ? N[1] : e == 2 ? N[2] : e == 3 ? N[3] : 0.0;
+            }
+            rx = px[i]; ry = py[i];
+        } else B[3] = 1.0;
+        for (int c = 0; c < K - 1; ++c) {
+            const double p3 = bcast(B[3], c), p4 = bcast(B[4], c), p5 = bcast(B[5], c), p6 = bcast(B[6], c);
+            const double qx = bcast(rx, c), qy = bcast(ry, c);
+            const int k = i - c;
+            if (i < K) {
+                if (k == 1) { const double f = B[2] / p3; B[3] -= f * p4; B[4] -= f * p5; B[5] -= f * p6; rx -= f * qx; ry -= f * qy; }
+                else if (k == 2) { const double f = B[1] / p3; B[2] -= f * p4; B[3] -= f * p5; B[4] -= f * p6; rx -= f * qx; ry -= f * qy; }
+                else if (k == 3) { const double f = B[0] / p3; B[1] -= f * p4; B[2] -= f * p5; B[3] -= f * p6; rx -= f * qx; ry -= f * qy; }
+            }
+        }
+        double x1 = 0, x2 = 0, x3 = 0, y1 = 0, y2 = 0, y3 = 0, solx = 0, soly = 0;
+        for (int c = K - 1; c >= 0; --c) {
+            const double vx = (rx - B[4] * x1 - B[5] * x2 - B[6] * x3) / B[3];
+            const double vy = (ry - B[4] * y1 - B[5] * y2 - B[6] * y3) / B[3];
+            if (i == c) { solx = vx; soly = vy; }
+            x3 = x2; x2 = x1; x1 = bcast(vx, c);
+            y3 = y2; y2 = y1; y1 = bcast(vy, c);
+        }
+        if (i < K) { cx[i] = solx; cy[i] = soly; }
+    }
+    __syncthreads();
+
+    // ---- draw: 1000 spline points (or the raw landmarks), upper clip, negative indices wrap once like numpy
+    auto plot = [&](int ix, int iy, bool wrap) {
+        if (ix > W - 1) ix = W - 1;
+        if (iy > H - 1) iy = H - 1;
+        if (wrap) { if (ix < 0) ix += W; if (iy < 0) iy += H; }
+        else { if (ix < 0) ix = 0; if (iy < 0) iy = 0; }
+        if (ix >= 0 && iy >= 0) atomicOr(&bmA[iy * 8 + (ix >> 5)], 1u << (ix & 31));
+    };
+    if (!fallback) {
+        for (int q = tid; q < 1000; q += MT) {
+            const double x = (double)q * (1.0 / 999.0);      // np.linspace(0, 1, 1000)
+            double N[4];
+            const int j = basis(q == 999 ? 1.0 : x, N);
+            const double sx = N[0] * cx[j] + N[1] * cx[j + 1] + N[2] * cx[j + 2] + N[3] * cx[j + 3];
+            const double sy = N[0] * cy[j] + N[1] * cy[j + 1] + N[2] * cy[j + 2] + N[3] * cy[j + 3];
+            plot((int)rint(sx), (int)rint(sy), true);
+        }
+    } else if (tid < K) {
+        plot((int)rint(px[tid]), (int)rint(py[tid]), true);
+    }
+    {   // closing edge, skimage.draw.line(last, first) with clip(min=0, max): Bresenham in closed form, one step per thread
+        int r0 = (int)rint(py[K - 1]), c0 = (int)rint(px[K - 1]), r1 = (int)rint(py[0]), c1 = (int)rint(px[0]);
+        int dr = abs(r1 - r0), dc = abs(c1 - c0);
+        int sr = r1 >= r0 ? 1 : -1, sc = c1 >= c0 ? 1 : -1;
+        const bool steep = dr > dc;
+        if (steep) { int a; a = r0; r0 = c0; c0 = a; a = dr; dr = dc; dc = a; a = sr; sr = sc; sc = a; }
+        for (int i = tid; i <= dc; i += MT) {
+            const int n = dc > 0 ? (int)((2ll * dr * i + dc) / (2ll * dc)) : 0;     // minor-axis steps before major step i
+            const int r = r0 + sr * n, c = c0 + sc * i;
+            if (steep) plot(r, c, false); else plot(c, r, false);
+        }
+    }
+    __syncthreads();
+
+    // ---- binary_fill_holes: flood the background from outside the image (4-connectivity), bit-parallel
+    const Row wmask = low_bits(W), hmask = low_bits(H);
+    Row freeR{{0, 0, 0, 0}}, reach{{0, 0, 0, 0}};
+    if (tid < H) {
+        const Row curve = load_row(bmA, tid);
+        freeR = Row{{~curve.w[0] & wmask.w[0], ~curve.w[1] & wmask.w[1], ~curve.w[2] & wmask.w[2], ~curve.w[3] & wmask.w[3]}};
+        if (tid == 0 || tid == H - 1) reach = freeR;
+        else {
+            const Row lo = low_bits(W - 1);
+            Row edge{{(wmask.w[0] ^ lo.w[0]) | 1ull, wmask.w[1] ^ lo.w[1], wmask.w[2] ^ lo.w[2], wmask.w[3] ^ lo.w[3]}};
+            reach = row_and(freeR, edge);
+        }
+        store_row(bmA, tid, freeR);
+    }
+    __syncthreads();
+    Row freeC{{0, 0, 0, 0}};
+    if (tid < W) freeC = row_and(gather_column(bmA, tid), hmask);
+    __syncthreads();
+    // rows >= H of bmA and rows >= W of bmB stay zero from here on (threads >= H / >= W store empty rows)
+    for (int iter = 0; iter < ((dbg & 2) ? 0 : 64); ++iter) {
+        const Row before = reach;
+        reach = fill_both(reach, freeR);
+        // the column pass leaves the map closed under vertical moves: a row pass that adds nothing means convergence
+        const int grew = __syncthreads_or(row_ne(before, reach) ? 1 : 0);
+        if (iter > 0 && !grew) break;
+        store_row(bmA, tid, reach);
+        __syncthreads();
+        Row col = fill_both(row_and(gather_column(bmA, tid), freeC), freeC);
+        store_row(bmB, tid, col);
+        __syncthreads();
+        reach = row_and(gather_column(bmB, tid), freeR);
+    }
+    // ---- mask = everything the flood did not reach
+    if (tid < H) {
+        const Row mk{{~reach.w[0] & wmask.w[0], ~reach.w[1] & wmask.w[1], ~reach.w[2] & wmask.w[2], ~reach.w[3] & wmask.w[3]}};
+        store_row(bmA, tid, mk);
+        if (packed) {
+            unsigned* o = packed + (m * H + tid) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = bmA[tid * 8 + i];
+        }
+    }
+    if (bytes) {
+        __syncthreads();
+        unsigned char* o = bytes + m * (size_t)H * W;
+        if ((W & 15) == 0) {        // 16 pixels -> one 16-byte store
+            const int per_row = W >> 4;
+            for (int i = tid; i < H * per_row; i += MT) {
+                const int y = i / per_row, xg = i - y * per_row;
+                const unsigned half = (bmA[y * 8 + (xg >> 1)] >> ((xg & 1) * 16)) & 0xffffu;
+                unsigned v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned n = (half >> (4 * q)) & 0xfu;
+                    v[q] = (n & 1u) | ((n & 2u) << 7) | ((n & 4u) << 14) | ((n & 8u) << 21);
+                }
+                *reinterpret_cast<uint4*>(o + (size_t)y * W + xg * 16) = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+        } else {
+            for (int i = tid; i < H * W; i += MT) {
+                const int y = i / W, x = i - y * W;
+                o[i] = (bmA[y * 8 + (x >> 5)] >> (x & 31)) & 1u;
+            }
+        }
+    }
+}
+
+// mean over S samples of the packed masks of every frame and its binary entropy (base 2; 0 where the mean is 0 or 1).
+// A workgroup owns 32 consecutive words (4 rows) of one frame; thread = (word, one of 8 slices of the samples) keeps the
+// 32 pixel counters of its word in registers; the slices are combined through LDS.
+constexpr int ENT_SL = 8;
+__global__ __launch_bounds__(256) void mask_entropy_kernel(int F, int S, int H, int W, const unsigned* __restrict__ packed,
+                                                           float* __restrict__ mean, float* __restrict__ entropy) {
+    __shared__ int part[ENT_SL][32][33];
+    const int tid = threadIdx.x, wl = tid & 31, sl = tid >> 5;
+    const int groups = (H * 8 + 31) / 32;
+    const int f = blockIdx.x / groups, g = blockIdx.x - f * groups;
+    const int word = g * 32 + wl;                 // word index inside one mask, < H * 8
+    int cnt[32];
+#pragma unroll
+    for (int b = 0; b < 32; ++b) cnt[b] = 0;
+    if (word < H * 8) {
+        const unsigned* p = packed + (size_t)f * S * H * 8 + word;
+        const int per = (S + ENT_SL - 1) / ENT_SL;
+        const int s1 = min(S, (sl + 1) * per);
+        for (int s = sl * per; s < s1; ++s) {
+            const unsigned w = p[(size_t)s * H * 8];
+#pragma unroll
+            for (int b = 0; b < 32; ++b) cnt[b] += (int)__builtin_amdgcn_ubfe(w, (unsigned)b, 1u);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 32; ++b) part[sl][wl][b] = cnt[b];
+    __syncthreads();
+    for (int j = tid; j < 1024; j += 256) {
+        const int wj = j >> 5, b = j & 31;
+        const int wd = g * 32 + wj;
+        const int y = wd >> 3, x = (wd & 7) * 32 + b;
+        if (y >= H || x >= W) continue;
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < ENT_SL; ++q) c += part[q][wj][b];
+        const float pr = (float)c / (float)S;
+        const size_t o = ((size_t)f * H + y) * W + x;
+        if (mean) mean[o] = pr;
+        if (entropy) entropy[o] = (c == 0 || c == S) ? 0.f : -(pr * log2f(pr) + (1.f - pr) * log2f(1.f - pr));
+    }
+}
+
+}  // namespace
+
+extern "C" int cu_contour_masks(int M, int K, int H, int W, const float* contours, int round_landmarks, unsigned* packed,
+                                unsigned char* bytes, void* stream) {
+    CU_CHECK_ARG(M > 0 && K >= 2 && K <= MAXK && H > 0 && H <= MT && W > 0 && W <= MT, "cu_contour_masks: bad sizes M=%d K=%d H=%d W=%d", M, K, H, W);
+    CU_CHECK_ARG(contours && (packed || bytes), "cu_contour_masks: null pointer");
+    static const int dbg = getenv("CU_MASKS_DBG") ? atoi(getenv("CU_MASKS_DBG")) : 0;      // timing aid (tools/masks_bench.py)
+    hipLaunchKernelGGL(contour_mask_kernel, dim3(M), dim3(MT), 0, reinterpret_cast<hipStream_t>(stream), K, H, W, contours,
+                       round_landmarks, packed, bytes, dbg);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_mask_entropy(int F, int S, int H, int W, const unsigned* packed, float* mean, float* entropy, void* stream) {
+    CU_CHECK_ARG(F > 0 && S > 0 && H > 0 && H <= MT && W > 0 && W <= MT && packed && (mean || entropy), "cu_mask_entropy: bad argument");
+    hipLaunchKernelGGL(mask_entropy_kernel, dim3((unsigned)(F * ((H * 8 + 31) / 32))), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), F, S, H, W, packed, mean, entropy);
+    CU_LAUNCH_CHECK();
+    return 0;
+}

@@ -476,6 +476,33 @@ def psm_condition(rec: Tensor, table: Tensor, nt: int, known: Tensor, per_rec: i
     return mu_c, cov_c, mu_f, cov_f
 
 
+def contour_masks(contours: Tensor, height: int, width: int, round_landmarks: bool = False, packed: bool = True,
+                  as_bytes: bool = True):
+    """contours (M, K, 2) f32 (x, y) pixels -> (packed (M, H, 8) int32 | None, masks (M, H, W) uint8 | None)  (cu_contour_masks)."""
+    m, k, _ = contours.shape
+    contours = contours.contiguous().float()
+    dev = contours.device
+    pk = torch.empty((m, height, 8), dtype=torch.int32, device=dev) if packed else None
+    by = torch.empty((m, height, width), dtype=torch.uint8, device=dev) if as_bytes else None
+    with _Prof("masks"):
+        L.check(L.load().cu_contour_masks(m, k, height, width, L.ptr(contours), int(round_landmarks), L.ptr(pk), L.ptr(by),
+                                          L.stream_ptr()), "cu_contour_masks")
+    return pk, by
+
+
+def mask_entropy(packed: Tensor, frames: int, width: int, mean: bool = True, entropy: bool = True):
+    """packed (F*S, H, 8) int32, frame-major -> (mean (F, H, W) f32 | None, entropy (F, H, W) f32 | None)  (cu_mask_entropy)."""
+    ms, h, _ = packed.shape
+    assert ms % frames == 0
+    dev = packed.device
+    mo = torch.empty((frames, h, width), dtype=torch.float32, device=dev) if mean else None
+    eo = torch.empty((frames, h, width), dtype=torch.float32, device=dev) if entropy else None
+    with _Prof("masks"):
+        L.check(L.load().cu_mask_entropy(frames, ms // frames, h, width, L.ptr(packed), L.ptr(mo), L.ptr(eo),
+                                         L.stream_ptr()), "cu_mask_entropy")
+    return mo, eo
+
+
 def logpdf_grid(pts: Tensor, mu: Tensor, sigma3: Tensor, alpha: Optional[Tensor] = None, pairwise: bool = False) -> Tensor:
     """pts (P,2), mu (M,2), sigma3 (M,3), alpha (M,2)|None -> log density (M,P) or (P,) when pairwise."""
     m, p = mu.shape[0], pts.shape[0]

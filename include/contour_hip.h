@@ -240,6 +240,22 @@ int cu_logpdf_grid(int M, int P, int pairwise, const float* pts, const float* mu
 int cu_skew_rvs(int M, int S, const float* mu, const float* sigma, const float* alpha, const float* eps, uint64_t seed,
                 float* out, void* stream);
 
+/* ----------------------------------------------------------------------------------------------------------------
+ * Sampled contours -> filled masks -> entropy map (csrc/masks.hip).
+ * cu_contour_masks: `reconstruction` (reference contour_uncertainty/utils/contour.py:28-40: interpolating cubic spline at
+ *   1000 parameters, round, upper clip, closing line last -> first landmark, binary_fill_holes) of M contours
+ *   [M][K][2] (x, y) in pixels, K <= 32, H, W <= 256.  round_landmarks != 0 rounds the landmarks first, as
+ *   USContourToMask does (reference data/camus/utils.py:31-45).  Contours with duplicate consecutive landmarks or
+ *   K < 4 use the raw landmarks, like the reference's bare `except`.  Outputs (either may be NULL): packed
+ *   [M][H][8] uint32 (bit x%32 of word x/32 = pixel (y, x)), bytes [M][H][W] of 0/1.
+ * cu_mask_entropy: UncertaintyTask.sample_entropy (reference task/uncertainty.py:107-133) over the S packed masks of
+ *   each of F frames (packed [F][S][H][8]): mean [F][H][W] and/or its base-2 binary entropy [F][H][W] (0 where the
+ *   mean is 0 or 1).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int cu_contour_masks(int M, int K, int H, int W, const float* contours, int round_landmarks, uint32_t* packed,
+                     uint8_t* bytes, void* stream);
+int cu_mask_entropy(int F, int S, int H, int W, const uint32_t* packed, float* mean, float* entropy, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -375,3 +375,38 @@ def test_predict_step_sampling_fanout(golden_dir, kind, seq):
     assert res.mu.shape == (n, k, 2) and res.cov.shape == (n, k, 2, 2)
     assert res.post_mu.shape[-2:] == (k, 2) and np.isfinite(res.post_cov).all()
     assert set(res.point_uncertainty) >= {"cov_xx", "cov_yy", "cov_det", "cov_eigval_sum"}
+
+
+@pytest.mark.parametrize("kind", ["dsnt-al", "dsnt-skew"])
+def test_predict_step_device_masks_and_entropy(golden_dir, kind):
+    """with the CAMUS converter (the default) every sampled contour of the step is rasterised by
+    cu_contour_masks and the entropy map reduced by cu_mask_entropy; both must equal the reference's per-contour
+    USContourToMask + sample_entropy (oracle/masks.py) on the very contours the step sampled."""
+    from oracle import masks as MO
+    from contour_uncertainty._compat import ContourTags, Tags
+    from contour_uncertainty.data.camus.utils import USContourToMask
+    n, size, k, t_a = 2, 64, 21, 12
+    img, contour = synthetic_batch(n, size, k, seed=5)
+    torch.manual_seed(2)
+    t = make_task(kind, 6, size, "f32").to(DEV).eval()
+    t.hparams.psm_path = str(golden_dir / "camus-cont_psm_11_no_std.npz")
+    t.hparams.t_a = t_a
+    assert isinstance(t.contour_to_mask_fn, USContourToMask)
+    t.contour_to_mask_fn = staticmethod(USContourToMask())          # how on_predict_start binds the datamodule's
+    t.umap_fn = lambda mu, cov, labels: np.zeros((size, size), dtype=np.float32)
+    t.skew_umap_fn = lambda mu, cov, alpha, labels: (mu, np.zeros((size, size), dtype=np.float32))
+    res = t.predict_step({Tags.img: img.to(DEV), ContourTags.contour: contour.to(DEV), Tags.id: ["a", "b"]}, 0)
+    cs = res.contour_samples
+    t_a = 25 if kind == "dsnt-skew" else t_a          # hard-coded in the reference's skew predict step (aleatoric_skew.py:63)
+    assert res.pred_samples.shape == (n, 1, t_a, size, size) and res.entropy_map.shape == (n, size, size)
+    bad = 0
+    for i in range(n):
+        ref = np.stack([MO.us_contour_to_mask(cs[i, 0, j], (size, size)) for j in range(t_a)])
+        bad += int((ref != res.pred_samples[i, 0]).sum())
+        ent = MO.sample_entropy(res.pred_samples[i, 0][:, None].astype(float))
+        assert np.allclose(res.entropy_map[i], ent, atol=1e-5)
+    assert bad <= 2
+    assert res.pred.shape == (n, size, size)
+    # single-contour call keeps the reference signature and agrees with the batch
+    one = USContourToMask()(cs[0, 0, 0], (size, size), None, apply_argmax=False)
+    assert one.shape == (1, size, size) and (one[0] == res.pred_samples[0, 0, 0]).all()

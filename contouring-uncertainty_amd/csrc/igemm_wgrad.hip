@@ -32,6 +32,7 @@ struct WgKArgs {
     int zsame;                                 // all taps read the same Z pixel
     unsigned src0_bytes, src1_bytes, z_bytes;  // tensor sizes (LDS-DMA kernel: buffer resources, out-of-range = zero fill)
     int s_iters, z_iters;                      // LDS-DMA kernel: 4-KiB staging blocks per tile for S / Z
+    int pc_items;                              // producer/consumer kernel: staging rounds issued by the producer waves
     int dbg;                                   // CU_CONV_DBG bits (timing experiments): 1 no atomics, 2 no MFMA, 4 no commit, 8 no loads
 };
 
@@ -322,18 +323,26 @@ constexpr int DMA_IMG_BYTES = 78 * 1024;      // per image; two of them per work
 // NW = 8 waves: two waves per SIMD own the SAME 32x32 block and split the k-steps; while one is blocked issuing its
 // DMA instructions (the queue drains at L2 speed, ~4 us per tile) the other keeps the MFMA pipe busy.  The k-split
 // partial sums are combined through LDS before the atomics, so the atomic traffic does not grow with the wave count.
-template <int NBLK, int CBLK, int NTAPS, int NW>
+// PC (producer / consumer, NW = 8): waves 0..3 run the k-loop over the whole tile (software-pipelined, one per SIMD),
+// waves 4..7 only issue the LDS-DMA of the next tile into the other image.  The DMA queue drains at L2 speed and blocks
+// the wave that issues into it; in this split that wave has nothing else to do, and its SIMD keeps issuing the other
+// wave's MFMAs, so staging and k-loop overlap instead of adding up.
+template <int NBLK, int CBLK, int NTAPS, int NW, bool PC = false>
 __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs p) {
     constexpr int TN = 32 * NBLK, TC = 32 * CBLK;
-    constexpr int NWB = NBLK * CBLK, KSPLIT = NW / NWB;
-    constexpr int NTHR = 64 * NW, BLK_B = NTHR * 16;   // threads; bytes of one staging round
+    constexpr int NWC = PC ? NW / 2 : NW;              // waves that compute
+    constexpr int NWI = PC ? NW / 2 : NW;              // waves that issue DMA
+    constexpr int NWB = NBLK * CBLK, KSPLIT = NWC / NWB;
+    constexpr int NTHR = 64 * NWI, BLK_B = NTHR * 16;  // issuing threads; bytes of one staging round
     constexpr int ROW_B = 64;                          // one pixel of one 32-channel plane
     __shared__ __attribute__((aligned(16))) unsigned char img2[2 * DMA_IMG_BYTES];
     unsigned char* imgA = img2;
     unsigned char* imgB = img2 + DMA_IMG_BYTES;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int blk = wave % NWB, kpart = wave / NWB;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool producer = PC && wave >= NWC, issuer = !PC || producer;
+    const int tid = PC ? (threadIdx.x & (NTHR - 1)) : threadIdx.x;      // index among the issuing threads
+    const int iwave = tid >> 6;
+    const int blk = wave % NWB, kpart = producer ? 2 * KSPLIT : wave / NWB;
     const int nblk = blk / CBLK, cblk = blk % CBLK;
     const int TW = 1 << p.twl, TH = 1 << p.thl;
     const int CI = p.C0 + p.C1;
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     const int ct = bxi % p.ctiles, nt = bxi / p.ctiles;
     const int c_base = ct * TC, n_base = nt * TN;
     const int s_hpi = p.SHH * p.SHW, z_hpi = p.ZHH * p.ZHW;
-    const bool wave_active = (n_base + nblk * 32 < p.CO) && (c_base + cblk * 32 < CI);
+    const bool wave_active = !producer && (n_base + nblk * 32 < p.CO) && (c_base + cblk * 32 < CI);
     const int s_img_bytes = p.s_iters * BLK_B;
 
     const i32x4 rs0 = make_rsrc(p.src0, p.src0_bytes);
@@ -397,7 +406,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
             const bool s1 = c >= p.C0;
             const unsigned pix = (unsigned)((n * p.SH + sy) * p.SW + sx);
             const unsigned off = ok ? (pix * (unsigned)(s1 ? p.C1 : p.C0) + (unsigned)(s1 ? c - p.C0 : c)) * 2u : OOB;
-            const unsigned dst = lds_addr(img) + wave * 1024 + j * BLK_B;
+            const unsigned dst = lds_addr(img) + iwave * 1024 + j * BLK_B;
             if (s1) dma16(rs1, off, dst);
             else dma16(rs0, off, dst);
         } else {
@@ -412,10 +421,11 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
             const bool ok = hp < p.z_halo && col < p.CO && n < p.N && zy >= 0 && zy < p.ZH && zx >= 0 && zx < p.ZW;
             const unsigned pix = (unsigned)((n * p.ZH + zy) * p.ZW + zx);
             const unsigned off = ok ? (pix * (unsigned)p.ZC + (unsigned)col) * 2u : OOB;
-            dma16(rz, off, lds_addr(img) + s_img_bytes + wave * 1024 + jz * BLK_B);
+            dma16(rz, off, lds_addr(img) + s_img_bytes + iwave * 1024 + jz * BLK_B);
         }
     };
     const int n_items = p.s_iters + p.z_iters;
+    if (PC && producer && (p.dbg & 128)) __builtin_amdgcn_s_setprio(3);
 
     // lane l = 16g + 4q + pp supplies row q of its group's 4x16 transpose block
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
@@ -435,16 +445,24 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
         __syncthreads();      // ... everybody's has, and the other image is no longer being read
         const long long c2 = (p.dbg & 16) ? wall_clock64() : 0;
         const bool more = tile + p.splits < p.ntiles && !(p.dbg & 8);
-        int item = 0;
-        if (more) {
-            tile_geo(tile + p.splits);
+        if (more) tile_geo(tile + p.splits);
+        if (more && issuer) {
             // all DMA instructions now: spreading them over the k-steps was slower with one wave per SIMD (it stalls
-            // the software pipeline, 157 -> 191 us) and with two (157 -> 181 us)
-            for (; item < n_items; ++item) issue_item(item, other);
+            // the software pipeline, 157 -> 191 us) and with two (157 -> 181 us).  PC: the producers take the first
+            // pc_items rounds, the computing waves the rest once their k-loop is done (they would otherwise idle at
+            // the barrier: under the k-loop's LDS traffic the DMA queue drains slower than the MFMAs finish).
+            const int n_mine = PC ? p.pc_items : n_items;
+            for (int item = 0; item < n_mine; ++item) issue_item(item, other);
         }
         const long long c3 = (p.dbg & 16) ? wall_clock64() : 0;
         t_wait += c1 - c0; t_bar += c2 - c1; t_issue += c3 - c2; t_loop -= c3;
-        if (!wave_active || (p.dbg & 2)) return;
+        auto late_items = [&]() {
+            if constexpr (PC) {
+                if (more && !producer)
+                    for (int item = p.pc_items; item < n_items; ++item) issue_item(item, other);
+            }
+        };
+        if (!wave_active || (p.dbg & 2)) { late_items(); return; }
         const unsigned char* Ss = cur;
         const unsigned char* Zs = cur + s_img_bytes;
         auto load = [&](int i, bf16x8 (&A)[NA], bf16x8 (&B)[NTAPS]) {
@@ -475,7 +493,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
             for (int t = 0; t < NTAPS; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[NA == 1 ? 0 : t], B[t], acc[t], 0, 0, 0);
         };
-        if constexpr (NW == 4) {      // one wave per SIMD: software pipeline (ping-pong fragment registers)
+        if constexpr (NW == 4 || PC) {      // one computing wave per SIMD: software pipeline (ping-pong fragment registers)
             bf16x8 A0[NA], B0[NTAPS], A1[NA], B1[NTAPS];
             auto stage = [&](const bf16x8 (&Ac)[NA], const bf16x8 (&Bc)[NTAPS], int nxt, bf16x8 (&An)[NA], bf16x8 (&Bn)[NTAPS]) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -504,13 +522,19 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
             }
         }
         if (p.dbg & 16) t_loop += wall_clock64();
+        late_items();
     };
 
     int tile = byi;
     const long long k0 = (p.dbg & 16) ? wall_clock64() : 0;
     if (tile < p.ntiles) {
         tile_geo(tile);
-        for (int j = 0; j < n_items; ++j) issue_item(j, imgA);
+        if constexpr (PC) {       // first image: both wave groups issue half of the rounds
+            const int half = n_items / 2;
+            for (int j = producer ? 0 : half; j < (producer ? half : n_items); ++j) issue_item(j, imgA);
+        } else {
+            for (int j = 0; j < n_items; ++j) issue_item(j, imgA);
+        }
     }
     const long long k1 = (p.dbg & 16) ? wall_clock64() : 0;
     for (; tile < p.ntiles; tile += 2 * p.splits) {
@@ -560,10 +584,10 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     }
 }
 
-template <int NBLK, int CBLK, int NTAPS, int NW>
+template <int NBLK, int CBLK, int NTAPS, int NW, bool PC = false>
 int launch_dma(WgKArgs& a, hipStream_t st) {
-    CU_CHECK_ARG((size_t)(a.s_iters + a.z_iters) * 1024 * NW <= (size_t)DMA_IMG_BYTES, "cu_conv_wgrad: tile image exceeds %d bytes", DMA_IMG_BYTES);
-    auto k = igemm_wgrad_dma_kernel<NBLK, CBLK, NTAPS, NW>;
+    CU_CHECK_ARG((size_t)(a.s_iters + a.z_iters) * 1024 * (PC ? NW / 2 : NW) <= (size_t)DMA_IMG_BYTES, "cu_conv_wgrad: tile image exceeds %d bytes", DMA_IMG_BYTES);
+    auto k = igemm_wgrad_dma_kernel<NBLK, CBLK, NTAPS, NW, PC>;
     const int CI = a.C0 + a.C1;
     a.ctiles = cdiv(CI, 32 * CBLK);
     const int ntn = cdiv(a.CO, 32 * NBLK);
@@ -696,21 +720,32 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
         const char* nwe = getenv("CU_WGRAD_NW");
         int dma_nw = nwe ? atoi(nwe) : 8;
         CU_CHECK_ARG(dma_nw == 4 || dma_nw == 8, "CU_WGRAD_NW must be 4 or 8");
+        static const int pc_env = getenv("CU_WGRAD_PC") ? atoi(getenv("CU_WGRAD_PC")) : 1;      // 0 off, 2 every shape
+        // producer/consumer split (see the kernel); the 32-column x 64-channel tile of the 256^2 decoder layer is faster
+        // with eight computing waves (measured 294 vs 320 us)
+        const bool pc = pc_env && dma_nw == 8 && d->ntaps == 9 && (pc_env == 2 || !(!wn && wc));
         {   // every wave needs at least one k-step of the smallest tile this shape may end up with
             const int nwb = (wn ? 2 : 1) * (wc ? 2 : 1);
             const int min_nk = ((d->IS > 1 || d->ZS > 1) ? 64 : 256) / 16 / 4;      // the tile loop may halve BM twice
-            if (dma_nw / nwb > min_nk) dma_nw = 4;
+            if (!pc && dma_nw / nwb > min_nk) dma_nw = 4;
         }
+        const int issue_w = pc ? 4 : dma_nw;
         for (int BM = (d->IS > 1 || d->ZS > 1) ? 64 : 256;; BM >>= 1) {
             CU_CHECK_ARG(BM >= 16, "cu_conv_wgrad: patches do not fit in LDS");
             const int rc = geometry(BM);
             if (rc) return rc;
-            a.s_iters = cdiv(a.s_halo * spp, 64 * dma_nw);
-            a.z_iters = cdiv(a.z_halo * zpp, 64 * dma_nw);
-            if ((size_t)(a.s_iters + a.z_iters) * 1024 * dma_nw <= (size_t)DMA_IMG_BYTES) break;
+            a.s_iters = cdiv(a.s_halo * spp, 64 * issue_w);
+            a.z_iters = cdiv(a.z_halo * zpp, 64 * issue_w);
+            if ((size_t)(a.s_iters + a.z_iters) * 1024 * issue_w <= (size_t)DMA_IMG_BYTES) break;
         }
         CU_CHECK_ARG(d->ntaps == 4 || a.zsame, "cu_conv_wgrad: per-tap Z shifts are only built for 4 taps");
         a.src0_bytes = (unsigned)b0; a.src1_bytes = (unsigned)b1; a.z_bytes = (unsigned)bz;
+        {
+            static const int pcf = getenv("CU_WGRAD_PCF") ? atoi(getenv("CU_WGRAD_PCF")) : 70;      // percent of the rounds (measured optimum 65-75)
+            const int n = a.s_iters + a.z_iters;
+            a.pc_items = (n * pcf + 99) / 100;
+            if (a.pc_items > n) a.pc_items = n;
+        }
 #define CU_WDN(NBv, CBv, NWv)                                                   \
     do {                                                                        \
         if (d->ntaps == 9) return launch_dma<NBv, CBv, 9, NWv>(a, st);          \
@@ -719,6 +754,7 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
     } while (0)
 #define CU_WD(NBv, CBv)                                                         \
     do {                                                                        \
+        if (pc) return launch_dma<NBv, CBv, 9, 8, true>(a, st);                 \
         if (dma_nw == 8) CU_WDN(NBv, CBv, 8);                                   \
         CU_WDN(NBv, CBv, 4);                                                    \
     } while (0)

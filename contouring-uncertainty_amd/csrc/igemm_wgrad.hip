@@ -33,6 +33,7 @@ struct WgKArgs {
     unsigned src0_bytes, src1_bytes, z_bytes;  // tensor sizes (LDS-DMA kernel: buffer resources, out-of-range = zero fill)
     int s_iters, z_iters;                      // LDS-DMA kernel: 4-KiB staging blocks per tile for S / Z
     int pc_items;                              // producer/consumer kernel: staging rounds issued by the producer waves
+    int pc_early;                              // ... and rounds the computing waves issue before their k-loop
     int dbg;                                   // CU_CONV_DBG bits (timing experiments): 1 no atomics, 2 no MFMA, 4 no commit, 8 no loads
 };
 
@@ -327,7 +328,7 @@ constexpr int DMA_IMG_BYTES = 78 * 1024;      // per image; two of them per work
 // waves 4..7 only issue the LDS-DMA of the next tile into the other image.  The DMA queue drains at L2 speed and blocks
 // the wave that issues into it; in this split that wave has nothing else to do, and its SIMD keeps issuing the other
 // wave's MFMAs, so staging and k-loop overlap instead of adding up.
-template <int NBLK, int CBLK, int NTAPS, int NW, bool PC = false>
+template <int NBLK, int CBLK, int NTAPS, int NW, bool PC = false, bool ROWK = false>
 __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs p) {
     constexpr int TN = 32 * NBLK, TC = 32 * CBLK;
     constexpr int NWC = PC ? NW / 2 : NW;              // waves that compute
@@ -432,6 +433,12 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     const int hh = g >> 1, chalf = g & 1;
     const int s_col = cblk * p.s_halo * ROW_B + (16 * chalf + 4 * pp) * 2;      // plane base + column inside the row
     const int z_colb = nblk * p.z_halo * ROW_B + (16 * chalf + 4 * pp) * 2;
+    int s_lane[2], z_lane[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        s_lane[half] = (8 * hh + 4 * half + q) * p.IS * ROW_B + s_col;
+        z_lane[half] = (8 * hh + 4 * half + q) * p.ZS * ROW_B + z_colb;
+    }
     const int NK = p.tile_px / 16;
     const int NKW = NK / KSPLIT;
     constexpr int NA = NTAPS == 4 ? NTAPS : 1;
@@ -452,7 +459,11 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
             // pc_items rounds, the computing waves the rest once their k-loop is done (they would otherwise idle at
             // the barrier: under the k-loop's LDS traffic the DMA queue drains slower than the MFMAs finish).
             const int n_mine = PC ? p.pc_items : n_items;
-            for (int item = 0; item < n_mine; ++item) issue_item(item, other);
+            for (int item = PC ? p.pc_early : 0; item < n_mine; ++item) issue_item(item, other);
+        }
+        if constexpr (PC) {       // a few rounds fit the computing waves' empty DMA queue without blocking them
+            if (more && !producer)
+                for (int item = 0; item < p.pc_early; ++item) issue_item(item, other);
         }
         const long long c3 = (p.dbg & 16) ? wall_clock64() : 0;
         t_wait += c1 - c0; t_bar += c2 - c1; t_issue += c3 - c2; t_loop -= c3;
@@ -466,14 +477,29 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
         const unsigned char* Ss = cur;
         const unsigned char* Zs = cur + s_img_bytes;
         auto load = [&](int i, bf16x8 (&A)[NA], bf16x8 (&B)[NTAPS]) {
-            const int ks = kpart + (i < NKW ? i : NKW - 1) * KSPLIT;
+            // the k-part is wave-uniform: in a scalar register the whole k-step addressing below is scalar arithmetic
+            // instead of quarter-rate vector multiplies (they, not the MFMAs or the LDS, bounded the k-loop)
+            const int kp = KSPLIT == 1 ? 0 : __builtin_amdgcn_readfirstlane(kpart);
+            const int ks = (ROWK ? kp : kpart) + (i < NKW ? i : NKW - 1) * KSPLIT;
             int sbase[2], zbase[2];
+            if constexpr (ROWK) {   // tile rows of >= 16 pixels: a k-step lies in one row -> scalar row base + per-lane offset
+                const int m0 = ks * 16;
+                const int tx0 = m0 & (TW - 1), ty = (m0 >> p.twl) & (TH - 1), im = m0 >> (p.twl + p.thl);
+                const int srow = (im * s_hpi + ty * p.IS * p.SHW + tx0 * p.IS) * ROW_B;
+                const int zrow = (im * z_hpi + ty * p.ZS * p.ZHW + tx0 * p.ZS) * ROW_B;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    sbase[half] = srow + s_lane[half];
+                    zbase[half] = zrow + z_lane[half];
+                }
+            } else {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int m = ks * 16 + 8 * hh + 4 * half + q;
                 const int tx = m & (TW - 1), ty = (m >> p.twl) & (TH - 1), im = m >> (p.twl + p.thl);
                 sbase[half] = (im * s_hpi + ty * p.IS * p.SHW + tx * p.IS) * ROW_B + s_col;
                 zbase[half] = (im * z_hpi + ty * p.ZS * p.ZHW + tx * p.ZS) * ROW_B + z_colb;
+            }
             }
 #pragma unroll
             for (int t = 0; t < NA; ++t) {
@@ -584,10 +610,10 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     }
 }
 
-template <int NBLK, int CBLK, int NTAPS, int NW, bool PC = false>
+template <int NBLK, int CBLK, int NTAPS, int NW, bool PC = false, bool ROWK = false>
 int launch_dma(WgKArgs& a, hipStream_t st) {
     CU_CHECK_ARG((size_t)(a.s_iters + a.z_iters) * 1024 * (PC ? NW / 2 : NW) <= (size_t)DMA_IMG_BYTES, "cu_conv_wgrad: tile image exceeds %d bytes", DMA_IMG_BYTES);
-    auto k = igemm_wgrad_dma_kernel<NBLK, CBLK, NTAPS, NW, PC>;
+    auto k = igemm_wgrad_dma_kernel<NBLK, CBLK, NTAPS, NW, PC, ROWK>;
     const int CI = a.C0 + a.C1;
     a.ctiles = cdiv(CI, 32 * CBLK);
     const int ntn = cdiv(a.CO, 32 * NBLK);
@@ -743,7 +769,9 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
         {
             static const int pcf = getenv("CU_WGRAD_PCF") ? atoi(getenv("CU_WGRAD_PCF")) : 70;      // percent of the rounds (measured optimum 65-75)
             const int n = a.s_iters + a.z_iters;
-            a.pc_items = (n * pcf + 99) / 100;
+            static const int pce = getenv("CU_WGRAD_PCE") ? atoi(getenv("CU_WGRAD_PCE")) : 0;
+            a.pc_early = pce < n ? pce : n;
+            a.pc_items = a.pc_early + ((n - a.pc_early) * pcf + 99) / 100;
             if (a.pc_items > n) a.pc_items = n;
         }
 #define CU_WDN(NBv, CBv, NWv)                                                   \
@@ -754,6 +782,7 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
     } while (0)
 #define CU_WD(NBv, CBv)                                                         \
     do {                                                                        \
+        if (pc && a.twl >= 4) return launch_dma<NBv, CBv, 9, 8, true, true>(a, st); \
         if (pc) return launch_dma<NBv, CBv, 9, 8, true>(a, st);                 \
         if (dma_nw == 8) CU_WDN(NBv, CBv, 8);                                   \
         CU_WDN(NBv, CBv, 4);                                                    \

@@ -36,6 +36,8 @@ struct ConvKArgs {
     float slope0, slope1;
     int accum0, accum1, out_nchw;
     int par_co;                 // > 0: column group g = col / par_co goes to destination parity (g >> 1, g & 1)
+    int par_taps;               // with par_co: weight tap of (gather tap t, group g) = nibble t * 4 + g of par_pack, minus 1
+    unsigned long long par_pack;
     int imgs;                   // images per tile (TW*TH*imgs <= 128*MA; rows beyond are idle)
     int txl, tyl, ntiles;       // log2 of tiles per row / column, total pixel tiles
     int tap_lds;                // byte offset of the tap table inside the dynamic LDS
@@ -126,8 +128,15 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
         int t = (i >> 2) / BN;
         t = t < p.ntaps ? t : 0;
         const int n = n0 + col;
-        const bool ok = ex && n < p.CO;
-        wbase[j] = (s_tap[16 + t] * p.CO + (ok ? n : 0)) * CI + piece * PIECE;
+        bool ok = ex && n < p.CO;
+        if (p.par_taps) {        // stride-2 input gradient: the weight tap depends on (gather tap, output parity)
+            const int par = ok ? n / p.par_co : 0;
+            const int tw = (int)((p.par_pack >> (4 * ((t & 3) * 4 + par))) & 15ull) - 1;
+            ok = ok && tw >= 0;
+            wbase[j] = ((ok ? tw : 0) * p.par_co + (ok ? n - par * p.par_co : 0)) * CI + piece * PIECE;
+        } else {
+            wbase[j] = (s_tap[16 + t] * p.CO + (ok ? n : 0)) * CI + piece * PIECE;
+        }
         wlds[j] = (PPP == 1) ? (t * 4 + piece) * p.WP + col : (t * 16 + piece * 4) * p.WP + col;
         wexist |= (ex ? 1u : 0u) << j;
         wvalid |= (ok ? 1u : 0u) << j;
@@ -745,8 +754,16 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
     a.slope0 = d->slope0; a.slope1 = d->slope1; a.accum0 = d->accum0; a.accum1 = d->accum1;
     a.out_nchw = d->out_nchw_f32;
     a.par_co = d->par_co;
+    a.par_taps = d->par_co > 0 ? d->par_taps : 0;
+    a.par_pack = 0;
+    for (int i = 0; i < 16 && a.par_taps; ++i) {
+        CU_CHECK_ARG(d->par_tap_w[i] >= -1 && d->par_tap_w[i] < 15, "cu_conv_gemm: bad parity tap %d", d->par_tap_w[i]);
+        a.par_pack |= (unsigned long long)(d->par_tap_w[i] + 1) << (4 * i);
+    }
+    CU_CHECK_ARG(!a.par_taps || (d->ntaps <= 4 && !bias), "cu_conv_gemm: parity taps need ntaps <= 4 and no bias");
     CU_CHECK_ARG(d->par_co == 0 || (d->par_co > 0 && d->par_co % 32 == 0 && d->CO == 4 * d->par_co && d->D0 == d->CO &&
-                                    d->OS == 2 && d->OY0 == 0 && d->OX0 == 0 && !d->out_nchw_f32 && !d->accum0 &&
+                                    d->OS == 2 && d->OY0 == 0 && d->OX0 == 0 && !d->out_nchw_f32 &&
+                                    (!d->accum0 || d->par_taps) &&
                                     (d->PH - 1) * 2 + 1 < d->OH && (d->PW - 1) * 2 + 1 < d->OW),
                  "cu_conv_gemm: bad parity-column mode (par_co=%d)", d->par_co);
     const int CI = d->C0 + d->C1;

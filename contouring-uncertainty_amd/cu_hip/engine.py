@@ -34,6 +34,23 @@ def _parity_taps(par: int):
     return [(0, 1)] if par == 0 else [(1, 0), (0, 2)]
 
 
+def _s2_parity_taps():
+    """weight tap (kh*3+kw) of (gather tap (u, v) of dz, input parity (a, b)) at [(u*2+v)*4 + a*2+b], -1 = no such tap."""
+    k1 = {(par, off): k for par in range(2) for off, k in _parity_taps(par)}
+    out = []
+    for u in range(2):
+        for v in range(2):
+            for a in range(2):
+                for b in range(2):
+                    kh, kw = k1.get((a, u), -1), k1.get((b, v), -1)
+                    out.append(kh * 3 + kw if kh >= 0 and kw >= 0 else -1)
+    return out
+
+
+S2_PARITY_TAPS = _s2_parity_taps()
+ONE_PASS_S2_DGRAD = False
+
+
 @dataclass
 class _ConvRec:
     prefix: str
@@ -273,6 +290,14 @@ class UNetEngine:
         if rec.stride == 1:
             ops.conv_gemm([gz], wd, None, grid=(sh, sw), in_stride=1, taps=TAPS3_D, dsts=dsts, dst_cols=cols,
                           accum=acc)
+        elif ONE_PASS_S2_DGRAD and len(dsts) == 1 and cols[0] % 32 == 0:
+            # all four input parities in one pass: gather taps = the 2x2 neighbourhood of dz, the weight tap of
+            # (gather tap, parity) from S2_PARITY_TAPS (9 of the 16 pairs exist); dz is read once.  Measured SLOWER than
+            # the four parity launches below (128^2 x 64->32: 271 vs 194 us; 16/9 of the MFMA work and the 64-byte
+            # half-line stores of the parity epilogue), so it is off; tools/conv_bench.py s2dgrad compares the two.
+            ops.conv_gemm([gz], wd, None, grid=(sh // 2, sw // 2), in_stride=1,
+                          taps=[(u, v, 0) for u in range(2) for v in range(2)], dsts=dsts, dst_cols=cols, out_stride=2,
+                          accum=acc, n_cols=4 * cols[0], parity_cols=cols[0], parity_taps=S2_PARITY_TAPS)
         else:
             for py in range(2):
                 for px in range(2):

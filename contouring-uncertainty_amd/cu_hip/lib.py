@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
         ("OY0", C.c_int), ("OX0", C.c_int), ("CO", C.c_int), ("D0", C.c_int), ("DC0", C.c_int), ("DC1", C.c_int),
         ("ntaps", C.c_int), ("tap_dy", _INT9), ("tap_dx", _INT9), ("tap_w", _INT9),
         ("slope0", C.c_float), ("slope1", C.c_float), ("accum0", C.c_int), ("accum1", C.c_int),
-        ("out_nchw_f32", C.c_int), ("par_co", C.c_int),
+        ("out_nchw_f32", C.c_int), ("par_co", C.c_int), ("par_taps", C.c_int), ("par_tap_w", C.c_int * 16),
     ]
 
 

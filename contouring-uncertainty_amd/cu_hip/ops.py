@@ -80,8 +80,10 @@ def _taps(desc, dys, dxs, ws, zys=None, zxs=None):
 def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: Tuple[int, int], in_stride: int,
               taps: Sequence[Tuple[int, int, int]], dsts: Sequence[Tensor], dst_cols: Sequence[int],
               out_stride: int = 1, out_off: Tuple[int, int] = (0, 0), accum: Sequence[int] = (0, 0),
-              out_nchw: bool = False, n_cols: Optional[int] = None, parity_cols: int = 0):
-    """D[p, n] = bias[n] + sum_t sum_c act(S[p*IS + off_t, c]) W[tap_w[t]][n][c]  (cu_conv_gemm)."""
+              out_nchw: bool = False, n_cols: Optional[int] = None, parity_cols: int = 0,
+              parity_taps: Optional[Sequence[int]] = None):
+    """D[p, n] = bias[n] + sum_t sum_c act(S[p*IS + off_t, c]) W[tap_w[t]][n][c]  (cu_conv_gemm).
+    ``parity_taps`` (16 ints, with ``parity_cols``): weight tap of (gather tap t, parity group g) at [t*4+g], -1 = none."""
     lib = L.load()
     s0 = srcs[0]
     s1 = srcs[1] if len(srcs) > 1 else None
@@ -111,7 +113,12 @@ def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: T
     d.accum0, d.accum1 = int(accum[0]), int(accum[1]) if len(accum) > 1 else 0
     d.out_nchw_f32 = int(out_nchw)
     d.par_co = parity_cols
-    assert w.dtype == t0.dtype and w.shape[-1] == d.C0 + d.C1 and w.shape[-2] == d.CO, (w.shape, d.CO, d.C0, d.C1)
+    if parity_taps is not None:
+        d.par_taps = 1
+        for i, v in enumerate(parity_taps):
+            d.par_tap_w[i] = int(v)
+    assert w.dtype == t0.dtype and w.shape[-1] == d.C0 + d.C1 and \
+        w.shape[-2] == (parity_cols if parity_taps is not None else d.CO), (w.shape, d.CO, d.C0, d.C1)
     flops = 2.0 * d.N * d.PH * d.PW * d.ntaps * (d.C0 + d.C1) * (d.DC0 if out_nchw else d.CO)
     esz = t0.element_size()
     nbytes = (d.N * d.SH * d.SW * (d.C0 + d.C1) * esz if d.IS == 1 else d.N * d.PH * d.PW * d.ntaps * (d.C0 + d.C1) * esz) \

@@ -59,6 +59,13 @@ typedef struct {
     int par_co;             /* > 0: the CO columns are 4 groups of par_co, group g -> channels [0,par_co) of destination
                                pixel p*OS + (g >> 1, g & 1): all four output parities of a 2x2 stride-2 transposed conv
                                (W viewed as [1][4*par_co][C]) in ONE pass over the source.  Needs D0 == CO, OY0 = OX0 = 0 */
+    int par_taps;           /* with par_co: 1 = the weight tap depends on (gather tap t, parity group g):
+                               W is [wtaps][par_co][C] and group g of tap t uses weight tap par_tap_w[t*4 + g], or
+                               contributes nothing when that is < 0.  This is the input gradient of a stride-2 3x3 conv
+                               (4 gather taps = the 2x2 neighbourhood of dz, 9 of the 16 (t, g) pairs in use) in one
+                               pass: dz is read once and whole destination rows are written, instead of one launch per
+                               output parity.  ntaps <= 4. */
+    int par_tap_w[16];
 } cu_conv_desc;
 
 int cu_conv_gemm(const cu_conv_desc* d,

@@ -471,3 +471,30 @@ def test_conv_wide_dma_kernel_stride2(case):
     assert torch.equal(out, old)
     ref = F.conv2d(r, rq(w, dtype), b, stride=2, padding=1)
     assert rel_err(nchw(out), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 32, 64, 32, 0), (2, 64, 128, 16, 1), (3, 480, 480, 4, 1), (64, 480, 480, 2, 0),
+                                  (2, 256, 480, 8, 1)])
+def test_stride2_dgrad_single_pass(dtype, case):
+    """Input gradient of a stride-2 3x3 conv with all four input parities in one launch (par_taps) vs autograd of
+    F.conv2d, with and without accumulation onto existing data."""
+    ops = _ops()
+    from cu_hip.engine import S2_PARITY_TAPS
+    n, ci, co, os_, accum = case
+    size = 2 * os_
+    g = torch.Generator(device=DEV).manual_seed(11)
+    w = torch.randn(co, ci, 3, 3, device=DEV, generator=g) / math.sqrt(9 * ci)
+    wq = rq(w, dtype)
+    xin = torch.zeros(n, ci, size, size, device=DEV, requires_grad=True)
+    dz = rq(torch.randn(n, co, os_, os_, device=DEV, generator=g), dtype)
+    F.conv2d(xin, wq, None, stride=2, padding=1).backward(dz)
+    _, wd = ops.weight_prep(w, "conv", dtype)
+    base = rq(torch.randn(n, ci, size, size, device=DEV, generator=g), dtype)
+    d0 = nhwc(base, dtype)
+    gz = ops.Act(nhwc(dz, dtype), None, 1.0)
+    ops.conv_gemm([gz], wd, None, grid=(os_, os_), in_stride=1, taps=[(u, v, 0) for u in range(2) for v in range(2)],
+                  dsts=[d0], dst_cols=[ci], out_stride=2, accum=[accum], n_cols=4 * ci, parity_cols=ci,
+                  parity_taps=S2_PARITY_TAPS)
+    ref = xin.grad + (base if accum else 0)
+    assert rel_err(nchw(d0), ref) < tol(dtype)

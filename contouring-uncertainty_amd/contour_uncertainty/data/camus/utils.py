@@ -10,6 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 from contour_uncertainty.utils.contour import linear_reconstruction, reconstruction_batch
+from contour_uncertainty.utils.skew_umap import skew_umap
 
 LABEL_MYO = 2           # vital.data.camus.config.Label.MYO
 
@@ -40,3 +41,14 @@ class USContourToMask:
         if _has_myo(labels):
             raise NotImplementedError("USContourToMask: the LV + MYO branch is not part of this build (SURVEY.md 8)")
         return reconstruction_batch(landmarks, shape[0], shape[1], round_landmarks=True, packed=packed)
+
+
+class USSkewUmap:
+    """reference data/camus/utils.py:126-151, single-structure labels: projected mode + skew-normal uncertainty map."""
+
+    @staticmethod
+    def __call__(mu, cov, alpha, labels=None):
+        if _has_myo(labels):
+            raise NotImplementedError("USSkewUmap: the LV + MYO branch is not part of this build (SURVEY.md 8)")
+        projected_mode, umap = skew_umap(mu, cov, alpha, linear_close=True)
+        return projected_mode, umap / umap.max()

@@ -29,6 +29,15 @@ class BivariateNormal(BivariateDistribution):
         return mu
 
     @classmethod
+    def marginal(cls, mu, cov, axis: int, angle=torch.tensor(0), *args, **kwargs):
+        """(mean, variance) of the marginal along ``axis`` after rotating the covariance by -angle (reference :69-86);
+        host code of the u-map post-processing."""
+        from contour_uncertainty.distributions.utils import rotate_cov
+        assert axis == 0 or axis == 1
+        cov = rotate_cov(cov, -angle)
+        return mu[axis], cov[axis, axis]
+
+    @classmethod
     def rvs(cls, mu, cov, size=(1,)):
         """MultivariateNormal(mu, cov).sample(size) (reference :89-90): mu + chol(cov) eps, via the skew kernel with
         alpha = 0 (which then never flips a draw's sign in distribution)."""

@@ -34,6 +34,25 @@ class BivariateSkewNormal(BivariateDistribution):
         return terms[:, 0], terms[:, 1], terms[:, 2], terms[:, 3]
 
     @classmethod
+    def marginal(cls, mu, cov, alpha, axis: int, angle=torch.tensor(0), *args, **kwargs):
+        """(location, variance, skewness) of the marginal along ``axis`` after rotating by -angle (reference
+        distributions/bivariateskewnormal.py:92-135; the y component of alpha is negated first, as there)."""
+        from contour_uncertainty.distributions.utils import cov2corr, rotate_alpha, rotate_cov
+        assert axis == 0 or axis == 1
+        cov = rotate_cov(cov, -angle)
+        alpha = torch.tensor(alpha).clone()
+        alpha[1] = -alpha[1]
+        alpha = rotate_alpha(alpha, -angle)
+        corr, _ = cov2corr(cov)
+        corr = corr.squeeze()
+        other = 1 - axis
+        corr_11, corr_22, corr_12 = corr[axis, axis], corr[other, other], corr[0, 1]
+        alpha_1, alpha_2 = alpha[axis], alpha[other]
+        corr_22_1 = corr_22 - corr_12 * corr_12 / corr_11
+        alpha_1_2 = (alpha_1 + (1 / corr_11) * corr_12 * alpha_2) / torch.sqrt(1 + alpha_2 * corr_22_1 * alpha_2)
+        return mu[axis], cov[axis, axis], alpha_1_2
+
+    @classmethod
     def rvs_fast(cls, mu, cov, alpha, size=1, eps=None, seed=None):
         """Draws via the 3-D Gaussian construction (reference :159-191) -> (size, 2)."""
         from cu_hip import ops

@@ -333,6 +333,23 @@ __global__ __launch_bounds__(256) void mask_entropy_kernel(int F, int S, int H, 
     }
 }
 
+// weighted mean over S packed masks per frame (weights sum to 1) and its natural-log binary entropy: the reduction of
+// skew_umap (reference utils/skew_umap.py:74-79: np.average(rec, weights) then scipy.stats.entropy of [m, 1 - m])
+__global__ __launch_bounds__(256) void mask_weighted_entropy_kernel(int F, int S, int H, int W, const unsigned* __restrict__ packed,
+                                                                    const float* __restrict__ weights, float* __restrict__ mean,
+                                                                    float* __restrict__ entropy) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)F * H * W) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H), f = (int)(i / ((size_t)W * H));
+    const unsigned* p = packed + ((size_t)f * S * H + y) * 8 + (x >> 5);
+    float m = 0.f;
+    for (int s = 0; s < S; ++s)
+        if ((p[(size_t)s * H * 8] >> (x & 31)) & 1u) m += weights[s];
+    m = fminf(fmaxf(m, 0.f), 1.f);
+    if (mean) mean[i] = m;
+    if (entropy) entropy[i] = -((m > 0.f ? m * logf(m) : 0.f) + (m < 1.f ? (1.f - m) * logf(1.f - m) : 0.f));
+}
+
 }  // namespace
 
 extern "C" int cu_contour_masks(int M, int K, int H, int W, const float* contours, int round_landmarks, unsigned* packed,
@@ -350,6 +367,17 @@ extern "C" int cu_mask_entropy(int F, int S, int H, int W, const unsigned* packe
     CU_CHECK_ARG(F > 0 && S > 0 && H > 0 && H <= MT && W > 0 && W <= MT && packed && (mean || entropy), "cu_mask_entropy: bad argument");
     hipLaunchKernelGGL(mask_entropy_kernel, dim3((unsigned)(F * ((H * 8 + 31) / 32))), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), F, S, H, W, packed, mean, entropy);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_mask_weighted_entropy(int F, int S, int H, int W, const unsigned* packed, const float* weights, float* mean,
+                                        float* entropy, void* stream) {
+    CU_CHECK_ARG(F > 0 && S > 0 && H > 0 && H <= MT && W > 0 && W <= MT && packed && weights && (mean || entropy),
+                 "cu_mask_weighted_entropy: bad argument");
+    const size_t total = (size_t)F * H * W;
+    hipLaunchKernelGGL(mask_weighted_entropy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), F, S, H, W, packed, weights, mean, entropy);
     CU_LAUNCH_CHECK();
     return 0;
 }

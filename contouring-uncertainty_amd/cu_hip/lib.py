@@ -75,6 +75,7 @@ _SIGS = {
     "cu_psm_condition": (C.c_int, [C.c_int] * 3 + [_P, C.c_int, _P, C.c_int] + [_P] * 10),
     "cu_contour_masks": (C.c_int, [C.c_int] * 4 + [_P, C.c_int, _P, _P, _P]),
     "cu_mask_entropy": (C.c_int, [C.c_int] * 4 + [_P] * 4),
+    "cu_mask_weighted_entropy": (C.c_int, [C.c_int] * 4 + [_P] * 5),
     "cu_logpdf_grid": (C.c_int, [C.c_int] * 3 + [_P] * 6),
     "cu_skew_rvs": (C.c_int, [C.c_int] * 2 + [_P] * 4 + [C.c_uint64, _P, _P]),
     "cu_adam_step": (C.c_int, [C.c_size_t] + [_P] * 4 + [C.c_float] * 5 + [C.c_int, C.c_float, _P]),

@@ -510,6 +510,19 @@ def mask_entropy(packed: Tensor, frames: int, width: int, mean: bool = True, ent
     return mo, eo
 
 
+def mask_weighted_entropy(packed: Tensor, frames: int, width: int, weights: Tensor):
+    """packed (F*S, H, 8) int32, weights (S,) f32 summing to 1 -> (weighted mean (F, H, W), natural-log binary entropy)
+    (cu_mask_weighted_entropy)."""
+    ms, h, _ = packed.shape
+    assert ms % frames == 0 and weights.numel() == ms // frames and weights.dtype == torch.float32
+    mo = torch.empty((frames, h, width), dtype=torch.float32, device=packed.device)
+    eo = torch.empty_like(mo)
+    with _Prof("masks"):
+        L.check(L.load().cu_mask_weighted_entropy(frames, ms // frames, h, width, L.ptr(packed), L.ptr(weights.contiguous()),
+                                                  L.ptr(mo), L.ptr(eo), L.stream_ptr()), "cu_mask_weighted_entropy")
+    return mo, eo
+
+
 def logpdf_grid(pts: Tensor, mu: Tensor, sigma3: Tensor, alpha: Optional[Tensor] = None, pairwise: bool = False) -> Tensor:
     """pts (P,2), mu (M,2), sigma3 (M,3), alpha (M,2)|None -> log density (M,P) or (P,) when pairwise."""
     m, p = mu.shape[0], pts.shape[0]

@@ -262,6 +262,10 @@ int cu_skew_rvs(int M, int S, const float* mu, const float* sigma, const float* 
 int cu_contour_masks(int M, int K, int H, int W, const float* contours, int round_landmarks, uint32_t* packed,
                      uint8_t* bytes, void* stream);
 int cu_mask_entropy(int F, int S, int H, int W, const uint32_t* packed, float* mean, float* entropy, void* stream);
+/* Weighted form for the skew-normal uncertainty map (reference contour_uncertainty/utils/skew_umap.py:74-79): mean =
+ * sum_s weights[s] * mask_s (weights [S], normalised by the caller), entropy = natural-log binary entropy of the mean. */
+int cu_mask_weighted_entropy(int F, int S, int H, int W, const uint32_t* packed, const float* weights, float* mean,
+                             float* entropy, void* stream);
 
 #ifdef __cplusplus
 }

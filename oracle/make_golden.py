@@ -379,11 +379,38 @@ def gen_skew_grid():
     np.savez_compressed(OUT / "skew_grid.npz", **out)
 
 
+def gen_umap():
+    """projected_uncertainty (utils/uncertainty_projection.py:17-129, importable) and the distribution marginals it calls,
+    on LV-like contours: the per-landmark normal direction, projected standard deviation and projected skewness that
+    skew_umap / uncertainty_map build their maps from (those two modules need scikit-image and are not importable)."""
+    from contour_uncertainty.utils.uncertainty_projection import projected_uncertainty
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    for case in range(4):
+        k = 21
+        t = np.linspace(0.0, np.pi, k)
+        rng = np.random.default_rng(case)
+        mu = np.stack([128 + (50 + 10 * case) * np.cos(t), 170 - (80 + 5 * case) * np.sin(t)], -1) + rng.normal(size=(k, 2))
+        mu = mu.astype(np.float32)          # the predict step hands float32 arrays over (aleatoric_skew.py:70-90)
+        cov = rand_spd(k, g, 2.0, 60.0).numpy().astype(np.float32)
+        alpha = (torch.randn(k, 2, generator=g) * 2.0).numpy().astype(np.float32)
+        out[f"c{case}_mu"], out[f"c{case}_cov"], out[f"c{case}_alpha"] = mu, cov, alpha
+        for lc in (False, True):
+            u, v, a = projected_uncertainty(mu, cov, alpha.copy(), all=True, linear_close=lc)
+            out[f"c{case}_lc{int(lc)}_u"], out[f"c{case}_lc{int(lc)}_v"] = np.asarray(u, dtype=np.float64), np.asarray(v)
+            out[f"c{case}_lc{int(lc)}_a"] = np.asarray([float(x) for x in a])
+        u, v = projected_uncertainty(mu, cov, all=True)
+        out[f"c{case}_gauss_u"], out[f"c{case}_gauss_v"] = np.asarray([float(x) for x in u]), np.asarray(v)
+        u, v = projected_uncertainty(mu, cov)
+        out[f"c{case}_ends_u"] = np.asarray([float(x) for x in u])
+    np.savez_compressed(OUT / "umap_projection.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dsnt", "nll", "unet_small", "unet_full", "step", "psm", "skew_grid"]
+    which = sys.argv[1:] or ["dsnt", "nll", "unet_small", "unet_full", "step", "psm", "skew_grid", "umap"]
     for w in which:
         print("generating", w, flush=True)
         {"dsnt": gen_dsnt, "nll": gen_nll, "unet_small": gen_unet_small, "unet_full": gen_unet_full,
-         "step": gen_step, "psm": gen_psm, "skew_grid": gen_skew_grid}[w]()
+         "step": gen_step, "psm": gen_psm, "skew_grid": gen_skew_grid, "umap": gen_umap}[w]()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)

@@ -11,6 +11,7 @@ import numpy as np
 
 from contour_uncertainty.utils.contour import linear_reconstruction, reconstruction_batch
 from contour_uncertainty.utils.skew_umap import skew_umap
+from contour_uncertainty.utils.umap import uncertainty_map
 
 LABEL_MYO = 2           # vital.data.camus.config.Label.MYO
 
@@ -52,3 +53,14 @@ class USSkewUmap:
             raise NotImplementedError("USSkewUmap: the LV + MYO branch is not part of this build (SURVEY.md 8)")
         projected_mode, umap = skew_umap(mu, cov, alpha, linear_close=True)
         return projected_mode, umap / umap.max()
+
+
+class USUMap:
+    """reference data/camus/utils.py:103-123, single-structure labels: Gaussian uncertainty map scaled to a maximum of 1."""
+
+    @staticmethod
+    def __call__(mu, cov, labels=None):
+        if _has_myo(labels):
+            raise NotImplementedError("USUMap: the LV + MYO branch is not part of this build (SURVEY.md 8)")
+        umap = uncertainty_map(mu, cov)
+        return umap / umap.max()

@@ -12,12 +12,12 @@ import torch
 from numpy import linalg as LA
 
 from contour_uncertainty.task.uncertainty import UncertaintyTask
-from contour_uncertainty.data.camus.utils import USContourToMask, USSkewUmap
+from contour_uncertainty.data.camus.utils import USContourToMask, USSkewUmap, USUMap
 
 
 class ContourUncertaintyTask(UncertaintyTask):
     contour_to_mask_fn = USContourToMask()          # the CAMUS datamodule's (reference data/camus/datamodule.py:72)
-    umap_fn = None
+    umap_fn = USUMap()                              # the CAMUS datamodule's (reference data/camus/datamodule.py:73)
     skew_umap_fn = USSkewUmap()                     # the CAMUS datamodule's (reference data/camus/datamodule.py:74)
     _entropy_map = None                             # device-computed entropy of the last convert_to_mask call
 

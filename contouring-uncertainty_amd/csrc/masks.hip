@@ -95,7 +95,7 @@ __device__ __forceinline__ Row low_bits(int n) {      // bits [0, n)
 }
 
 __global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, const float* __restrict__ contours,
-                                                          int round_landmarks, unsigned* __restrict__ packed,
+                                                          int round_landmarks, int mode, unsigned* __restrict__ packed,
                                                           unsigned char* __restrict__ bytes, int dbg) {
     __shared__ unsigned bmA[MT * 8];        // the drawn curve, then the reached background (rows)
     __shared__ unsigned bmB[MT * 8];        // transposed bitmaps
@@ -198,25 +198,31 @@ __global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, c
         else { if (ix < 0) ix = 0; if (iy < 0) iy = 0; }
         if (ix >= 0 && iy >= 0) atomicOr(&bmA[iy * 8 + (ix >> 5)], 1u << (ix & 31));
     };
+    // mode 0: `reconstruction` (1000 points, upper clip + numpy's negative wrap, rounded closing line, fill);
+    // mode 1 / 2: the curve of `uncertainty_map` (reference utils/umap.py:24-31: 1001 points, clip to [0, size-1] on both
+    // sides, closing line between the TRUNCATED end landmarks (mode 2: no closing line), no fill)
+    const int npts = mode == 0 ? 1000 : 1001;
+    const bool wrap_pts = mode == 0;
     if (!fallback) {
-        for (int q = tid; q < 1000; q += MT) {
-            const double x = (double)q * (1.0 / 999.0);      // np.linspace(0, 1, 1000)
+        for (int q = tid; q < npts; q += MT) {
+            const double x = (double)q * (1.0 / (double)(npts - 1));      // np.linspace(0, 1, npts)
             double N[4];
-            const int j = basis(q == 999 ? 1.0 : x, N);
+            const int j = basis(q == npts - 1 ? 1.0 : x, N);
             const double sx = N[0] * cx[j] + N[1] * cx[j + 1] + N[2] * cx[j + 2] + N[3] * cx[j + 3];
             const double sy = N[0] * cy[j] + N[1] * cy[j + 1] + N[2] * cy[j + 2] + N[3] * cy[j + 3];
-            plot((int)rint(sx), (int)rint(sy), true);
+            plot((int)rint(sx), (int)rint(sy), wrap_pts);
         }
     } else if (tid < K) {
-        plot((int)rint(px[tid]), (int)rint(py[tid]), true);
+        plot((int)rint(px[tid]), (int)rint(py[tid]), wrap_pts);
     }
     {   // closing edge, skimage.draw.line(last, first) with clip(min=0, max): Bresenham in closed form, one step per thread
         int r0 = (int)rint(py[K - 1]), c0 = (int)rint(px[K - 1]), r1 = (int)rint(py[0]), c1 = (int)rint(px[0]);
+        if (mode != 0) { r0 = (int)py[K - 1]; c0 = (int)px[K - 1]; r1 = (int)py[0]; c1 = (int)px[0]; }      // astype(int)
         int dr = abs(r1 - r0), dc = abs(c1 - c0);
         int sr = r1 >= r0 ? 1 : -1, sc = c1 >= c0 ? 1 : -1;
         const bool steep = dr > dc;
         if (steep) { int a; a = r0; r0 = c0; c0 = a; a = dr; dr = dc; dc = a; a = sr; sr = sc; sc = a; }
-        for (int i = tid; i <= dc; i += MT) {
+        for (int i = tid; i <= dc && mode != 2; i += MT) {
             const int n = dc > 0 ? (int)((2ll * dr * i + dc) / (2ll * dc)) : 0;     // minor-axis steps before major step i
             const int r = r0 + sr * n, c = c0 + sc * i;
             if (steep) plot(r, c, false); else plot(c, r, false);
@@ -224,6 +230,21 @@ __global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, c
     }
     __syncthreads();
 
+    if (mode != 0) {          // curve only
+        if (tid < H && packed) {
+            unsigned* o = packed + (m * H + tid) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = bmA[tid * 8 + i];
+        }
+        if (bytes) {
+            unsigned char* o = bytes + m * (size_t)H * W;
+            for (int i = tid; i < H * W; i += MT) {
+                const int y = i / W, x = i - y * W;
+                o[i] = (bmA[y * 8 + (x >> 5)] >> (x & 31)) & 1u;
+            }
+        }
+        return;
+    }
     // ---- binary_fill_holes: flood the background from outside the image (4-connectivity), bit-parallel
     const Row wmask = low_bits(W), hmask = low_bits(H);
     Row freeR{{0, 0, 0, 0}}, reach{{0, 0, 0, 0}};
@@ -350,15 +371,30 @@ __global__ __launch_bounds__(256) void mask_weighted_entropy_kernel(int F, int S
     if (entropy) entropy[i] = -((m > 0.f ? m * logf(m) : 0.f) + (m < 1.f ? (1.f - m) * logf(1.f - m) : 0.f));
 }
 
+// out[pixel] = values[s] of the LAST mask s that covers the pixel, 0 if none: the sequential overwrites of
+// `uncertainty_map` (reference utils/umap.py:22-31)
+__global__ __launch_bounds__(256) void mask_last_value_kernel(int S, int H, int W, const unsigned* __restrict__ packed,
+                                                              const float* __restrict__ values, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int x = i % W, y = i / W;
+    const unsigned* p = packed + (size_t)y * 8 + (x >> 5);
+    float v = 0.f;
+    for (int s = S - 1; s >= 0; --s)
+        if ((p[(size_t)s * H * 8] >> (x & 31)) & 1u) { v = values[s]; break; }
+    out[i] = v;
+}
+
 }  // namespace
 
-extern "C" int cu_contour_masks(int M, int K, int H, int W, const float* contours, int round_landmarks, unsigned* packed,
-                                unsigned char* bytes, void* stream) {
+extern "C" int cu_contour_masks(int M, int K, int H, int W, const float* contours, int round_landmarks, int mode,
+                                unsigned* packed, unsigned char* bytes, void* stream) {
+    CU_CHECK_ARG(mode >= 0 && mode <= 2, "cu_contour_masks: bad mode %d", mode);
     CU_CHECK_ARG(M > 0 && K >= 2 && K <= MAXK && H > 0 && H <= MT && W > 0 && W <= MT, "cu_contour_masks: bad sizes M=%d K=%d H=%d W=%d", M, K, H, W);
     CU_CHECK_ARG(contours && (packed || bytes), "cu_contour_masks: null pointer");
     static const int dbg = getenv("CU_MASKS_DBG") ? atoi(getenv("CU_MASKS_DBG")) : 0;      // timing aid (tools/masks_bench.py)
     hipLaunchKernelGGL(contour_mask_kernel, dim3(M), dim3(MT), 0, reinterpret_cast<hipStream_t>(stream), K, H, W, contours,
-                       round_landmarks, packed, bytes, dbg);
+                       round_landmarks, mode, packed, bytes, dbg);
     CU_LAUNCH_CHECK();
     return 0;
 }
@@ -378,6 +414,14 @@ extern "C" int cu_mask_weighted_entropy(int F, int S, int H, int W, const unsign
     const size_t total = (size_t)F * H * W;
     hipLaunchKernelGGL(mask_weighted_entropy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), F, S, H, W, packed, weights, mean, entropy);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_mask_last_value(int S, int H, int W, const unsigned* packed, const float* values, float* out, void* stream) {
+    CU_CHECK_ARG(S > 0 && H > 0 && H <= MT && W > 0 && W <= MT && packed && values && out, "cu_mask_last_value: bad argument");
+    hipLaunchKernelGGL(mask_last_value_kernel, dim3((unsigned)((H * W + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), S, H, W, packed, values, out);
     CU_LAUNCH_CHECK();
     return 0;
 }

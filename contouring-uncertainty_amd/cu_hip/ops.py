@@ -484,7 +484,7 @@ def psm_condition(rec: Tensor, table: Tensor, nt: int, known: Tensor, per_rec: i
 
 
 def contour_masks(contours: Tensor, height: int, width: int, round_landmarks: bool = False, packed: bool = True,
-                  as_bytes: bool = True):
+                  as_bytes: bool = True, mode: int = 0):
     """contours (M, K, 2) f32 (x, y) pixels -> (packed (M, H, 8) int32 | None, masks (M, H, W) uint8 | None)  (cu_contour_masks)."""
     m, k, _ = contours.shape
     contours = contours.contiguous().float()
@@ -492,7 +492,7 @@ def contour_masks(contours: Tensor, height: int, width: int, round_landmarks: bo
     pk = torch.empty((m, height, 8), dtype=torch.int32, device=dev) if packed else None
     by = torch.empty((m, height, width), dtype=torch.uint8, device=dev) if as_bytes else None
     with _Prof("masks"):
-        L.check(L.load().cu_contour_masks(m, k, height, width, L.ptr(contours), int(round_landmarks), L.ptr(pk), L.ptr(by),
+        L.check(L.load().cu_contour_masks(m, k, height, width, L.ptr(contours), int(round_landmarks), int(mode), L.ptr(pk), L.ptr(by),
                                           L.stream_ptr()), "cu_contour_masks")
     return pk, by
 
@@ -508,6 +508,17 @@ def mask_entropy(packed: Tensor, frames: int, width: int, mean: bool = True, ent
         L.check(L.load().cu_mask_entropy(frames, ms // frames, h, width, L.ptr(packed), L.ptr(mo), L.ptr(eo),
                                          L.stream_ptr()), "cu_mask_entropy")
     return mo, eo
+
+
+def mask_last_value(packed: Tensor, width: int, values: Tensor) -> Tensor:
+    """packed (S, H, 8) int32, values (S,) f32 -> (H, W) f32: value of the last mask covering each pixel (cu_mask_last_value)."""
+    s_, h, _ = packed.shape
+    assert values.numel() == s_ and values.dtype == torch.float32
+    out = torch.empty((h, width), dtype=torch.float32, device=packed.device)
+    with _Prof("masks"):
+        L.check(L.load().cu_mask_last_value(s_, h, width, L.ptr(packed), L.ptr(values.contiguous()), L.ptr(out),
+                                            L.stream_ptr()), "cu_mask_last_value")
+    return out
 
 
 def mask_weighted_entropy(packed: Tensor, frames: int, width: int, weights: Tensor):

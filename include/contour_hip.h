@@ -253,19 +253,25 @@ int cu_skew_rvs(int M, int S, const float* mu, const float* sigma, const float* 
  *   1000 parameters, round, upper clip, closing line last -> first landmark, binary_fill_holes) of M contours
  *   [M][K][2] (x, y) in pixels, K <= 32, H, W <= 256.  round_landmarks != 0 rounds the landmarks first, as
  *   USContourToMask does (reference data/camus/utils.py:31-45).  Contours with duplicate consecutive landmarks or
- *   K < 4 use the raw landmarks, like the reference's bare `except`.  Outputs (either may be NULL): packed
+ *   K < 4 use the raw landmarks, like the reference's bare `except`.  mode 0 = the filled mask described above;
+ *   mode 1 = only the curve as `uncertainty_map` draws it (reference contour_uncertainty/utils/umap.py:24-31: 1001 spline
+ *   points clipped to the image on both sides + the line between the TRUNCATED end landmarks, no fill); mode 2 = mode 1
+ *   without that line.  Outputs (either may be NULL): packed
  *   [M][H][8] uint32 (bit x%32 of word x/32 = pixel (y, x)), bytes [M][H][W] of 0/1.
  * cu_mask_entropy: UncertaintyTask.sample_entropy (reference task/uncertainty.py:107-133) over the S packed masks of
  *   each of F frames (packed [F][S][H][8]): mean [F][H][W] and/or its base-2 binary entropy [F][H][W] (0 where the
  *   mean is 0 or 1).
  * ---------------------------------------------------------------------------------------------------------------- */
-int cu_contour_masks(int M, int K, int H, int W, const float* contours, int round_landmarks, uint32_t* packed,
+int cu_contour_masks(int M, int K, int H, int W, const float* contours, int round_landmarks, int mode, uint32_t* packed,
                      uint8_t* bytes, void* stream);
 int cu_mask_entropy(int F, int S, int H, int W, const uint32_t* packed, float* mean, float* entropy, void* stream);
 /* Weighted form for the skew-normal uncertainty map (reference contour_uncertainty/utils/skew_umap.py:74-79): mean =
  * sum_s weights[s] * mask_s (weights [S], normalised by the caller), entropy = natural-log binary entropy of the mean. */
 int cu_mask_weighted_entropy(int F, int S, int H, int W, const uint32_t* packed, const float* weights, float* mean,
                              float* entropy, void* stream);
+/* out [H][W] = values[s] of the last of the S packed masks that covers the pixel, 0 where none does: the sequential
+ * overwrites of `uncertainty_map` (reference contour_uncertainty/utils/umap.py:22-31). */
+int cu_mask_last_value(int S, int H, int W, const uint32_t* packed, const float* values, float* out, void* stream);
 
 #ifdef __cplusplus
 }

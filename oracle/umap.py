@@ -5,6 +5,8 @@
                                helpers of distributions/utils.py:38-75,132-150.  That module IS importable from the
                                reference; tests/golden/umap_projection.npz (oracle/make_golden.py umap) pins this
                                restatement to its outputs.
+  * ``uncertainty_map``        reference contour_uncertainty/utils/umap.py:10-33 (needs scikit-image: not importable); spline
+                               through oracle/masks.py ``contour_spline`` (1001 points), line = Bresenham.
   * ``skew_umap``              reference contour_uncertainty/utils/skew_umap.py:11-81 (needs scikit-image: not importable);
                                its 200 mask reconstructions go through oracle/masks.py.
 """
@@ -101,3 +103,18 @@ def skew_umap(mu, cov, alpha, linear_close=False):
     rec = np.array([M.reconstruction(c, 256, 256) for c in contours])
     m = np.average(rec, axis=0, weights=weights)
     return mode, scipy.stats.entropy(np.stack([m, 1 - m]), axis=0)
+
+
+def uncertainty_map(mu_p, cov_p, shape=(256, 256), close=True):
+    u, v = projected_uncertainty(mu_p, cov_p, every=True)
+    out = np.zeros(shape)
+    for i in np.linspace(-2, 2, 100):
+        mu = mu_p + v * u[..., None] * i
+        c = M.contour_spline(mu, close=False)
+        mi = mu.astype(int)
+        rr, cc = M._line(mi[-1, 1], mi[-1, 0], mi[0, 1], mi[0, 0])
+        c = c.round().astype(int).clip(max=255, min=0)
+        out[c[:, 1], c[:, 0]] = norm.pdf(i, loc=0, scale=1)
+        if close:
+            out[rr.clip(max=255, min=0), cc.clip(max=255, min=0)] = norm.pdf(i, loc=0, scale=1)
+    return out

@@ -47,3 +47,21 @@ def test_weighted_entropy_kernel():
     r = ref.double().clamp(1e-300, 1)
     e = -(torch.where(ref > 0, r * r.log(), torch.zeros_like(r)) + torch.where(ref < 1, (1 - r) * (1 - r).clamp_min(1e-300).log(), torch.zeros_like(r)))
     assert torch.allclose(ent[0].cpu().double(), e, atol=1e-5)
+
+
+@pytest.mark.parametrize("case,close", [(0, True), (1, True), (3, False)])
+def test_gaussian_uncertainty_map_matches_oracle(golden_dir, case, close):
+    from contour_uncertainty.data.camus.utils import USUMap
+    from contour_uncertainty.utils.umap import uncertainty_map
+    g = np.load(golden_dir / "umap_projection.npz")
+    mu, cov = g[f"c{case}_mu"], g[f"c{case}_cov"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = U.uncertainty_map(mu, cov, close=close)
+        got = uncertainty_map(mu, cov, close=close)
+        if close:
+            assert np.allclose(USUMap()(mu, cov, labels=[0, 1]), got / got.max())
+    assert got.shape == (256, 256) and (ref > 0).sum() > 2000
+    # identical up to a handful of pixels whose spline point sits within float32 rounding of a .5 / integer boundary
+    assert (np.abs(got - ref) > 1e-6).sum() <= 12
+    assert abs(got.max() - ref.max()) < 1e-6

@@ -36,12 +36,18 @@ mu, cov, alpha = mu.cuda(), cov.cuda(), alpha.cuda()
 
 
 def timeit(fn, reps=5):
-    fn(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    """median of `reps` synchronised calls after three warm-ups (the sequence samplers pick the first instant at random,
+    so a single warm-up does not touch both code paths)"""
+    for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps
+    ts = []
+    for _ in range(max(reps, 5)):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
 
 
 res = {"frames": F, "samples_per_frame": NS, "unit": "frames/s"}
@@ -58,6 +64,28 @@ res["sequence_gauss (1 ED/ES pair)"] = {"pairs_per_s": round(1 / dt, 2), "ms": r
 ss = SequenceSkewPSMSampler(psm_path, seq_path)
 dt = timeit(lambda: ss(pair_mu, cov[:2], alpha[:2], n=NS), reps=3)
 res["sequence_skew (1 ED/ES pair)"] = {"pairs_per_s": round(1 / dt, 2), "ms": round(dt * 1e3, 3)}
+
+# samples -> filled masks -> entropy map, device-resident end to end
+from cu_hip import ops
+from oracle import masks as MO
+
+
+def pipeline(sampler, *extra):
+    c = sampler.sample_batch(mu, cov, *extra, n=NS, seed=1)                     # (F, NS, 21, 2) on the device
+    packed, _ = ops.contour_masks(c.reshape(F * NS, 21, 2), 256, 256, round_landmarks=True, as_bytes=False)
+    return ops.mask_entropy(packed, F, 256)
+
+
+dt = timeit(lambda: pipeline(gs))
+res["gauss_psm + masks + entropy"] = {"frames_per_s": round(F / dt, 1), "ms": round(dt * 1e3, 3)}
+dt = timeit(lambda: pipeline(sk, alpha), reps=3)
+res["skew_psm + masks + entropy"] = {"frames_per_s": round(F / dt, 1), "ms": round(dt * 1e3, 3)}
+cs = gs.sample_batch(mu[:1], cov[:1], n=256, seed=1)[0].cpu().numpy()
+t0 = time.perf_counter()
+ms = np.stack([MO.us_contour_to_mask(cs[i]) for i in range(256)])
+MO.sample_entropy(ms[:, None].astype(float))
+dt = time.perf_counter() - t0
+res["cpu_oracle_masks_entropy"] = {"frames_per_s_at_S": round(1 / (dt / 256 * NS), 4), "sample": "1 frame x 256 samples, 1 core"}
 
 # CPU oracle on a bounded sample (1 frame, a few samples), same algorithm as the reference
 torch.set_num_threads(16)

@@ -843,7 +843,7 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
             nb = nn;
         }
     }
-    const int coltiles = cdiv(d->CO, 32 * nb);
+    int coltiles = cdiv(d->CO, 32 * nb);
     a.WP = 32 * nb + 2;
 
     int dymin = 1 << 20, dxmin = 1 << 20, dymax = -(1 << 20), dxmax = -(1 << 20);
@@ -857,6 +857,13 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
     //      enough work to keep every CU busy with 256-pixel tiles.
     const long total_px = (long)d->N * d->PH * d->PW;
     int ma = (bf && d->IS == 1 && d->ntaps == 9 && total_px / 256 * coltiles >= 512) ? 2 : 1;
+    // 256 pixels x 128 columns needs 8 accumulator tiles + staging registers per wave: that instance spills (220 bytes
+    // of scratch per lane) and runs 1.5x slower than two 64-column tiles (128^2 x 64->128: 452 vs 299 us)
+    if (ma == 2 && nb == 4 && (d->D0 == d->CO || d->D0 % 64 == 0)) {
+        nb = 2;
+        a.WP = 32 * nb + 2;
+        coltiles = cdiv(d->CO, 32 * nb);
+    }
     int tw = 0, th = 0, imgs = 0;
     for (;; ma = 1) {
         const int BM = 128 * ma;

@@ -18,6 +18,8 @@ def bench(fn, iters=10):
 cases = [(64, 32, 0, 32, 256, 1), (64, 32, 32, 32, 256, 1), (64, 64, 0, 64, 128, 1), (64, 128, 0, 128, 64, 1), (64, 256, 0, 256, 32, 1),
          (64, 480, 0, 480, 16, 1), (64, 480, 480, 480, 16, 1), (64, 32, 0, 64, 256, 2)]
 which = sys.argv[1] if len(sys.argv) > 1 else "conv"
+if len(sys.argv) > 2 and sys.argv[2] == "c64x128":
+    cases = [(64, 64, 0, 128, 128, 1)]
 if which in ("convT", "s2dgrad"):
     from cu_hip.engine import S2_PARITY_TAPS, _parity_taps
     for (n, ci, co, size) in [(64, 64, 32, 128), (64, 128, 64, 64), (64, 256, 128, 32), (64, 480, 256, 16)]:

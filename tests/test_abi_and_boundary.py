@@ -125,3 +125,25 @@ def test_validation_mask_and_dice_helpers():
     d = Dice(labels=[0, 1])
     assert d(m.astype(int)[None], m.astype(int)[None]) == 1.0
     assert contour_to_mask(c, (64, 64), apply_argmax=False).shape == (1, 64, 64)
+
+
+def test_mask_and_umap_paths_have_no_cpu_fallback():
+    """Rasterisation goes through cu_contour_masks or fails: no scipy fallback hides behind the drop-in functors; the
+    branches this build does not serve raise instead of returning something else."""
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    from contour_uncertainty.data.camus.utils import USContourToMask, USSkewUmap, USUMap
+    from contour_uncertainty.utils.contour import reconstruction
+    t = np.linspace(0, np.pi, 21)
+    c = np.stack([128 + 50 * np.cos(t), 170 - 80 * np.sin(t)], -1).astype(np.float32)
+    for call in (lambda: reconstruction(c, 256, 256), lambda: USContourToMask()(c, (256, 256), [0, 1]),
+                 lambda: USContourToMask.batch(c[None], (256, 256), [0, 1])):
+        with pytest.raises(Exception) as e:
+            call()
+        assert "CUDA" in str(e.value) or "cuda" in str(e.value) or "HIP" in str(e.value) or "GPU" in str(e.value)
+    # host-only pieces keep working without a GPU: linear reconstruction (validation Dice), projection
+    assert USContourToMask()(c, (256, 256), [0, 1], reconstruction_type="linear").sum() > 1000
+    for fn, args in ((USContourToMask(), (c, (256, 256), [0, 1, 2])), (USUMap(), (c, None, [0, 1, 2])),
+                     (USSkewUmap(), (c, None, None, [0, 1, 2]))):
+        with pytest.raises(NotImplementedError):
+            fn(*args)

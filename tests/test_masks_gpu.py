@@ -114,3 +114,32 @@ def test_masks_reject_bad_sizes():
         ops.contour_masks(torch.zeros(1, 40, 2).cuda(), 256, 256)
     with pytest.raises(ContourHipError):
         ops.contour_masks(torch.zeros(1, 21, 2).cuda(), 300, 256)
+
+
+def test_masks_edge_cases():
+    """Single contour, two / three landmarks (no spline possible), collinear landmarks, everything outside the image,
+    non-finite coordinates (must not fault: the reference would raise an IndexError there)."""
+    from cu_hip import ops
+    # K = 2 and K = 3: raw landmarks + closing line, like the reference's fallback
+    for k in (2, 3):
+        pts = np.array([[[10.2, 12.7], [40.1, 30.3], [22.0, 50.9]][:k]], dtype=np.float32)
+        _check(pts, 64, 64, False, max_px=0, min_exact=1.0)
+    # collinear, distinct landmarks: the spline is the segment, the closing line retraces it, nothing to fill
+    t = np.linspace(0, 1, 21, dtype=np.float32)
+    line = np.stack([20 + 200 * t, 30 + 150 * t], -1)[None]
+    by = _check(line, 256, 256, False, max_px=0, min_exact=1.0)
+    assert 150 < by.sum() < 700
+    # far outside the image on the high side: every point clips onto the last row / column
+    far = (_contour(1) + 400.0)[None]
+    _check(far, 256, 256, False, max_px=0, min_exact=1.0)
+    # NaN / inf: no fault, no pixel from the bad coordinates beyond the image
+    bad = _contour(2)[None].astype(np.float32)
+    bad[0, 3] = np.nan
+    bad[0, 7, 0] = np.inf
+    _, m = ops.contour_masks(torch.tensor(bad).cuda(), 256, 256)
+    torch.cuda.synchronize()
+    assert m.shape == (1, 256, 256) and int(m.max()) <= 1
+    # one sample per frame: entropy is zero everywhere, the mean is the mask
+    pk, m1 = ops.contour_masks(torch.tensor(_contour(3)[None], dtype=torch.float32).cuda(), 256, 256)
+    mean, ent = ops.mask_entropy(pk, 1, 256)
+    assert float(ent.abs().max()) == 0.0 and torch.equal(mean[0].cpu(), m1[0].float().cpu())

@@ -115,7 +115,8 @@ class _UNetFn(torch.autograd.Function):
         module.last_flat_grad = flat
         if module.flat_grad_hook is not None:
             module.flat_grad_hook(flat)
-        module.engine.backward(P, G, ctx.ectx, dlogits, dfeats)
+        with _lib.device_guard(dlogits):
+            module.engine.backward(P, G, ctx.ectx, dlogits, dfeats)
         ctx.ectx = None
         return (None, None) + tuple(G.get(n) for n in module._pnames)
 
@@ -189,10 +190,11 @@ class UNet(nn.Module):
         self.drop_block = drop_block
         self.mc_dropout = False     # True: Dropout2d stays active in eval mode (reference utils/mcdropout.py:89-137)
         if drop_block:
-            # reference unet2.py:129-136 (bottleneck) and :302 (`len(in_channels) - i <= 2`: the last two downsamples);
+            # reference unet2.py:129-136 (bottleneck) and :302: `len(in_channels) - i <= 2` where in_channels is
+            # filters[:-1] (unet2.py:123, nd + 1 entries for nd downsample blocks), i.e. ONLY the last downsample block;
             # both ConvLayers of a block get the Dropout2d (layers.py:231-232)
             nd = len(self.downsamples)
-            blocks = [f"downsamples.{i}" for i in range(nd) if nd - i <= 2] + ["bottleneck"]
+            blocks = [f"downsamples.{i}" for i in range(nd) if (nd + 1) - i <= 2] + ["bottleneck"]
             for b in blocks:
                 for li in ("conv1", "conv2"):
                     self.engine.drop_layers.add(f"{b}.{li}")
@@ -230,7 +232,10 @@ class UNet(nn.Module):
             raise _lib.ContourHipError("UNet.forward needs a device tensor: the HIP path has no CPU fallback")
         self._ensure_flat()
         params = [p for _, p in self.named_parameters()]
-        return _UNetFn.apply(self, input_data.float(), *params)
+        if params[0].device != input_data.device:
+            raise _lib.ContourHipError(f"input on {input_data.device}, parameters on {params[0].device}")
+        with _lib.device_guard(input_data):
+            return _UNetFn.apply(self, input_data.float(), *params)
 
 
 class _ConfidenceFn(torch.autograd.Function):
@@ -255,7 +260,8 @@ class _ConfidenceFn(torch.autograd.Function):
             G[n] = flat[off:off + p.numel()].view(p.shape)
             off += p.numel()
         module.last_flat_grad = flat
-        gin = module.engine.backward(P, G, ctx.ectx, gout, ctx.need_in)
+        with _lib.device_guard(gout):
+            gin = module.engine.backward(P, G, ctx.ectx, gout, ctx.need_in)
         ctx.ectx = None
         return (None, gin) + tuple(G[n] for n in module._pnames)
 
@@ -300,4 +306,5 @@ class ConfidenceNet(nn.Module):
                              f"{tuple(x.shape)}")
         self._ensure_flat()
         params = [p for _, p in self.named_parameters()]
-        return _ConfidenceFn.apply(self, x.float(), *params)
+        with _lib.device_guard(x):
+            return _ConfidenceFn.apply(self, x.float(), *params)

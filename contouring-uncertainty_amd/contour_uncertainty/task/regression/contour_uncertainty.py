@@ -64,6 +64,7 @@ class ContourUncertaintyTask(UncertaintyTask):
         self._bind_datamodule_fns()
 
     def on_fit_start(self):
+        super().on_fit_start()
         self._bind_datamodule_fns()
 
     def predict_step(self, batch: Any, batch_idx: int, dataloader_idx: int = 0):

@@ -47,6 +47,30 @@ class UncertaintyTask(SharedStepsTask):
                     import warnings
                     warnings.warn("No layer was modified by patch_module!", UserWarning)
 
+    def on_fit_start(self) -> None:
+        """``train_ensemble=True``: every ensemble member trains on its own random 90 % of the training set (reference
+        task/uncertainty.py:76-80 swaps the datamodule's TRAIN dataset for a ``torch.utils.data.Subset``)."""
+        if not self.hparams.get("train_ensemble"):
+            return
+        import random
+        from torch.utils.data import Subset as TorchSubset
+        dm = getattr(getattr(self, "trainer", None), "datamodule", None)
+        sets = getattr(dm, "_dataset", None)
+        if sets is None:
+            raise RuntimeError("train_ensemble=True needs trainer.datamodule._dataset (vital's VitalDataModule layout) to "
+                               "draw the member's 90 % training subset from")
+        key = next((k for k in sets if str(getattr(k, "value", k)).lower() == "train"), None)
+        if key is None:
+            raise RuntimeError("train_ensemble=True: the datamodule has no TRAIN subset")
+        full = sets[key]
+        keep = random.sample(range(len(full)), int(0.9 * len(full)))
+        sets[key] = TorchSubset(full, keep)
+
+    def on_fit_end(self) -> None:
+        logger = getattr(getattr(self, "trainer", None), "logger", None)
+        if logger is not None and hasattr(logger, "log_hyperparams"):
+            logger.log_hyperparams({"train_complete": True})          # reference task/uncertainty.py:82-83
+
     def forward(self, *args, **kwargs):  # noqa: D102
         return self.model(*args, **kwargs)
 

@@ -97,7 +97,21 @@ def prefix_ranges(names: Sequence[str], sizes: Sequence[int]) -> Dict[str, Tuple
 
 
 class GradSync:
-    """Wires a DSNT task's modules (``model`` and optionally ``skew_block``) to bucketed all-reduces."""
+    """Wires a DSNT task's modules (``model`` and optionally ``skew_block``) to bucketed all-reduces.
+
+    The modules' autograd nodes write every backward's gradients into ONE fresh flat buffer and return views of it;
+    when ``p.grad`` is ``None`` beforehand (``zero_grad(set_to_none=True)``, no gradient accumulation) autograd keeps
+    those views as ``p.grad``, so reducing the flat buffer IS reducing ``p.grad`` and the reduction can start while the
+    backward still runs (overlapped mode).  Whenever that does not hold -- ``zero_grad(set_to_none=False)``, Lightning's
+    ``accumulate_grad_batches > 1``, a hook that replaced a gradient -- autograd ADDS the views into older ``p.grad``
+    tensors: an in-flight in-place collective would race with that read and the sum would never reach the optimizer.
+    ``begin`` detects it (a used parameter already has a gradient) and switches this backward to deferred mode: nothing
+    is launched during the backward and ``finish`` packs the accumulated ``p.grad`` into the flat buffer, reduces it and
+    writes the sums back.  ``finish`` verifies the aliasing in overlapped mode and refuses to continue if it broke.
+
+    Gradient accumulation over micro-batches: set ``overlap = False`` (the Lightning glue does when
+    ``accumulate_grad_batches > 1``) and call ``finish`` once, after the last micro-batch's backward -- an overlapped
+    first micro-batch would otherwise be reduced twice."""
 
     def __init__(self, task, bucket_elems: int = 8 * 1024 * 1024, group=None):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -107,12 +121,15 @@ class GradSync:
         params = dict(self.model.named_parameters())
         names = list(self.model._used_names)
         sizes = [params[n].numel() for n in names]
+        self._used = [params[n] for n in names]
         self.ranges = prefix_ranges(names, sizes)
         self.bar = BucketedAllReduce(sum(sizes), bucket_elems, group)
+        self.overlap = True               # False: never reduce during a backward (gradient accumulation)
+        self.overlapped = False           # mode of the backward in flight
+        self.deferred_steps = 0           # statistics (tests): backwards that could not overlap
         if self.world > 1:      # a single rank has nothing to exchange: the engine then un-prepares all gradients at once
             self.model.engine.grad_ready_hook = self._ready
-            self.model.flat_grad_hook = self.bar.begin
-        self._skew_work = None
+            self.model.flat_grad_hook = self._begin
 
     def broadcast_parameters(self):
         """Rank 0's weights everywhere (same start as a single-GPU run)."""
@@ -124,17 +141,75 @@ class GradSync:
             sflat, _ = self.skew.flat_params()
             dist.broadcast(sflat, 0, group=self.group)
 
+    def _begin(self, flat: torch.Tensor):
+        if self.overlapped:
+            raise RuntimeError("GradSync: a second backward started before finish() consumed the first one; set "
+                               "overlap = False when accumulating gradients over micro-batches")
+        self.overlapped = self.overlap and all(p.grad is None for p in self._used)
+        if self.overlapped:
+            self.bar.begin(flat)
+        else:
+            self.deferred_steps += 1
+
     def _ready(self, prefix: str):
+        if not self.overlapped:
+            return
         lo, hi = self.ranges[prefix]
         self.bar.ready(lo, hi)
 
+    @staticmethod
+    def _aliased(plist, flat) -> bool:
+        """every p.grad is the view of ``flat`` at the parameter's offset"""
+        if flat is None:
+            return False
+        ptr = flat.data_ptr()
+        for p in plist:
+            g = p.grad
+            if g is None or g.data_ptr() != ptr or not g.is_contiguous() or g.dtype != flat.dtype:
+                return False
+            ptr += p.numel() * flat.element_size()
+        return ptr == flat.data_ptr() + flat.numel() * flat.element_size()
+
+    def _reduce_packed(self, plist, like: torch.Tensor):
+        """pack p.grad (missing gradients count as zero) -> one all-reduce -> write the sums back"""
+        plist = [p for p in plist]
+        total = sum(p.numel() for p in plist)
+        buf = torch.zeros(total, dtype=torch.float32, device=like.device)
+        off = 0
+        for p in plist:
+            if p.grad is not None:
+                buf[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            off += p.numel()
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for p in plist:
+            if p.grad is None:
+                p.grad = buf[off:off + p.numel()].view(p.shape)
+            else:
+                p.grad.copy_(buf[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+
     def finish(self):
-        """Call after ``loss.backward()`` and before the optimizer step."""
+        """Call after ``loss.backward()`` (of the LAST micro-batch when accumulating) and before the optimizer step."""
         if self.world == 1:
             return
-        if self.skew is not None and self.skew.last_flat_grad is not None and self.world > 1:
-            dist.all_reduce(self.skew.last_flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-        self.bar.finish()
+        if self.skew is not None:
+            splist = [p for _, p in self.skew.named_parameters()]
+            if any(p.grad is not None for p in splist):
+                if self._aliased(splist, self.skew.last_flat_grad):
+                    dist.all_reduce(self.skew.last_flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    self._reduce_packed(splist, splist[0])
+        if self.overlapped:
+            self.bar.finish()
+            self.overlapped = False
+            if not self._aliased(self._used, self.model.last_flat_grad):
+                raise RuntimeError(
+                    "GradSync: the gradients were all-reduced in the flat buffer of this backward, but p.grad no longer "
+                    "aliases it (a hook or a second backward replaced the gradients): the reduced values would not reach "
+                    "the optimizer.  Call finish() right after the backward it belongs to.")
+        else:
+            self._reduce_packed(self._used, self._used[0])
 
     @property
     def grad_scale(self) -> float:

@@ -94,8 +94,8 @@ class UNetEngine:
         # True: one streaming pass materialises LeakyReLU(InstanceNorm(z)) per layer and every consumer stages a plain
         # operand; False: consumers recompute it in their operand load (less HBM traffic, but VALU-bound thin layers)
         self.materialize = True
-        # Dropout2d(p=0.5) between conv and norm in the listed ConvLayers (reference unet2.py:129-136,302: the last two
-        # downsample blocks and the bottleneck when task.model.drop_block=True); active in training mode only
+        # Dropout2d(p=0.5) between conv and norm in the listed ConvLayers (reference unet2.py:129-136,302: the last
+        # downsample block and the bottleneck when task.model.drop_block=True); active in training mode only
         self.drop_layers: set = set()
         self.drop_p = 0.5
         self.drop_mask_fn: Optional[Callable[[str, int, int, torch.device], Tensor]] = None   # tests inject masks

@@ -23,9 +23,10 @@ class _DsntNllFn(torch.autograd.Function):
     def forward(ctx, logits: Tensor, y: Tensor, alpha: Optional[Tensor], covar: bool, w_mse: float, w_log: float):
         logits = logits.contiguous()
         need_grad = logits.requires_grad or (alpha is not None and alpha.requires_grad)
-        mu, sigma, aux = ops.dsnt_head_fwd(logits, covar)
-        al = alpha.contiguous().float() if alpha is not None else None
-        logs, gmu, gsigma, galpha = ops.nll_fwd_bwd(mu, sigma, y.contiguous().float(), al, w_mse, w_log, need_grad)
+        with ops.L.device_guard(logits):
+            mu, sigma, aux = ops.dsnt_head_fwd(logits, covar)
+            al = alpha.contiguous().float() if alpha is not None else None
+            logs, gmu, gsigma, galpha = ops.nll_fwd_bwd(mu, sigma, y.contiguous().float(), al, w_mse, w_log, need_grad)
         ctx.covar = covar
         ctx.has_alpha = alpha is not None
         if need_grad:
@@ -37,7 +38,8 @@ class _DsntNllFn(torch.autograd.Function):
     def backward(ctx, gloss, _glogs, _gmu, _gsigma):
         logits, aux, gmu, gsigma, galpha = ctx.saved_tensors
         scale = gloss.reshape(1)
-        dl = ops.dsnt_head_bwd(logits, aux, (gmu * scale).contiguous(), (gsigma * scale).contiguous(), ctx.covar)
+        with ops.L.device_guard(logits):
+            dl = ops.dsnt_head_bwd(logits, aux, (gmu * scale).contiguous(), (gsigma * scale).contiguous(), ctx.covar)
         dalpha = (galpha * scale) if ctx.has_alpha else None
         return dl, None, dalpha, None, None, None
 

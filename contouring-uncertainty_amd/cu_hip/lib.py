@@ -118,8 +118,25 @@ def check(rc: int, what: str = ""):
         raise ContourHipError(f"{what} failed ({rc}): {msg}")
 
 
+_first_operand = [None]      # first tensor handed to ptr() since the last stream_ptr(): one device check per launch
+
+
 def stream_ptr() -> int:
+    """The current HIP stream of the CURRENT device: kernels launch on the thread's current device, so the operands
+    must live there (checked here on the first operand of the call -- the wrappers allocate every output on that
+    operand's device; ``device_guard`` makes an operand's device current)."""
+    t, _first_operand[0] = _first_operand[0], None
+    if t is not None and t.device.index != torch.cuda.current_device():
+        raise ContourHipError(f"operand on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                              "launches go to the current device's stream (use torch.cuda.set_device / "
+                              "cu_hip.lib.device_guard)")
     return torch.cuda.current_stream().cuda_stream
+
+
+def device_guard(t):
+    """Context manager that makes ``t``'s device the current one for the launches inside (a module moved with
+    ``.to('cuda:1')`` while cuda:0 is current would otherwise enqueue its kernels on the wrong GPU and stream)."""
+    return torch.cuda.device(t.device)
 
 
 def ptr(t):
@@ -130,6 +147,8 @@ def ptr(t):
         raise ContourHipError("HIP kernels need device tensors (no CPU fallback)")
     if not t.is_contiguous():
         raise ContourHipError("HIP kernels need contiguous tensors")
+    if _first_operand[0] is None:
+        _first_operand[0] = t
     return t.data_ptr()
 
 

@@ -1,4 +1,4 @@
-"""Fused Adam on the HIP kernel, with ``torch.optim.Adam`` semantics.
+"""Fused Adam on the HIP kernel, with ``torch.optim.Adam`` semantics AND ``torch.optim.Adam`` state layout.
 
 Replaces ``torch.optim.Adam(lr=1e-3, weight_decay=1e-3)`` instantiated by ``VitalSystem.configure_optimizers``
 (reference vital/vital/system.py:82-115, vital/vital/config/task/optim/adam.yaml:1-4): L2 weight decay folded into the
@@ -6,15 +6,25 @@ gradient, bias-corrected first/second moments, parameters whose ``.grad`` is Non
 ``deep_supervision_heads`` tensors never move, as in the reference).
 
 Parameters that live back-to-back in one flat buffer (``UNet.flat_params``) with back-to-back gradients are updated
-by ONE kernel launch per run.
+by ONE kernel launch per run.  The optimizer state is nevertheless PER PARAMETER (``state[p] = {"step", "exp_avg",
+"exp_avg_sq"}`` like ``torch.optim.Adam``): the moments of a run live in one flat buffer and every parameter's entry is
+a view into it, so ``state_dict()`` / ``load_state_dict()`` interchange with ``torch.optim.Adam`` (a Lightning resume,
+an ``optimizer_states`` entry of a reference checkpoint).  After a ``load_state_dict`` -- or a re-flatten / ``.to()`` --
+the loaded per-parameter tensors are no longer views of one buffer: the flat moments are then REBUILT from them (never
+silently zeroed).
 """
 from __future__ import annotations
 
-from typing import List
+from typing import Dict, List, Tuple
 
 import torch
 
 from . import ops
+
+
+def _step_of(st) -> int:
+    s = st.get("step", 0)
+    return int(s.item()) if torch.is_tensor(s) else int(s)
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -23,6 +33,9 @@ class FusedAdam(torch.optim.Optimizer):
             raise NotImplementedError("amsgrad is not used by the reference config")
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
+        # flat moment buffers per run, keyed by the run's first parameter (NOT part of state_dict: the per-parameter
+        # views in self.state are)
+        self._flat: Dict[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]] = {}
 
     @staticmethod
     def _runs(params: List[torch.Tensor]):
@@ -46,6 +59,56 @@ class FusedAdam(torch.optim.Optimizer):
             runs.append(cur)
         return runs
 
+    def _split_by_step(self, run: List[torch.Tensor]):
+        """A fused launch shares one bias correction: split a memory run where the per-parameter step counts differ
+        (parameters that had no gradient in some earlier step)."""
+        out, cur, cur_step = [], [], None
+        for p in run:
+            s = _step_of(self.state[p]) if p in self.state else 0
+            if cur and s != cur_step:
+                out.append(cur)
+                cur = []
+            cur.append(p)
+            cur_step = s
+        if cur:
+            out.append(cur)
+        return out
+
+    def _moments(self, run: List[torch.Tensor]):
+        """(flat exp_avg, flat exp_avg_sq) of a run with every parameter's state entry a view into them."""
+        first = run[0]
+        n = sum(p.numel() for p in run)
+        flat = self._flat.get(first)
+        ok = flat is not None and flat[0].numel() == n and flat[0].device == first.device
+        if ok:
+            off = 0
+            base_m, base_v = flat[0].data_ptr(), flat[1].data_ptr()
+            for p in run:
+                st = self.state.get(p)
+                if (st is None or "exp_avg" not in st or st["exp_avg"].data_ptr() != base_m + 4 * off
+                        or st["exp_avg_sq"].data_ptr() != base_v + 4 * off):
+                    ok = False
+                    break
+                off += p.numel()
+        if ok:
+            return flat
+        # (re)build: keep whatever per-parameter state exists (fresh start: zeros)
+        m = torch.zeros(n, dtype=torch.float32, device=first.device)
+        v = torch.zeros(n, dtype=torch.float32, device=first.device)
+        off = 0
+        for p in run:
+            st = self.state[p]
+            k = p.numel()
+            if "exp_avg" in st:
+                m[off:off + k].copy_(st["exp_avg"].detach().reshape(-1).to(m))
+                v[off:off + k].copy_(st["exp_avg_sq"].detach().reshape(-1).to(v))
+            st["step"] = torch.tensor(float(_step_of(st)))
+            st["exp_avg"] = m[off:off + k].view(p.shape)
+            st["exp_avg_sq"] = v[off:off + k].view(p.shape)
+            off += k
+        self._flat[first] = (m, v)
+        return m, v
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         loss = None
@@ -54,21 +117,16 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         for group in self.param_groups:
             b1, b2 = group["betas"]
-            for run in self._runs(group["params"]):
-                first = run[0]
-                n = sum(p.numel() for p in run)
-                key = (first.data_ptr(), n)
-                st = self.state[first]
-                if st.get("key") != key:
-                    # (re)allocate the moments for this run; carry over per-parameter state if the run changed shape
-                    st.clear()
-                    st["key"] = key
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros(n, dtype=torch.float32, device=first.device)
-                    st["exp_avg_sq"] = torch.zeros(n, dtype=torch.float32, device=first.device)
-                st["step"] += 1
-                pflat = torch.as_strided(first.data, (n,), (1,))
-                gflat = torch.as_strided(first.grad, (n,), (1,))
-                ops.adam_step(pflat, gflat, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"],
-                              group["weight_decay"], st["step"], grad_scale)
+            for mem_run in self._runs(group["params"]):
+                for run in self._split_by_step(mem_run):
+                    first = run[0]
+                    n = sum(p.numel() for p in run)
+                    m, v = self._moments(run)
+                    step = _step_of(self.state[first]) + 1
+                    for p in run:
+                        self.state[p]["step"] += 1
+                    pflat = torch.as_strided(first.data, (n,), (1,))
+                    gflat = torch.as_strided(first.grad, (n,), (1,))
+                    ops.adam_step(pflat, gflat, m, v, group["lr"], b1, b2, group["eps"], group["weight_decay"], step,
+                                  grad_scale)
         return loss

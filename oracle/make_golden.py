@@ -264,6 +264,13 @@ def gen_step():
             if it == 0:
                 out[f"{task}_mu0"] = npy(mu)
                 out[f"{task}_sigma0"] = npy(S)
+                if task == "dsnt-skew":
+                    # raw head output of the step (dsnt_skew.py:68-71, skew_indices = all 21) and what predict_on_batch
+                    # returns for the same weights: alpha_y negated (dsnt_skew.py:164)
+                    out["dsnt-skew_alpha0"] = npy(alpha)
+                    a_pred = alpha.detach().clone()
+                    a_pred[..., 1] = -a_pred[..., 1]
+                    out["dsnt-skew_alpha0_predict"] = npy(a_pred)
                 gn, gs = [], []
                 for m, pre in zip(mods, ("model.", "skew_block.")):
                     for name, p in m.named_parameters():
@@ -406,11 +413,24 @@ def gen_umap():
     np.savez_compressed(OUT / "umap_projection.npz", **out)
 
 
+def gen_drop():
+    """Which ConvLayers carry a Dropout2d when task.model.drop_block=True (reference unet2.py:129-136,302; layers.py
+    196-202): read off the instantiated reference modules for the 6-stage (config c1) and 8-stage (unet2.yaml) nets."""
+    import json
+    from contour_uncertainty.models.nnUnet.unet2 import UNet
+    res = {}
+    for n in (4, 6, 8):
+        net = UNet((1, 0, 0), (21, 0, 0), [256, 256], [[3, 3]] * n, [[1, 1]] + [[2, 2]] * (n - 1), drop_block=True)
+        res[str(n)] = sorted(name for name, m in net.named_modules() if getattr(m, "use_drop_block", False)
+                             and hasattr(m, "conv") and not hasattr(m, "conv1"))
+    (OUT / "drop_block_layers.json").write_text(json.dumps(res, indent=1) + "\n")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dsnt", "nll", "unet_small", "unet_full", "step", "psm", "skew_grid", "umap"]
+    which = sys.argv[1:] or ["dsnt", "nll", "unet_small", "unet_full", "step", "psm", "skew_grid", "umap", "drop"]
     for w in which:
         print("generating", w, flush=True)
         {"dsnt": gen_dsnt, "nll": gen_nll, "unet_small": gen_unet_small, "unet_full": gen_unet_full,
-         "step": gen_step, "psm": gen_psm, "skew_grid": gen_skew_grid, "umap": gen_umap}[w]()
+         "step": gen_step, "psm": gen_psm, "skew_grid": gen_skew_grid, "umap": gen_umap, "drop": gen_drop}[w]()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)

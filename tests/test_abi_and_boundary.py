@@ -97,6 +97,23 @@ def test_unsupported_reference_options_are_refused_not_ignored():
             UNet((1, 64, 64), (21, 1, 64), [256, 256], [[3, 3]] * 6, [[1, 1]] + [[2, 2]] * 5, **kw)
 
 
+def test_drop_block_layer_set_matches_reference(golden_dir):
+    """task.model.drop_block=True: the ConvLayers that get a Dropout2d are exactly the ones the instantiated reference
+    module flags (tests/golden/drop_block_layers.json, written by oracle/make_golden.py `drop` from the reference's
+    use_drop_block attributes; unet2.py:302 selects only the last downsample block, :129-136 the bottleneck)."""
+    import json
+    from contour_uncertainty.models.nnUnet.unet2 import UNet
+    ref = json.loads((golden_dir / "drop_block_layers.json").read_text())
+    for n, layers in ref.items():
+        n = int(n)
+        net = UNet((1, 64, 64), (21, 1, 64), [256, 256], [[3, 3]] * n, [[1, 1]] + [[2, 2]] * (n - 1), drop_block=True)
+        assert sorted(net.engine.drop_layers) == layers
+        flagged = sorted(name for name, m in net.named_modules() if getattr(m, "use_drop_block", False))
+        assert flagged == layers
+    plain = UNet((1, 64, 64), (21, 1, 64), [256, 256], [[3, 3]] * 6, [[1, 1]] + [[2, 2]] * 5, drop_block=False)
+    assert not plain.engine.drop_layers
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly when there is no GPU (or the tensor is not on it)."""
     from cu_hip.lib import ContourHipError
@@ -147,3 +164,42 @@ def test_mask_and_umap_paths_have_no_cpu_fallback():
                      (USSkewUmap(), (c, None, None, [0, 1, 2]))):
         with pytest.raises(NotImplementedError):
             fn(*args)
+
+
+def test_train_ensemble_takes_a_random_90_percent_subset():
+    """reference task/uncertainty.py:76-80: on_fit_start swaps the TRAIN dataset for a 90 % random Subset; a missing
+    datamodule is an error, not a silent no-op."""
+    import random
+    from enum import Enum
+    from torch.utils.data import Subset as TorchSubset
+
+    class Sub(Enum):
+        TRAIN = "train"
+        VAL = "val"
+
+    class DM:
+        def __init__(self):
+            self._dataset = {Sub.TRAIN: list(range(50)), Sub.VAL: list(range(7))}
+            self.umap_fn = self.contour_to_mask_fn = self.skew_umap_fn = staticmethod(lambda *a, **k: None)
+
+    class Trainer:
+        datamodule = DM()
+        logger = None
+
+    task = _task("dsnt-al")
+    task.hparams.train_ensemble = True
+    task.trainer = Trainer()
+    random.seed(3)
+    task.on_fit_start()
+    sub = Trainer.datamodule._dataset[Sub.TRAIN]
+    assert isinstance(sub, TorchSubset) and len(sub) == 45 and len(set(sub.indices)) == 45
+    assert len(Trainer.datamodule._dataset[Sub.VAL]) == 7
+    task2 = _task("dsnt-al")
+    task2.hparams.train_ensemble = True
+    with pytest.raises(RuntimeError):
+        task2.on_fit_start()
+    task3 = _task("dsnt-al")            # default: untouched
+    task3.trainer = Trainer()
+    before = Trainer.datamodule._dataset[Sub.TRAIN]
+    task3.on_fit_start()
+    assert Trainer.datamodule._dataset[Sub.TRAIN] is before

@@ -109,3 +109,141 @@ def test_single_rank_needs_no_process_group():
     bar.finish()
     assert sorted(bar.launched) == [(0, 2), (2, 6), (6, 10)]
     assert torch.equal(flat, torch.arange(10.0))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GradSync on a stand-in module that hands gradients over exactly like UNet's autograd node does (views of one fresh
+# flat buffer per backward, flat_grad_hook at the start, grad_ready_hook per layer): the aliasing invariant, the
+# zero_grad(set_to_none=False) case and gradient accumulation.
+class _FlatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        ctx.module = module
+        ctx.save_for_backward(x, *params)
+        return sum((p * p).sum() for p in params) * x.sum()
+
+    @staticmethod
+    def backward(ctx, gout):
+        module = ctx.module
+        x, *params = ctx.saved_tensors
+        flat = torch.zeros(sum(p.numel() for p in params))
+        module.last_flat_grad = flat
+        if module.flat_grad_hook is not None:
+            module.flat_grad_hook(flat)
+        views, off = [], 0
+        for p in params:
+            views.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        for name, p, v in reversed(list(zip(module._used_names, params, views))):     # decoder first
+            v.copy_(2 * p * x.sum() * gout)
+            if module.engine.grad_ready_hook is not None:
+                module.engine.grad_ready_hook(name.rsplit(".", 1)[0])
+        return (None, None) + tuple(views)
+
+
+class _Engine:
+    grad_ready_hook = None
+
+
+class _FlatModule(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        self.a = torch.nn.Linear(5, 7)
+        self.b = torch.nn.Linear(7, 3)
+        for p in self.parameters():
+            p.data = torch.randn(p.shape, generator=g)
+        self._used_names = [n for n, _ in self.named_parameters()]
+        self.engine = _Engine()
+        self.flat_grad_hook = None
+        self.last_flat_grad = None
+
+    def flat_params(self):
+        return torch.cat([p.data.reshape(-1) for p in self.parameters()]), self.last_flat_grad
+
+    def forward(self, x):
+        return _FlatFn.apply(self, x, *self.parameters())
+
+
+class _Task:
+    def __init__(self):
+        self.model = _FlatModule()
+
+
+def _sync_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cu_hip.ddp import GradSync
+        xs = [torch.full((2,), 1.0 + r + 10 * k) for k in range(2) for r in range(world)]   # micro-batch k of rank r
+        x = lambda k: xs[k * world + rank]                                                  # noqa: E731
+
+        def expected(task, ks):
+            tot = sum(float(xs[k * world + r].sum()) for k in ks for r in range(world))
+            return [2 * p.detach() * tot for p in task.model.parameters()]
+
+        res = {}
+        # (a) overlapped: p.grad is None before the backward
+        task = _Task()
+        sync = GradSync(task, bucket_elems=16)
+        task.model(x(0)).backward()
+        assert sync.overlapped and sync._aliased(sync._used, task.model.last_flat_grad)
+        sync.finish()
+        res["overlapped"] = all(torch.allclose(p.grad, e) for p, e in zip(task.model.parameters(), expected(task, [0])))
+        res["buckets"] = len(sync.bar.launched)
+        # (b) zero_grad(set_to_none=False): autograd accumulates into the old tensors -> deferred mode, same result
+        for p in task.model.parameters():
+            p.grad.zero_()
+        task.model(x(1)).backward()
+        assert not sync.overlapped and sync.deferred_steps == 1
+        sync.finish()
+        res["deferred"] = all(torch.allclose(p.grad, e) for p, e in zip(task.model.parameters(), expected(task, [1])))
+        # (c) gradient accumulation over two micro-batches, one finish()
+        task = _Task()
+        sync = GradSync(task, bucket_elems=16)
+        sync.overlap = False
+        task.model(x(0)).backward()
+        task.model(x(1)).backward()
+        sync.finish()
+        res["accumulated"] = all(torch.allclose(p.grad, e) for p, e in zip(task.model.parameters(), expected(task, [0, 1])))
+        # (d) a second overlapped backward without finish() is refused, not silently mis-reduced
+        task = _Task()
+        sync = GradSync(task, bucket_elems=16)
+        task.model(x(0)).backward()
+        try:
+            for p in task.model.parameters():
+                p.grad = None
+            task.model(x(1)).backward()
+            res["refused"] = False
+        except RuntimeError as e:
+            res["refused"] = "finish()" in str(e)
+        sync.bar.finish()
+        # (e) gradients replaced between backward and finish(): detected
+        task = _Task()
+        sync = GradSync(task, bucket_elems=16)
+        task.model(x(0)).backward()
+        for p in task.model.parameters():
+            p.grad = p.grad.clone()
+        try:
+            sync.finish()
+            res["alias_checked"] = False
+        except RuntimeError as e:
+            res["alias_checked"] = "aliases" in str(e)
+        ret[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_sync_invariants_two_ranks_gloo():
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sync_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert len(ret) == 2
+    for rank in (0, 1):
+        r = ret[rank]
+        assert r["overlapped"] and r["buckets"] >= 2, r
+        assert r["deferred"], "zero_grad(set_to_none=False): the reduced sum did not reach p.grad"
+        assert r["accumulated"], "accumulate_grad_batches: wrong sum"
+        assert r["refused"] and r["alias_checked"], r

@@ -154,8 +154,17 @@ def test_predict_mu_sigma_alpha_vs_reference_golden(golden_dir, kind):
     mu_ref, sig_ref = T(g[f"{kind}_mu0"]), T(g[f"{kind}_sigma0"])
     assert float((out[0].cpu() - mu_ref).abs().max() / mu_ref.abs().max()) < 1e-4
     assert float((out[1].cpu() - sig_ref).abs().max() / sig_ref.abs().max()) < 1e-4
-    S, cov = task.predict(img.to(DEV))[:2]
+    res = task.predict(img.to(DEV))
+    S, cov = res[:2]
     assert S.shape == (2, 1, 21, 2) and cov.shape == (2, 1, 21, 2, 2) and not S.is_cuda
+    if kind == "dsnt-skew":
+        # alpha of predict_on_batch: the reference's raw head output with alpha_y negated (dsnt_skew.py:164), 1e-4
+        a_ref = T(g["dsnt-skew_alpha0_predict"])
+        assert float((out[2].cpu() - a_ref).abs().max() / a_ref.abs().max()) < 1e-4
+        assert torch.equal(T(g["dsnt-skew_alpha0"])[..., 0], a_ref[..., 0])
+        assert torch.equal(T(g["dsnt-skew_alpha0"])[..., 1], -a_ref[..., 1])
+        assert res[2].shape == (2, 1, 21, 2)
+        assert float((res[2][:, 0] - a_ref).abs().max() / a_ref.abs().max()) < 1e-4
 
 
 def test_full_size_forward_vs_reference_golden(golden_dir):
@@ -257,8 +266,10 @@ def test_oracle_vs_hip_larger_batch():
 
 
 def test_drop_block_matches_oracle_with_shared_masks():
-    """task.model.drop_block=True (tmi_scripts/train.sh:9): Dropout2d between conv and norm in the last two downsample
-    blocks and the bottleneck, training mode only.  Same channel masks on both sides -> same loss and gradients."""
+    """task.model.drop_block=True (tmi_scripts/train.sh:9): Dropout2d between conv and norm in the LAST downsample block
+    and the bottleneck (reference unet2.py:302 with in_channels = filters[:-1]; the flagged layer names are pinned by
+    tests/golden/drop_block_layers.json, generated from the imported reference), training mode only.  Same channel masks
+    on both sides -> same loss and gradients."""
     from contour_uncertainty.models.nnUnet.unet2 import UNet
     spec = OU.UNetSpec(strides=(1, 2, 2, 2, 2, 2))
     gen = torch.Generator().manual_seed(4)
@@ -268,8 +279,8 @@ def test_drop_block_matches_oracle_with_shared_masks():
                compute_dtype="f32")
     net.load_state_dict(sd, strict=True)
     net = net.to(DEV)
-    assert sorted(net.engine.drop_layers) == ["bottleneck.conv1", "bottleneck.conv2", "downsamples.2.conv1",
-                                              "downsamples.2.conv2", "downsamples.3.conv1", "downsamples.3.conv2"]
+    assert sorted(net.engine.drop_layers) == ["bottleneck.conv1", "bottleneck.conv2", "downsamples.3.conv1",
+                                              "downsamples.3.conv2"]
     masks = {}
 
     def mask_fn(prefix, n, c, device):
@@ -291,7 +302,7 @@ def test_drop_block_matches_oracle_with_shared_masks():
     ref["loss"].backward()
     assert abs(float(logs["loss"]) - float(ref["loss"])) < 2e-4 * abs(float(ref["loss"]))
     params = dict(net.named_parameters())
-    for name in ("downsamples.3.conv1.conv.weight", "bottleneck.conv2.conv.weight", "downsamples.2.conv2.norm.weight",
+    for name in ("downsamples.3.conv1.conv.weight", "bottleneck.conv2.conv.weight", "downsamples.3.conv2.norm.weight",
                  "input_block.conv1.conv.weight", "upsamples.0.transp_conv.weight"):
         a, b = params[name].grad.cpu(), sdr[name].grad
         assert float((a - b).norm() / b.norm()) < 5e-4, name

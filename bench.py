@@ -54,16 +54,16 @@ def build_task(size: int, dtype: str, task_name: str):
 
 def conv_flops_per_image(n_stages: int, size: int):
     """Algorithmic conv FLOPs of one training step per image: fwd + dgrad + wgrad,
-    no dgrad for the first conv."""
-    from oracle.unet import UNetSpec, conv_macs_per_image
-    spec = UNetSpec(strides=tuple([1] + [2] * (n_stages - 1)))
-    m = conv_macs_per_image(spec, size)
-    return 2.0 * (3.0 * m["fwd"] - m["first_conv"]), 2.0 * m["fwd"]
+    no dgrad for the first conv (counted from the layer list, cu_hip/flops.py)."""
+    from cu_hip.flops import train_step_flops_per_image
+    return train_step_flops_per_image([1] + [2] * (n_stages - 1), size)
 
 
 def cpu_baseline(size: int, n_stages: int, task_name: str, batch: int, steps: int):
-    """The oracle's training step (op-for-op the reference on PyTorch-CPU) on the host cores."""
-    from oracle.step import OracleTask, synthetic_batch
+    """The oracle's training step (op-for-op the reference on PyTorch-CPU) on the host cores.  The ONLY place where
+    bench.py touches oracle/ (as the thing timed beside the product, never as part of it)."""
+    from contour_uncertainty.data.synthetic import synthetic_batch
+    from oracle.step import OracleTask
     from oracle.unet import UNetSpec
     # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() would report the whole host
     try:
@@ -117,7 +117,7 @@ def main():
 
     from cu_hip import ops
     from cu_hip.ddp import GradSync
-    from oracle.step import synthetic_batch   # input generator only (SURVEY 8d synthetic inputs)
+    from contour_uncertainty.data.synthetic import synthetic_batch   # SURVEY 8d synthetic inputs
 
     task_name = "dsnt-al" if args.task == "dsnt-al2" else args.task
     task, n_stages = build_task(args.size, args.dtype, task_name)

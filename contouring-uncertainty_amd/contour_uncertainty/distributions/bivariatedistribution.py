@@ -37,6 +37,13 @@ class BivariateDistribution:
         return matrix[:, 0, 0] * matrix[:, 1, 1] - matrix[:, 0, 1] * matrix[:, 1, 0]
 
 
+def _frame_axis(angle, axis: int):
+    """unit vector of coordinate ``axis`` (0 | 1) of the frame turned by ``angle`` -> numpy (2,)"""
+    import numpy as np
+    a = float(angle)
+    return np.array([np.cos(a), np.sin(a)]) if axis == 0 else np.array([-np.sin(a), np.cos(a)])
+
+
 def _sigma3(cov: torch.Tensor) -> torch.Tensor:
     return torch.stack([cov[..., 0, 0], cov[..., 1, 1], cov[..., 1, 0]], -1).float().contiguous()
 

@@ -1,9 +1,11 @@
 """``BivariateNormal`` on the HIP kernels (reference distributions/bivariatenormal.py:12-90)."""
 from __future__ import annotations
 
+import numpy as np
 import torch
 
-from contour_uncertainty.distributions.bivariatedistribution import BivariateDistribution, _device_logpdf, _sigma3
+from contour_uncertainty.distributions.bivariatedistribution import (BivariateDistribution, _device_logpdf, _frame_axis,
+                                                                       _sigma3)
 
 
 class BivariateNormal(BivariateDistribution):
@@ -30,12 +32,13 @@ class BivariateNormal(BivariateDistribution):
 
     @classmethod
     def marginal(cls, mu, cov, axis: int, angle=torch.tensor(0), *args, **kwargs):
-        """(mean, variance) of the marginal along ``axis`` after rotating the covariance by -angle (reference :69-86);
-        host code of the u-map post-processing."""
-        from contour_uncertainty.distributions.utils import rotate_cov
+        """(mean, variance) of the 1-D marginal along coordinate ``axis`` of the frame turned by ``angle`` (boundary:
+        reference :69-86).  The variance along a unit vector e is the quadratic form e^T cov e; no rotated matrix is
+        built (``utils.uncertainty_projection.normal_frame_moments`` does the same for K landmarks at once)."""
         assert axis == 0 or axis == 1
-        cov = rotate_cov(cov, -angle)
-        return mu[axis], cov[axis, axis]
+        from contour_uncertainty.utils.uncertainty_projection import normal_frame_moments
+        var, _ = normal_frame_moments(np.asarray(cov, dtype=np.float64)[None], _frame_axis(angle, axis)[None])
+        return mu[axis], torch.tensor(var[0], dtype=torch.float32)
 
     @classmethod
     def rvs(cls, mu, cov, size=(1,)):

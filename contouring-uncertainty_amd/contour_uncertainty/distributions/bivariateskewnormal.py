@@ -1,14 +1,16 @@
 """``BivariateSkewNormal`` on the HIP kernels (reference distributions/bivariateskewnormal.py:16-191).
 
-logpdf / pdf / nll / affine / unit_normal_logcdf / rvs_fast keep the reference's signatures.  ``mode``, ``marginal`` and
-the plotting helpers are analysis utilities outside the accelerated path."""
+logpdf / pdf / nll / affine / unit_normal_logcdf / rvs_fast keep the reference's signatures.  ``mode`` / ``marginal`` are
+host-side analysis helpers of the u-map post-processing; the plotting helpers are out of scope."""
 from __future__ import annotations
 
 import math
 
+import numpy as np
 import torch
 
-from contour_uncertainty.distributions.bivariatedistribution import BivariateDistribution, _device_logpdf, _sigma3
+from contour_uncertainty.distributions.bivariatedistribution import (BivariateDistribution, _device_logpdf, _frame_axis,
+                                                                       _sigma3)
 
 
 class BivariateSkewNormal(BivariateDistribution):
@@ -35,22 +37,28 @@ class BivariateSkewNormal(BivariateDistribution):
 
     @classmethod
     def marginal(cls, mu, cov, alpha, axis: int, angle=torch.tensor(0), *args, **kwargs):
-        """(location, variance, skewness) of the marginal along ``axis`` after rotating by -angle (reference
-        distributions/bivariateskewnormal.py:92-135; the y component of alpha is negated first, as there)."""
-        from contour_uncertainty.distributions.utils import cov2corr, rotate_alpha, rotate_cov
+        """(location, variance, skewness) of the 1-D marginal along coordinate ``axis`` of the frame turned by ``angle``
+        (boundary: reference distributions/bivariateskewnormal.py:92-135; alpha_y is negated first, as there -- image
+        rows grow downwards).  Closed form shared with the batched u-map code, see
+        ``utils.uncertainty_projection.normal_frame_moments``."""
         assert axis == 0 or axis == 1
-        cov = rotate_cov(cov, -angle)
-        alpha = torch.tensor(alpha).clone()
-        alpha[1] = -alpha[1]
-        alpha = rotate_alpha(alpha, -angle)
-        corr, _ = cov2corr(cov)
-        corr = corr.squeeze()
-        other = 1 - axis
-        corr_11, corr_22, corr_12 = corr[axis, axis], corr[other, other], corr[0, 1]
-        alpha_1, alpha_2 = alpha[axis], alpha[other]
-        corr_22_1 = corr_22 - corr_12 * corr_12 / corr_11
-        alpha_1_2 = (alpha_1 + (1 / corr_11) * corr_12 * alpha_2) / torch.sqrt(1 + alpha_2 * corr_22_1 * alpha_2)
-        return mu[axis], cov[axis, axis], alpha_1_2
+        from contour_uncertainty.utils.uncertainty_projection import normal_frame_moments
+        var, skew = normal_frame_moments(np.asarray(cov, dtype=np.float64)[None], _frame_axis(angle, axis)[None],
+                                         np.asarray(alpha, dtype=np.float64)[None])
+        return mu[axis], torch.tensor(var[0], dtype=torch.float32), torch.tensor(skew[0], dtype=torch.float32)
+
+    @classmethod
+    def mode(cls, mu, cov, alpha):
+        """Mode estimate of the bivariate skew-normal (boundary: reference :73-82): Azzalini's univariate approximation
+        ``m0*`` at the summary shape ``alpha* = sqrt(alpha^T R alpha)`` (R = correlation matrix), pushed back along
+        ``R alpha``.  The reference contracts the standard-deviation VECTOR w with ``R alpha`` (``w @ corr @ alpha``: one
+        scalar) instead of scaling by diag(w), so both coordinates move by the same amount; reproduced as is so that the
+        two stay interchangeable (pinned by tests/golden/skew_mode.npz, generated from the reference)."""
+        mu, cov, alpha = (torch.as_tensor(v, dtype=torch.float32) for v in (mu, cov, alpha))
+        std = torch.sqrt(torch.diagonal(cov))
+        r_alpha = (cov / torch.outer(std, std)) @ alpha
+        alpha_star = torch.sqrt(alpha @ r_alpha)
+        return mu + m0(alpha_star) / alpha_star * (std @ r_alpha)
 
     @classmethod
     def rvs_fast(cls, mu, cov, alpha, size=1, eps=None, seed=None):
@@ -62,3 +70,28 @@ class BivariateSkewNormal(BivariateDistribution):
         out = ops.skew_rvs(mu.reshape(1, 2).float().contiguous(), _sigma3(cov.reshape(1, 2, 2)),
                            alpha.reshape(1, 2).float().contiguous(), n, eps=eps, seed=seed)
         return out[0]
+
+
+# ---- univariate skew-normal summaries used by ``mode`` (boundary: reference :195-219) ------------------------------
+def delta(alpha):
+    """alpha / sqrt(1 + alpha^2)"""
+    alpha = torch.as_tensor(alpha, dtype=torch.float32)
+    return alpha * torch.rsqrt(1 + alpha * alpha)
+
+
+def skewness(alpha):
+    """third standardised moment of SN(0, 1, alpha): (4 - pi)/2 * mean^3 / (1 - mean^2)^(3/2), mean = sqrt(2/pi) delta"""
+    mean = math.sqrt(2 / math.pi) * delta(alpha)
+    return (4 - math.pi) / 2 * mean ** 3 / (1 - mean * mean) ** 1.5
+
+
+def m0(alpha):
+    """Azzalini's closed-form approximation of the mode of SN(0, 1, alpha)"""
+    alpha = torch.as_tensor(alpha, dtype=torch.float32)
+    mean = math.sqrt(2 / math.pi) * delta(alpha)
+    spread = torch.sqrt(1 - mean * mean)
+    return mean - skewness(alpha) * spread / 2 - torch.sign(alpha) / 2 * torch.exp(-2 * math.pi / torch.abs(alpha))
+
+
+def univariate_mode(mu, sigma, alpha):
+    return mu + sigma * m0(alpha)

@@ -121,6 +121,20 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p);
 }
 
+// ---- timing experiments (tools/): compiled OUT of the product library.  `make TUNING=1` builds with -DCU_TUNING, which
+// lets CU_CONV_DBG bits skip stores / MFMAs / loads and lets CU_* environment variables override the kernel selection;
+// without it no environment variable can change what a launch computes or which kernel runs.
+#ifdef CU_TUNING
+#include <stdlib.h>
+#define CU_DBG(p, bits) ((p).dbg & (bits))
+static inline int cu_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline bool cu_env_set(const char* name) { return getenv(name) != nullptr; }
+#else
+#define CU_DBG(p, bits) 0
+static inline int cu_env_int(const char*, int dflt) { return dflt; }
+static inline bool cu_env_set(const char*) { return false; }
+#endif
+
 static inline int ilog2_exact(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

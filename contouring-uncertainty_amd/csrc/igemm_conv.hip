@@ -15,8 +15,6 @@
 //     im2col);
 //   - the next chunk's global loads are issued before the current chunk's MFMAs (register prefetch);
 //   - bf16: v_mfma_f32_32x32x16_bf16; f32 (parity mode): v_mfma_f32_32x32x2_f32 (exact f32 FMA chain).
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -304,7 +302,7 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
     // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (own L2 each), so logical tile L -> tile
     // (L % 8) * ntiles/8 + L / 8: the workgroups running on one XCD at a time walk one contiguous eighth of the tiles and
     // the halo rows shared by vertically adjacent tiles are L2 hits instead of second HBM reads.
-    const bool xcd_order = (ntiles & 7) == 0 && (gridDim.x & 7) == 0 && !(p.dbg & 64);
+    const bool xcd_order = (ntiles & 7) == 0 && (gridDim.x & 7) == 0 && !CU_DBG(p, 64);
     auto tile_of = [&](int l) { return xcd_order ? (l & 7) * (ntiles >> 3) + (l >> 3) : l; };
     int ltile = blockIdx.x;
     int tile = tile_of(ltile);
@@ -330,9 +328,9 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
 
         for (int c0 = 0, ci = 0; c0 < CI; c0 += CK, ++ci) {
             __syncthreads();          // previous chunk's fragment reads are done
-            if (!(p.dbg & 4)) commit(c0);
+            if (!CU_DBG(p, 4)) commit(c0);
             __syncthreads();
-            if (!(p.dbg & 8)) {
+            if (!CU_DBG(p, 8)) {
             if (c0 + CK < CI) {
                 prefetch(c0 + CK);
             } else if (lnext < ntiles) {  // cross-tile prefetch: the next tile's first chunk flies under these MFMAs
@@ -375,7 +373,7 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[b], af[a], acc[a][b], 0, 0, 0);
                 }
             };
-            if (!(p.dbg & 2)) {
+            if (!CU_DBG(p, 2)) {
                 if constexpr (NT > 0) {      // exact tap count: branch-free, the scheduler hoists the fragment reads
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
@@ -395,7 +393,7 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
         for (int a = 0; a < MA; ++a) {
             const int n = cur_img0 + pim[a];
             const int py = py0 + pty[a], px = px0 + ptx[a];
-            const bool pvalid = !(pim[a] >= p.imgs || n >= p.N || py >= p.PH || px >= p.PW || (p.dbg & 1));
+            const bool pvalid = !(pim[a] >= p.imgs || n >= p.N || py >= p.PH || px >= p.PW || CU_DBG(p, 1));
             const int oy = py * p.OS + p.OY0, ox = px * p.OS + p.OX0;
             const size_t opix0 = pvalid ? ((size_t)n * p.OH + oy) * p.OW + ox : 0;
 #pragma unroll
@@ -767,7 +765,7 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
                                     (d->PH - 1) * 2 + 1 < d->OH && (d->PW - 1) * 2 + 1 < d->OW),
                  "cu_conv_gemm: bad parity-column mode (par_co=%d)", d->par_co);
     const int CI = d->C0 + d->C1;
-    { const char* e = getenv("CU_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = cu_env_int("CU_CONV_DBG", 0);
 
     // ---- wide bf16 3x3 stride-1 layers whose weight slice cannot stay in LDS: 8-wave LDS-DMA kernel
     {
@@ -783,7 +781,7 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
         if (bf && plain0 && (d->IS == 1 || (d->IS == 2 && d->CO % 128 == 0)) && d->ntaps == 9 &&
             !d->out_nchw_f32 && d->CO >= 128 && CI >= (d->IS == 1 ? 128 : 64) && d->C0 % 32 == 0 &&
             d->D0 % 32 == 0 && d->CO % 16 == 0 && !d->par_co && b0 < lim && b1 < lim && bw < lim &&
-            (px_all / dbm) * cdiv(d->CO, 32 * dnb) >= 128 && !getenv("CU_CONV_NODMA")) {
+            (px_all / dbm) * cdiv(d->CO, 32 * dnb) >= 128 && !cu_env_set("CU_CONV_NODMA")) {
             int tw = d->PW < 32 ? d->PW : 32;
             int th = dbm / tw;
             if (th > d->PH) th = d->PH;
@@ -831,11 +829,11 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
     else nb = 1;
     if (d->D0 != d->CO && d->D0 % (32 * nb) != 0) nb = (d->D0 % 64 == 0 && d->CO % 64 == 0) ? 2 : 1;
     if (!bf && nb > 2) nb = (d->CO % 64 == 0) ? 2 : 1;   // keep the f32 weight tile within LDS
-    { const char* e = getenv("CU_CONV_NBMAX"); const int cap = e ? atoi(e) : 4;
+    { const int cap = cu_env_int("CU_CONV_NBMAX", 4);
       while (nb > cap) nb = (nb == 4) ? 2 : (nb == 3 ? 1 : 1); }
     // small feature maps: few pixel tiles, and every workgroup walks all channel chunks one L2 round trip at a time --
     // narrower column tiles put more CUs on the same work (4x4 x 480 channels: 20 workgroups with 96 columns each)
-    if (!getenv("CU_CONV_NO_NARROW")) {
+    if (!cu_env_set("CU_CONV_NO_NARROW")) {
         const long px_tiles = ((long)d->N * d->PH * d->PW + 127) / 128;
         while (nb > 1 && px_tiles * cdiv(d->CO, 32 * nb) < 192) {
             const int nn = (nb == 4) ? 2 : 1;

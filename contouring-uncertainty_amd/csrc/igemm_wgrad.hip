@@ -10,8 +10,6 @@
 // shifts are plain row offsets; f32 parity mode uses v_mfma_f32_32x32x2_f32 with scalar LDS reads.
 // One workgroup owns a (32*NBLK) x (32*CBLK) block of dW for all taps (<= 9 accumulators of 32x32 per wave) and walks
 // pixel tiles split over grid.y; partial sums are added with f32 atomics in 128-byte rows.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -213,10 +211,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
     if (tile < p.ntiles) prefetch(tile);
     for (; tile < p.ntiles; tile += p.splits) {
         __syncthreads();   // previous tile's fragment reads are done
-        if (!(p.dbg & 4)) commit();
+        if (!CU_DBG(p, 4)) commit();
         __syncthreads();
-        if (tile + p.splits < p.ntiles && !(p.dbg & 8)) prefetch(tile + p.splits);   // flies under this tile's MFMAs
-        if (!wave_active || (p.dbg & 2)) continue;
+        if (tile + p.splits < p.ntiles && !CU_DBG(p, 8)) prefetch(tile + p.splits);   // flies under this tile's MFMAs
+        if (!wave_active || CU_DBG(p, 2)) continue;
 
         const int NK = p.tile_px / KPIX;
         if constexpr (sizeof(T) == 2) {
@@ -295,7 +293,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
         }
     }
 
-    if (!wave_active || (p.dbg & 1)) return;
+    if (!wave_active || CU_DBG(p, 1)) return;
     // ---- atomics: col (lane&31) = c, rows = n
     const int r = lane & 31, hh = lane >> 5;
     const int c = c_base + cblk * 32 + r;
@@ -351,7 +349,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     // same pixel split read the same S / Z tiles, so when the split count allows it all (n, c) tiles of a split are put
     // on one XCD: hardware id h -> xcd = h % 8, slot = h / 8; that XCD owns splits xcd, xcd + 8, ...
     int bxi = blockIdx.x, byi = blockIdx.y;
-    if ((p.splits & 7) == 0 && !(p.dbg & 64)) {
+    if ((p.splits & 7) == 0 && !CU_DBG(p, 64)) {
         const int gx = gridDim.x;
         const int hid = blockIdx.x + gx * blockIdx.y;
         const int xcd = hid & 7, slot = hid >> 3;
@@ -383,7 +381,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     // logical tile L -> tile (L % 8) * ntiles/8 + L / 8: the workgroups of one XCD walk a contiguous eighth of the pixel
     // tiles at a time, so the halo rows shared by neighbouring tiles are L2 hits (thin layers: splits = 256 workgroups
     // with consecutive logical tiles)
-    const bool xcd_tiles = (p.ntiles & 7) == 0 && !(p.dbg & 64);
+    const bool xcd_tiles = (p.ntiles & 7) == 0 && !CU_DBG(p, 64);
     auto tile_geo = [&](int ltile) {
         int bx = xcd_tiles ? (ltile & 7) * (p.ntiles >> 3) + (ltile >> 3) : ltile;
         const int tile_x = bx % p.tiles_x; bx /= p.tiles_x;
@@ -426,7 +424,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
         }
     };
     const int n_items = p.s_iters + p.z_iters;
-    if (PC && producer && (p.dbg & 128)) __builtin_amdgcn_s_setprio(3);
+    if (PC && producer && CU_DBG(p, 128)) __builtin_amdgcn_s_setprio(3);
 
     // lane l = 16g + 4q + pp supplies row q of its group's 4x16 transpose block
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
@@ -446,12 +444,12 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     // one tile: wait for its image, start the DMA of the next tile into the other image, run the k-loop
     long long t_wait = 0, t_bar = 0, t_issue = 0, t_loop = 0;     // CU_CONV_DBG bit 16: phase stamps of one workgroup
     auto run_tile = [&](int tile, const unsigned char* cur, unsigned char* other) {
-        const long long c0 = (p.dbg & 16) ? wall_clock64() : 0;
+        const long long c0 = CU_DBG(p, 16) ? wall_clock64() : 0;
         dma_wait();           // this wave's share of the tile has landed ...
-        const long long c1 = (p.dbg & 16) ? wall_clock64() : 0;
+        const long long c1 = CU_DBG(p, 16) ? wall_clock64() : 0;
         __syncthreads();      // ... everybody's has, and the other image is no longer being read
-        const long long c2 = (p.dbg & 16) ? wall_clock64() : 0;
-        const bool more = tile + p.splits < p.ntiles && !(p.dbg & 8);
+        const long long c2 = CU_DBG(p, 16) ? wall_clock64() : 0;
+        const bool more = tile + p.splits < p.ntiles && !CU_DBG(p, 8);
         if (more) tile_geo(tile + p.splits);
         if (more && issuer) {
             // all DMA instructions now: spreading them over the k-steps was slower with one wave per SIMD (it stalls
@@ -465,7 +463,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
             if (more && !producer)
                 for (int item = 0; item < p.pc_early; ++item) issue_item(item, other);
         }
-        const long long c3 = (p.dbg & 16) ? wall_clock64() : 0;
+        const long long c3 = CU_DBG(p, 16) ? wall_clock64() : 0;
         t_wait += c1 - c0; t_bar += c2 - c1; t_issue += c3 - c2; t_loop -= c3;
         auto late_items = [&]() {
             if constexpr (PC) {
@@ -473,7 +471,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
                     for (int item = p.pc_items; item < n_items; ++item) issue_item(item, other);
             }
         };
-        if (!wave_active || (p.dbg & 2)) { late_items(); return; }
+        if (!wave_active || CU_DBG(p, 2)) { late_items(); return; }
         const unsigned char* Ss = cur;
         const unsigned char* Zs = cur + s_img_bytes;
         auto load = [&](int i, bf16x8 (&A)[NA], bf16x8 (&B)[NTAPS]) {
@@ -547,12 +545,12 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
                 mma(A0, B0);
             }
         }
-        if (p.dbg & 16) t_loop += wall_clock64();
+        if (CU_DBG(p, 16)) t_loop += wall_clock64();
         late_items();
     };
 
     int tile = byi;
-    const long long k0 = (p.dbg & 16) ? wall_clock64() : 0;
+    const long long k0 = CU_DBG(p, 16) ? wall_clock64() : 0;
     if (tile < p.ntiles) {
         tile_geo(tile);
         if constexpr (PC) {       // first image: both wave groups issue half of the rounds
@@ -562,12 +560,12 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
             for (int j = 0; j < n_items; ++j) issue_item(j, imgA);
         }
     }
-    const long long k1 = (p.dbg & 16) ? wall_clock64() : 0;
+    const long long k1 = CU_DBG(p, 16) ? wall_clock64() : 0;
     for (; tile < p.ntiles; tile += 2 * p.splits) {
         run_tile(tile, imgA, imgB);
         if (tile + p.splits < p.ntiles) run_tile(tile + p.splits, imgB, imgA);
     }
-    if ((p.dbg & 16) && bxi == 0 && byi == 0 && (tid & 63) == 0)
+    if (CU_DBG(p, 16) && bxi == 0 && byi == 0 && (tid & 63) == 0)
         printf("[wgrad wave %d] 100MHz ticks: first issue %lld, wait %lld, barrier %lld, issue %lld, k-loop %lld, total %lld (tiles %d)\n",
                wave, k1 - k0, t_wait, t_bar, t_issue, t_loop, wall_clock64() - k0, (p.ntiles - byi + p.splits - 1) / p.splits);
 
@@ -596,7 +594,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
             }
         }
     }
-    if (!wave_active || kpart != 0 || (p.dbg & 1)) return;
+    if (!wave_active || kpart != 0 || CU_DBG(p, 1)) return;
     const int r = lane & 31, h2 = lane >> 5;
     const int c = c_base + cblk * 32 + r;
     if (c >= CI) return;
@@ -678,7 +676,7 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
     a.N = d->N; a.PH = d->PH; a.PW = d->PW; a.SH = d->SH; a.SW = d->SW; a.C0 = d->C0; a.C1 = d->C1; a.IS = d->IS;
     a.ZH = d->ZH; a.ZW = d->ZW; a.ZC = d->ZC; a.ZS = d->ZS; a.CO = d->CO; a.ntaps = d->ntaps;
     a.slope0 = d->slope0; a.slope1 = d->slope1; a.splits = d->splits;
-    { const char* e = getenv("CU_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = cu_env_int("CU_CONV_DBG", 0);
 
     const int CI_all = d->C0 + d->C1;
     const bool wn = d->CO > 32, wc = CI_all > 32;
@@ -741,12 +739,11 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
     const size_t b0 = (size_t)d->N * d->SH * d->SW * d->C0 * 2, b1 = (size_t)d->N * d->SH * d->SW * d->C1 * 2;
     const size_t bz = (size_t)d->N * d->ZH * d->ZW * d->ZC * 2;
     const size_t lim = 0x7fff0000ull;
-    if (d->dtype == CU_BF16 && plain && b0 < lim && b1 < lim && bz < lim && !getenv("CU_WGRAD_NODMA")) {
+    if (d->dtype == CU_BF16 && plain && b0 < lim && b1 < lim && bz < lim && !cu_env_set("CU_WGRAD_NODMA")) {
         const int spp = wc ? 8 : 4, zpp = wn ? 8 : 4;
-        const char* nwe = getenv("CU_WGRAD_NW");
-        int dma_nw = nwe ? atoi(nwe) : 8;
+        int dma_nw = cu_env_int("CU_WGRAD_NW", 8);
         CU_CHECK_ARG(dma_nw == 4 || dma_nw == 8, "CU_WGRAD_NW must be 4 or 8");
-        static const int pc_env = getenv("CU_WGRAD_PC") ? atoi(getenv("CU_WGRAD_PC")) : 1;      // 0 off, 2 every shape
+        static const int pc_env = cu_env_int("CU_WGRAD_PC", 1);      // 0 off, 2 every shape
         // producer/consumer split (see the kernel); the 32-column x 64-channel tile of the 256^2 decoder layer is faster
         // with eight computing waves (measured 294 vs 320 us)
         const bool pc = pc_env && dma_nw == 8 && d->ntaps == 9 && (pc_env == 2 || !(!wn && wc));
@@ -767,9 +764,9 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
         CU_CHECK_ARG(d->ntaps == 4 || a.zsame, "cu_conv_wgrad: per-tap Z shifts are only built for 4 taps");
         a.src0_bytes = (unsigned)b0; a.src1_bytes = (unsigned)b1; a.z_bytes = (unsigned)bz;
         {
-            static const int pcf = getenv("CU_WGRAD_PCF") ? atoi(getenv("CU_WGRAD_PCF")) : 70;      // percent of the rounds (measured optimum 65-75)
+            static const int pcf = cu_env_int("CU_WGRAD_PCF", 70);      // percent of the rounds (measured optimum 65-75)
             const int n = a.s_iters + a.z_iters;
-            static const int pce = getenv("CU_WGRAD_PCE") ? atoi(getenv("CU_WGRAD_PCE")) : 0;
+            static const int pce = cu_env_int("CU_WGRAD_PCE", 0);
             a.pc_early = pce < n ? pce : n;
             a.pc_items = a.pc_early + ((n - a.pc_early) * pcf + 99) / 100;
             if (a.pc_items > n) a.pc_items = n;

@@ -392,7 +392,7 @@ extern "C" int cu_contour_masks(int M, int K, int H, int W, const float* contour
     CU_CHECK_ARG(mode >= 0 && mode <= 2, "cu_contour_masks: bad mode %d", mode);
     CU_CHECK_ARG(M > 0 && K >= 2 && K <= MAXK && H > 0 && H <= MT && W > 0 && W <= MT, "cu_contour_masks: bad sizes M=%d K=%d H=%d W=%d", M, K, H, W);
     CU_CHECK_ARG(contours && (packed || bytes), "cu_contour_masks: null pointer");
-    static const int dbg = getenv("CU_MASKS_DBG") ? atoi(getenv("CU_MASKS_DBG")) : 0;      // timing aid (tools/masks_bench.py)
+    static const int dbg = cu_env_int("CU_MASKS_DBG", 0);      // timing aid (tools/masks_bench.py)
     hipLaunchKernelGGL(contour_mask_kernel, dim3(M), dim3(MT), 0, reinterpret_cast<hipStream_t>(stream), K, H, W, contours,
                        round_landmarks, mode, packed, bytes, dbg);
     CU_LAUNCH_CHECK();

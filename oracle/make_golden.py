@@ -413,6 +413,28 @@ def gen_umap():
     np.savez_compressed(OUT / "umap_projection.npz", **out)
 
 
+def gen_skew_mode():
+    """BivariateSkewNormal.mode and the univariate summaries it is built from (bivariateskewnormal.py:73-82,195-219)."""
+    from contour_uncertainty.distributions import bivariateskewnormal as B
+    g = torch.Generator().manual_seed(21)
+    m = 12
+    mu = torch.rand(m, 2, generator=g) * 200 + 20
+    cov = rand_spd(m, g, 2.0, 80.0)
+    alpha = torch.randn(m, 2, generator=g) * 3
+    alpha[0] = torch.tensor([5.0, 0.0])                      # the reference's own check_bivariate_mode() constants
+    cov[0] = torch.tensor([[10.0, -5.0], [-5.0, 10.0]])
+    mu[0] = torch.tensor([100.0, 150.0])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        modes = torch.stack([B.BivariateSkewNormal.mode(mu[i], cov[i], alpha[i]) for i in range(m)])
+    a1 = torch.tensor([-8.0, -3.0, -1.0, -0.2, 0.3, 1.0, 3.0, 8.0, 25.0])
+    out = {"mu": npy(mu), "cov": npy(cov), "alpha": npy(alpha), "mode": npy(modes), "a1": npy(a1),
+           "delta": npy(B.delta(a1)), "skewness": npy(B.skewness(a1)), "m0": npy(B.m0(a1)),
+           "univariate_mode": npy(B.univariate_mode(torch.tensor(3.0), torch.tensor(2.0), a1))}
+    np.savez_compressed(OUT / "skew_mode.npz", **out)
+
+
 def gen_drop():
     """Which ConvLayers carry a Dropout2d when task.model.drop_block=True (reference unet2.py:129-136,302; layers.py
     196-202): read off the instantiated reference modules for the 6-stage (config c1) and 8-stage (unet2.yaml) nets."""
@@ -427,10 +449,10 @@ def gen_drop():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dsnt", "nll", "unet_small", "unet_full", "step", "psm", "skew_grid", "umap", "drop"]
+    which = sys.argv[1:] or ["dsnt", "nll", "unet_small", "unet_full", "step", "psm", "skew_grid", "umap", "drop", "skew_mode"]
     for w in which:
         print("generating", w, flush=True)
         {"dsnt": gen_dsnt, "nll": gen_nll, "unet_small": gen_unet_small, "unet_full": gen_unet_full,
-         "step": gen_step, "psm": gen_psm, "skew_grid": gen_skew_grid, "umap": gen_umap, "drop": gen_drop}[w]()
+         "step": gen_step, "psm": gen_psm, "skew_grid": gen_skew_grid, "umap": gen_umap, "drop": gen_drop, "skew_mode": gen_skew_mode}[w]()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)

@@ -203,3 +203,51 @@ def test_train_ensemble_takes_a_random_90_percent_subset():
     before = Trainer.datamodule._dataset[Sub.TRAIN]
     task3.on_fit_start()
     assert Trainer.datamodule._dataset[Sub.TRAIN] is before
+
+
+def test_product_library_has_no_tuning_hooks():
+    """The shipped library must not honour timing-experiment environment variables: they are compiled
+    in only under `make TUNING=1` (-DCU_TUNING), so their names do not even appear in the product .so."""
+    from cu_hip import lib
+    blob = Path(lib.LIB_PATH).read_bytes()
+    for name in (b"CU_CONV_DBG", b"CU_CONV_NODMA", b"CU_CONV_NBMAX", b"CU_CONV_NO_NARROW", b"CU_WGRAD_NODMA",
+                 b"CU_WGRAD_NW", b"CU_WGRAD_PC", b"CU_MASKS_DBG"):
+        assert name not in blob, name
+
+
+def test_synthetic_inputs_of_product_and_oracle_agree():
+    """bench.py takes its inputs from the product's data/synthetic module; the oracle keeps its own statement of SURVEY
+    8(d)'s generator.  Same seed -> same tensors, and the FLOP model of cu_hip.flops equals the oracle's layer count."""
+    from contour_uncertainty.data.synthetic import synthetic_batch
+    from cu_hip.flops import conv_macs_per_image
+    from oracle.step import synthetic_batch as oracle_batch
+    for n, size, seed in ((2, 64, 1234), (3, 32, 7)):
+        a, b = synthetic_batch(n, size, 21, seed), oracle_batch(n, size, 21, seed)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for strides, size in (((1, 2, 2, 2, 2, 2, 2, 2), 256), ((1, 2, 2, 2, 2, 2), 64)):
+        a, b = conv_macs_per_image(strides, size), OU.conv_macs_per_image(OU.UNetSpec(strides=strides), size)
+        assert a == b
+    assert abs(2 * conv_macs_per_image((1, 2, 2, 2, 2, 2, 2, 2), 256)["fwd"] - 28.98e9) < 0.01e9      # SURVEY section 6
+
+
+def test_synthetic_datamodule_contract():
+    """data=synthetic emits the reference's batch contract (dataset.py:100-149; predict items are whole views)."""
+    from contour_uncertainty.data.synthetic import SyntheticContourDataModule
+    dm = SyntheticContourDataModule(size=64, batch_size=2, n_train=5, n_val=3, n_predict=2)
+    assert dm.data_params.in_shape == (1, 64, 64) and dm.data_params.out_shape == (21, 2)
+    dm.setup("fit")
+    b = next(iter(dm.train_dataloader()))
+    assert b["img"].shape == (2, 1, 64, 64) and b["img"].dtype == torch.float32
+    assert 0 <= float(b["img"].min()) and float(b["img"].max()) <= 1
+    assert b["contour"].shape == (2, 21, 2) and b["gt"].shape == (2, 64, 64) and b["gt"].dtype == torch.int64
+    assert len(b["id"]) == 2 and sum(len(x["id"]) for x in dm.train_dataloader()) == 5
+    # the contour's x is the column, y the row: the landmarks lie on the boundary of the gt mask
+    c = b["contour"][0].round().long()
+    assert int(b["gt"][0][c[10, 1] + 3, c[10, 0]]) == 1          # just below the apex: inside
+    dm.setup("predict")
+    v = next(iter(dm.predict_dataloader()))
+    assert v["img"].shape == (2, 1, 64, 64) and v["contour"].shape == (2, 21, 2) and isinstance(v["id"], str)
+    # deterministic
+    dm2 = SyntheticContourDataModule(size=64, batch_size=2, n_train=5, n_val=3)
+    dm2.setup("fit")
+    assert torch.equal(dm2.datasets["val"][1]["img"], dm.datasets["val"][1]["img"])

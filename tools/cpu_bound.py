@@ -5,7 +5,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "contouring-uncertainty_amd"))
 import torch
 from bench import build_task
-from oracle.step import synthetic_batch
+from contour_uncertainty.data.synthetic import synthetic_batch
 dev = torch.device("cuda", 0)
 task, _ = build_task(256, "bf16", "dsnt-skew")
 task = task.to(dev)

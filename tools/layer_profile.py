@@ -9,7 +9,7 @@ sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "contouring-uncerta
 import torch
 from cu_hip import ops
 from bench import build_task
-from oracle.step import synthetic_batch
+from contour_uncertainty.data.synthetic import synthetic_batch
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 256

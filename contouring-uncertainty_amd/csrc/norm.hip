@@ -646,6 +646,291 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict_
     *o = accum ? *o + v : v;
 }
 
+// ------------------------------------------------------------------------------------------------ resident-chunk kernels
+// One launch per direction, each tensor read ONCE:
+//   forward : a = LeakyReLU((z - mean) * rstd * gamma + beta)        read z, write a            (two-pass: stats + apply)
+//   backward: dz = gamma*rstd*(gl - mean(gl) - xhat*mean(gl*xhat))   read g, z, write dz        (two-pass: reduce + apply)
+// A workgroup takes one (image, pixel chunk) task, keeps the chunk in REGISTERS (NP 16-byte pieces per thread and tensor),
+// adds its partial sums to the image's accumulator row with f32 atomics, then waits until every chunk of that image has
+// arrived before it normalises what it holds.  Nothing but the per-(image, channel) sums crosses workgroups.
+//
+// Progress without any assumption on dispatch order or co-residency of the whole grid: tasks are handed out by a TICKET
+// counter (atomicAdd at workgroup start), so the chunks of one image go to nchunks consecutive starters.  A workgroup only
+// ever waits for tickets of its own image; if all resident workgroups are waiting, fewer than nchunks tickets of the
+// lowest unfinished image are out, i.e. fewer than nchunks workgroups are resident: with nchunks <= 256 (one workgroup
+// per CU always fits) a slot is free and the next starter takes the missing ticket.
+// Visibility (MI355X_MICROARCH.md, inter-workgroup visibility): the accumulator rows and the arrival counters are only
+// touched by agent-scope atomics (executed at the memory side) and read by agent-scope (sc1) loads; the arrival add is
+// issued after this workgroup's sum atomics have been acknowledged (s_waitcnt vmcnt(0) + barrier).
+//
+// Measured on MI355X (tools/norm_bench.py, 64 images, bf16; profiles/r02_norm_bench.txt): the streaming itself runs at
+// 4.2 TB/s (256^2 x 32: forward 127 us, backward 180 us without any exchange), but every workgroup holds its registers
+// through a chain of dependent memory round trips (adds acknowledged -> arrival add -> poll -> totals), and all chunks of
+// an image finish together, so loads and stores alternate in bursts: with the exchange 262 / 335 us against 176 / 291 us
+// for the two-pass kernels.  The one-launch form wins where an image is a few chunks (forward at <= 16x16: 17-24 us
+// against 25-27) and where the two-pass kernels are latency-bound (backward at 64x64: 66 against 95 us); the host entry
+// points below pick per shape.  History of the exchange at 256^2 x 32, forward: every piece holder adding its own 16
+// floats (16 four-lane wave instructions per workgroup on one 256-byte row) 965 us; one coalesced add per 64 floats
+// 278 us; totals fetched once per workgroup through LDS instead of per thread 262 us; 64-byte segments carrying their
+// own arrival count (no acknowledgement wait, no counter, every thread polling) 332 us.
+constexpr int RC_MAX_CHUNKS = 256;
+#ifdef CU_TUNING
+#define RC_DBG(dbg, bits) ((dbg) & (bits))      // CU_NORM_DBG: 1 no sum atomics, 2 no arrive/wait, 4 no totals fetch, 8 no ticket
+#else
+#define RC_DBG(dbg, bits) 0
+#endif
+// workspace (32-bit words): a 4-KiB header ([0] = ticket, [1] = spin-limit flag), then one 4-KiB-aligned block per image:
+// [0, 2C) the sums [C][2], then on a 256-byte line of its own the image's arrival counter
+constexpr int RC_HDR = 1024;
+constexpr int RC_LINE = 64;
+__host__ __device__ inline int rc_ctr_off(int C) { return (2 * C + RC_LINE - 1) / RC_LINE * RC_LINE; }
+__host__ __device__ inline int rc_block_words(int C) { return (rc_ctr_off(C) + RC_LINE + 1023) / 1024 * 1024; }
+constexpr unsigned RC_SPIN_LIMIT = 1u << 20;    // ~1 s: the kernel drains and raises ws[1] instead of hanging the GPU
+
+struct RcTask { int n, chunk; };
+
+__device__ __forceinline__ RcTask rc_take_ticket(unsigned* ctr, int nchunks, unsigned* s_slot) {
+    if (threadIdx.x == 0) *s_slot = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned t = *s_slot;
+    RcTask k;
+    k.n = (int)(t / (unsigned)nchunks);
+    k.chunk = (int)(t - (unsigned)k.n * (unsigned)nchunks);
+    return k;
+}
+
+__device__ __forceinline__ float rc_read(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// acc (held by the threads with prow == 0, one channel piece each) -> lds[c * 2 + k] = the image's totals.
+// The partial sums go through LDS so that consecutive lanes add consecutive floats (one 256-byte wave instruction per 64
+// floats), and the totals come back through LDS from one coalesced agent-scope load per workgroup.
+template <int PIECE>
+__device__ __forceinline__ void rc_exchange(const float (&acc)[2][PIECE], float* lds, float* row, unsigned* flag, int C,
+                                            int piece, bool holder, int nchunks, int dbg) {
+    __syncthreads();                      // reduce_rows is done with the LDS scratch
+    if (holder) {
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+            lds[(piece * PIECE + e) * 2] = acc[0][e];
+            lds[(piece * PIECE + e) * 2 + 1] = acc[1][e];
+        }
+    }
+    __syncthreads();
+    if (!RC_DBG(dbg, 1))
+        for (int i = threadIdx.x; i < 2 * C; i += NT) unsafeAtomicAdd(row + i, lds[i]);
+    if (!RC_DBG(dbg, 2)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's adds are acknowledged ...
+        __syncthreads();                                       // ... everybody's are
+        if (threadIdx.x == 0) {
+            unsigned* arrived = reinterpret_cast<unsigned*>(row) + rc_ctr_off(C);
+            __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nchunks) {
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > RC_SPIN_LIMIT) {
+                    __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!RC_DBG(dbg, 4))
+        for (int i = threadIdx.x; i < 2 * C; i += NT) lds[i] = rc_read(row + i);
+    __syncthreads();
+}
+
+template <typename T> __device__ __forceinline__ void unpack_piece(const u32x4& r, float (&v)[Elem<T>::PIECE]);
+template <> __device__ __forceinline__ void unpack_piece<float>(const u32x4& r, float (&v)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(r[e]);
+}
+template <> __device__ __forceinline__ void unpack_piece<bf16_t>(const u32x4& r, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(r[i] << 16);
+        v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+    }
+}
+
+template <typename T, int NP>
+__global__ __launch_bounds__(NT, 4) void fwd_resident_kernel(const T* __restrict__ z, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, float slope,
+                                                              float* __restrict__ stats, T* __restrict__ out,
+                                                              float* ws, int N, int HW, int C, int tpp, int rows,
+                                                              int nchunks, int dbg) {
+    constexpr int PIECE = Elem<T>::PIECE;
+    extern __shared__ float lds[];
+    __shared__ unsigned s_slot;
+    unsigned* ctr = reinterpret_cast<unsigned*>(ws);
+    RcTask task = rc_take_ticket(ctr, nchunks, &s_slot);
+    if (RC_DBG(dbg, 8)) { task.n = blockIdx.x / nchunks; task.chunk = blockIdx.x % nchunks; }
+    const int n = task.n;
+    if (n >= N) return;                                   // uniform
+    const int piece = threadIdx.x % tpp, prow = threadIdx.x / tpp;
+    const bool active = prow < rows;
+    const int p0 = task.chunk * rows * NP;
+    const size_t base = (size_t)n * HW * C + (active ? piece : 0) * PIECE;
+    u32x4 zr[NP];
+    unsigned okm = 0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int p = p0 + prow + j * rows;
+        const bool ok = active && p < HW;
+        zr[j] = *reinterpret_cast<const u32x4*>(z + base + (size_t)(ok ? p : 0) * C);
+        okm |= (ok ? 1u : 0u) << j;
+    }
+    float k[PIECE];
+    load_piece<T>(z + base, k);              // shift by the image's first pixel: avoids E[x^2]-E[x]^2 cancellation
+    float acc[2][PIECE];
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) acc[0][e] = acc[1][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        float v[PIECE];
+        unpack_piece<T>(zr[j], v);
+        const float m = ((okm >> j) & 1u) ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+            const float d = (v[e] - k[e]) * m;
+            acc[0][e] += d;
+            acc[1][e] += d * d;
+        }
+    }
+    reduce_rows<2, PIECE>(acc, lds, piece, prow, rows, tpp, active);
+    rc_exchange<PIECE>(acc, lds, ws + RC_HDR + (size_t)n * rc_block_words(C), ctr + 1, C, piece, active && prow == 0,
+                       nchunks, dbg);
+    if (!active) return;
+    // only the PACKED pieces stay live across the wait (the compiler would otherwise keep their unpacked floats too)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) asm volatile("" : "+v"(zr[j]));
+    float sc[PIECE], sh[PIECE];
+    const float inv = 1.f / (float)HW;
+    const size_t NC = (size_t)N * C;
+    const size_t sidx = (size_t)n * C + piece * PIECE;
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) {
+        const float m1 = lds[(piece * PIECE + e) * 2] * inv, m2 = lds[(piece * PIECE + e) * 2 + 1] * inv;
+        const float mean = k[e] + m1;
+        const float rstd = 1.f / sqrtf(fmaxf(m2 - m1 * m1, 0.f) + eps);
+        const int c = piece * PIECE + e;
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        sc[e] = g * rstd;
+        sh[e] = b - mean * g * rstd;
+        if (task.chunk == 0 && prow == 0) {
+            stats[sidx + e] = mean;
+            stats[NC + sidx + e] = rstd;
+            stats[2 * NC + sidx + e] = sc[e];
+            stats[3 * NC + sidx + e] = sh[e];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        if ((okm >> j) & 1u) {
+            float v[PIECE];
+            unpack_piece<T>(zr[j], v);
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) {
+                const float y = v[e] * sc[e] + sh[e];
+                v[e] = y > 0.f ? y : y * slope;
+            }
+            store_piece<T>(out + base + (size_t)(p0 + prow + j * rows) * C, v);
+        }
+    }
+}
+
+template <typename T, int NP>
+__global__ __launch_bounds__(NT, 2) void bwd_resident_kernel(T* __restrict__ g, const T* __restrict__ z,
+                                                              const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                              float slope, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* ws, int N, int HW, int C, int tpp, int rows, int nchunks,
+                                                              int dbg) {
+    constexpr int PIECE = Elem<T>::PIECE;
+    extern __shared__ float lds[];
+    __shared__ unsigned s_slot;
+    unsigned* ctr = reinterpret_cast<unsigned*>(ws);
+    RcTask task = rc_take_ticket(ctr, nchunks, &s_slot);
+    if (RC_DBG(dbg, 8)) { task.n = blockIdx.x / nchunks; task.chunk = blockIdx.x % nchunks; }
+    const int n = task.n;
+    if (n >= N) return;                                   // uniform
+    const int piece = threadIdx.x % tpp, prow = threadIdx.x / tpp;
+    const bool active = prow < rows;
+    const int p0 = task.chunk * rows * NP;
+    const size_t base = (size_t)n * HW * C + (active ? piece : 0) * PIECE;
+    const size_t NC = (size_t)N * C;
+    const size_t sidx = (size_t)n * C + (active ? piece : 0) * PIECE;
+    u32x4 zr[NP], gr_[NP];
+    unsigned okm = 0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int p = p0 + prow + j * rows;
+        const bool ok = active && p < HW;
+        const size_t off = base + (size_t)(ok ? p : 0) * C;
+        zr[j] = *reinterpret_cast<const u32x4*>(z + off);
+        gr_[j] = *reinterpret_cast<const u32x4*>(g + off);
+        okm |= (ok ? 1u : 0u) << j;
+    }
+    float mean[PIECE], rstd[PIECE], sc[PIECE], sh[PIECE];
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) {
+        mean[e] = stats[sidx + e]; rstd[e] = stats[NC + sidx + e];
+        sc[e] = stats[2 * NC + sidx + e]; sh[e] = stats[3 * NC + sidx + e];
+    }
+    float acc[2][PIECE];
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) acc[0][e] = acc[1][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        float zv[PIECE], gv[PIECE];
+        unpack_piece<T>(zr[j], zv);
+        unpack_piece<T>(gr_[j], gv);
+        const float m = ((okm >> j) & 1u) ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+            const float y = zv[e] * sc[e] + sh[e];
+            const float gl = (y > 0.f ? gv[e] : gv[e] * slope) * m;
+            acc[0][e] += gl;
+            acc[1][e] += gl * (zv[e] - mean[e]) * rstd[e];
+        }
+    }
+    reduce_rows<2, PIECE>(acc, lds, piece, prow, rows, tpp, active);
+    rc_exchange<PIECE>(acc, lds, ws + RC_HDR + (size_t)n * rc_block_words(C), ctr + 1, C, piece, active && prow == 0,
+                       nchunks, dbg);
+    if (!active) return;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) asm volatile("" : "+v"(zr[j]), "+v"(gr_[j]));
+    float a1[PIECE], a2[PIECE], gr[PIECE];
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) {
+        const float t1 = lds[(piece * PIECE + e) * 2], t2 = lds[(piece * PIECE + e) * 2 + 1];
+        a1[e] = t1 * inv; a2[e] = t2 * inv;
+        gr[e] = (gamma ? gamma[piece * PIECE + e] : 1.f) * rstd[e];
+        if (task.chunk == 0 && prow == 0) {     // one contribution per (image, channel)
+            if (dbeta) unsafeAtomicAdd(dbeta + piece * PIECE + e, t1);
+            if (dgamma) unsafeAtomicAdd(dgamma + piece * PIECE + e, t2);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        if ((okm >> j) & 1u) {
+            float zv[PIECE], gv[PIECE];
+            unpack_piece<T>(zr[j], zv);
+            unpack_piece<T>(gr_[j], gv);
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) {
+                const float y = zv[e] * sc[e] + sh[e];
+                const float gl = y > 0.f ? gv[e] : gv[e] * slope;
+                const float xh = (zv[e] - mean[e]) * rstd[e];
+                gv[e] = gr[e] * (gl - a1[e] - xh * a2[e]);
+            }
+            store_piece<T>(g + base + (size_t)(p0 + prow + j * rows) * C, gv);
+        }
+    }
+}
+
 static int pick_chunk(int N, int HW, int rows, int* nchunks) {
     // aim for ~2048 workgroups in total; every chunk a multiple of the rows handled per iteration
     int want = cdiv(2048, N);

@@ -94,6 +94,9 @@ class UNetEngine:
         # True: one streaming pass materialises LeakyReLU(InstanceNorm(z)) per layer and every consumer stages a plain
         # operand; False: consumers recompute it in their operand load (less HBM traffic, but VALU-bound thin layers)
         self.materialize = True
+        # True: InstanceNorm + LeakyReLU forward (statistics + materialise) and backward (reduce + apply) each run as ONE
+        # resident-chunk launch that reads every tensor once (norm.hip); False: the two-pass kernels
+        self.fused_norm = True
         # Dropout2d(p=0.5) between conv and norm in the listed ConvLayers (reference unet2.py:129-136,302: the last
         # downsample block and the bottleneck when task.model.drop_block=True); active in training mode only
         self.drop_layers: set = set()
@@ -162,11 +165,17 @@ class UNetEngine:
                 keep = torch.rand((n, co), device=z.device) >= self.drop_p
                 mask = keep.float() / (1.0 - self.drop_p)
             ops.channel_scale(z, mask)
-        stats = ops.instnorm_stats(z, P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"], self.eps)
-        out = Act(z, stats, self.slope)
+        out = self._norm_act_fwd(P, prefix, z)
+        ctx.convs[prefix] = _ConvRec(prefix, srcs, out, stride, drop_mask=mask)
+        return out
+
+    def _norm_act_fwd(self, P, prefix: str, z: Tensor) -> Act:
+        gamma, beta = P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"]
+        if self.fused_norm and self.materialize:
+            return ops.instnorm_fwd_fused(z, gamma, beta, self.slope, self.eps)
+        out = Act(z, ops.instnorm_stats(z, gamma, beta, self.eps), self.slope)
         if self.materialize:
             ops.instnorm_apply(out)
-        ctx.convs[prefix] = _ConvRec(prefix, srcs, out, stride, drop_mask=mask)
         return out
 
     def _first_layer_fwd(self, P, ctx: UNetCtx, prefix: str, img: Tensor) -> Act:
@@ -181,10 +190,7 @@ class UNetEngine:
         n, _, h, w_ = img.shape
         z = torch.empty((n, h, w_, co), dtype=self.dtype, device=img.device)
         ops.conv_c1_fwd(img, w9, P[f"{prefix}.conv.bias"], z)
-        stats = ops.instnorm_stats(z, P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"], self.eps)
-        out = Act(z, stats, self.slope)
-        if self.materialize:
-            ops.instnorm_apply(out)
+        out = self._norm_act_fwd(P, prefix, z)
         ctx.convs[prefix] = _ConvRec(prefix, [], out, 1, first=True)
         return out
 
@@ -262,8 +268,12 @@ class UNetEngine:
             self.debug[f"{prefix}:da"] = g.float().clone()
         # d(conv bias) = sum_p dz is identically zero behind an InstanceNorm (dz has zero mean per (n, c)); the reference
         # accumulates rounding noise there.  G[conv.bias] stays exactly 0 (no kernel work, no atomics contention).
-        ops.instnorm_lrelu_bwd(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
-                               G[f"{prefix}.norm.bias"], None)
+        if self.fused_norm:
+            ops.instnorm_bwd_fused(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
+                                   G[f"{prefix}.norm.bias"], getattr(rec.out, "ws", None))
+        else:
+            ops.instnorm_lrelu_bwd(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
+                                   G[f"{prefix}.norm.bias"], None)
         if rec.drop_mask is not None:          # gradient through the Dropout2d that sits between conv and norm
             ops.channel_scale(g, rec.drop_mask)
         if self.debug is not None:

@@ -23,6 +23,7 @@ class Act:
     stats: Optional[Tensor] = None     # (4, N, C) f32: mean, rstd, scale, shift   (None = no affine)
     slope: float = 1.0                 # LeakyReLU slope (1.0 = identity, 0.0 = ReLU)
     a: Optional[Tensor] = None         # materialised LeakyReLU(z*scale+shift); consumers stage it as a plain operand
+    ws: Optional[Tensor] = None        # resident-chunk workspace of the forward launch (re-used by the backward launch)
 
     @property
     def scale(self):
@@ -206,6 +207,40 @@ def instnorm_lrelu_bwd(g: Tensor, act: Act, gamma: Optional[Tensor], dgamma, dbe
         L.check(L.load().cu_instnorm_lrelu_bwd(L.dtype_code(g.dtype), n, h * w_, c, L.ptr(g), L.ptr(act.z),
                                                L.ptr(act.stats), L.ptr(gamma), act.slope, L.ptr(dgamma), L.ptr(dbeta),
                                                L.ptr(dbias), L.ptr(ws), L.stream_ptr()), "cu_instnorm_lrelu_bwd")
+
+
+def _resident_ws(n: int, c: int, device) -> Tensor:
+    return torch.empty(L.load().cu_instnorm_resident_ws_floats(n, c), dtype=torch.float32, device=device)
+
+
+def instnorm_fwd_fused(z: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], slope: float, eps: float = 1e-5,
+                       ws: Optional[Tensor] = None) -> Act:
+    """statistics + LeakyReLU(z*scale + shift) in ONE launch, z read once (cu_instnorm_fwd_fused) -> Act(z, stats, a)."""
+    n, h, w_, c = z.shape
+    stats = torch.empty((4, n, c), dtype=torch.float32, device=z.device)
+    out = torch.empty_like(z)
+    ws = _resident_ws(n, c, z.device) if ws is None else ws
+    with _Prof("instnorm_fwd", 0.0, f"N{n} {h}x{w_} C{c}", 2 * z.numel() * z.element_size()):
+        L.check(L.load().cu_instnorm_fwd_fused(L.dtype_code(z.dtype), n, h * w_, c, L.ptr(z), L.ptr(gamma), L.ptr(beta), eps,
+                                               slope, L.ptr(stats), L.ptr(out), L.ptr(ws), L.stream_ptr()),
+                "cu_instnorm_fwd_fused")
+    return Act(z, stats, slope, out, ws)
+
+
+def instnorm_bwd_fused(g: Tensor, act: Act, gamma: Optional[Tensor], dgamma, dbeta, ws: Optional[Tensor] = None):
+    """In place: g (dL/d activated) -> dL/dz, g and z read once (cu_instnorm_bwd_fused)."""
+    n, h, w_, c = g.shape
+    ws = _resident_ws(n, c, g.device) if ws is None else ws
+    with _Prof("instnorm_bwd", 0.0, f"N{n} {h}x{w_} C{c}", 3 * g.numel() * g.element_size()):
+        L.check(L.load().cu_instnorm_bwd_fused(L.dtype_code(g.dtype), n, h * w_, c, L.ptr(g), L.ptr(act.z), L.ptr(act.stats),
+                                               L.ptr(gamma), act.slope, L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws),
+                                               L.stream_ptr()), "cu_instnorm_bwd_fused")
+    return ws
+
+
+def resident_wait_failed(ws: Tensor, n: int, c: int) -> bool:
+    """True if the bounded arrival wait of the last resident-chunk launch on ``ws`` gave up (synchronises)."""
+    return bool(ws.view(torch.int32)[1].item() != 0)
 
 
 def channel_scale(x: Tensor, mask: Tensor):

@@ -238,6 +238,47 @@ def test_instnorm_fwd_bwd(dtype, shape):
     assert float(dbias.abs().max()) < 1e-2 * float(go.abs().sum() / c) + 1e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 32, 128), (2, 32, 64), (3, 480, 4), (2, 128, 16), (64, 480, 2), (5, 64, 48),
+                                   (2, 256, 32), (3, 480, 16), (2, 480, 8)])
+def test_instnorm_resident_kernels(dtype, shape):
+    """One-launch forward (statistics + normalise + LeakyReLU, z read once) and one-launch backward (reduce + apply,
+    g and z read once) vs F.instance_norm -> leaky_relu autograd: images spanning 1 .. 256 chunks, a ragged last
+    chunk (48 x 48), 480 channels (threads-per-pixel not a power of two), tiny maps."""
+    ops = _ops()
+    n, c, size = shape
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(n, c, size, size, device=DEV, generator=g) * 2 + 3.0      # |mean| > std on purpose
+    gamma = torch.rand(c, device=DEV, generator=g) + 0.5
+    beta = torch.randn(c, device=DEV, generator=g) * 0.2
+    z = nhwc(x, dtype)
+    zf = nchw(z).requires_grad_(True)
+    gm = gamma.clone().requires_grad_(True)
+    bt = beta.clone().requires_grad_(True)
+    ref = F.leaky_relu(F.instance_norm(zf, weight=gm, bias=bt, eps=1e-5), 0.01)
+    act = ops.instnorm_fwd_fused(z, gamma, beta, 0.01, 1e-5)
+    assert not ops.resident_wait_failed(act.ws, n, c)
+    mean = zf.detach().mean((2, 3))
+    var = zf.detach().var((2, 3), unbiased=False)
+    assert torch.allclose(act.stats[0], mean, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(act.stats[1], 1 / torch.sqrt(var + 1e-5), rtol=2e-4)
+    assert torch.allclose(act.stats[2], gamma[None] * act.stats[1], rtol=1e-6)
+    assert rel_err(nchw(act.a), ref.detach()) < (2e-4 if dtype == torch.float32 else 1e-2)
+    # identical to the two-pass kernels
+    stats2 = ops.instnorm_stats(z, gamma, beta, 1e-5)
+    assert torch.allclose(stats2, act.stats, rtol=1e-5, atol=1e-6)
+    go = rq(torch.randn(n, c, size, size, device=DEV, generator=g), dtype)
+    ref.backward(go)
+    gt = nhwc(go, dtype)
+    dgamma = torch.zeros(c, device=DEV)
+    dbeta = torch.zeros(c, device=DEV)
+    ws = ops.instnorm_bwd_fused(gt, act, gamma, dgamma, dbeta)
+    assert not ops.resident_wait_failed(ws, n, c)
+    t = 2e-4 if dtype == torch.float32 else 1.5e-2
+    assert rel_err(nchw(gt), zf.grad) < t
+    assert rel_err(dgamma, gm.grad) < 2e-4 and rel_err(dbeta, bt.grad) < 2e-4
+
+
 @pytest.mark.parametrize("size", [16, 64, 256])
 def test_dsnt_head_vs_golden(golden_dir, size):
     ops = _ops()

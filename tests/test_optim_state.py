@@ -73,7 +73,7 @@ def _run(dev, monkeypatch=None):
         assert float(sd["state"][i]["step"]) == float(rsd["state"][i]["step"]) == 3.0
         assert sd["state"][i]["exp_avg"].shape == params[i].shape
         assert torch.allclose(sd["state"][i]["exp_avg"], rsd["state"][i]["exp_avg"], rtol=1e-5, atol=1e-7)
-        assert torch.allclose(sd["state"][i]["exp_avg_sq"], rsd["state"][i]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+        assert torch.allclose(sd["state"][i]["exp_avg_sq"], rsd["state"][i]["exp_avg_sq"], rtol=1e-4, atol=1e-9)
     # ---- save / load round trip into a NEW optimizer over re-flattened parameters: step and moments survive
     saved = copy.deepcopy(sd)
     _, params2 = _flat_model(dev, seed=0)

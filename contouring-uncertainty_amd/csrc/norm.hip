@@ -143,9 +143,10 @@ __global__ __launch_bounds__(NT) void stats_partial_kernel(const T* __restrict__
 template <typename T>
 __global__ void stats_finalize_kernel(const T* __restrict__ z, const float* __restrict__ ws,
                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                      float* __restrict__ stats, int N, int HW, int C) {
+                                      float* __restrict__ stats, int N, int HW, int C, int nimg) {
+    // N = images of the whole tensor (plane stride of stats), nimg = images of this launch
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * C) return;
+    if (i >= nimg * C) return;
     const int n = i / C, c = i - n * C;
     const float k = Elem<T>::ld(z + (size_t)n * HW * C + c);
     const float inv = 1.f / (float)HW;
@@ -958,52 +959,83 @@ static int pick_chunk(int N, int HW, int rows, int* nchunks) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);                                                   \
     (void)chunk; (void)nchunks; (void)st;
 
+// ---- launch helpers: `nimg` images starting at the pointers given, inside a tensor of N images (plane stride of stats)
+template <typename T>
+static int launch_stats(int nimg, int N, int HW, int C, const void* z, const float* gamma, const float* beta, float eps,
+                        float* stats, float* ws, hipStream_t st) {
+    constexpr int PIECE = Elem<T>::PIECE;
+    const RowMap rm = row_map(C, PIECE);
+    if (HW <= 1024) {       // small feature maps: one fused launch
+        dim3 sgrid(nimg, cdiv(C / PIECE, SG));
+        hipLaunchKernelGGL(stats_small_kernel<T>, sgrid, dim3(NT), 0, st, (const T*)z, gamma, beta, eps, stats, N, HW, C);
+        CU_LAUNCH_CHECK();
+        return 0;
+    }
+    int nchunks = 1;
+    const int chunk = pick_chunk(nimg, HW, rm.rows, &nchunks);
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)nimg * C, st);
+    CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_stats: memset failed: %s", hipGetErrorString(e));
+    const size_t lds = sizeof(float) * (size_t)rm.rows * rm.tpp * 2 * PIECE;
+    hipLaunchKernelGGL(stats_partial_kernel<T>, dim3(nimg, nchunks), dim3(NT), lds, st, (const T*)z, ws, HW, C, rm.tpp,
+                       rm.rows, chunk);
+    hipLaunchKernelGGL(stats_finalize_kernel<T>, dim3(cdiv(nimg * C, 256)), dim3(256), 0, st, (const T*)z, ws, gamma, beta,
+                       eps, stats, N, HW, C, nimg);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+static int launch_apply(int nimg, int N, int HW, int C, const void* z, const float* stats, float slope, void* out,
+                        hipStream_t st) {
+    const RowMap rm = row_map(C, Elem<T>::PIECE);
+    int nchunks = 1;
+    const int chunk = pick_chunk(nimg, HW, rm.rows, &nchunks);
+    hipLaunchKernelGGL(apply_kernel<T>, dim3(nimg, nchunks), dim3(NT), 0, st, (const T*)z, stats, slope, (T*)out, N, HW, C,
+                       rm.tpp, rm.rows, chunk);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+static int launch_bwd(int nimg, int N, int HW, int C, void* g, const void* z, const float* stats, const float* gamma,
+                      float slope, float* dgamma, float* dbeta, float* dbias, float* ws, hipStream_t st) {
+    constexpr int PIECE = Elem<T>::PIECE;
+    const RowMap rm = row_map(C, PIECE);
+    if (HW <= 1024) {       // small feature maps: one fused launch
+        dim3 sgrid(nimg, cdiv(C / PIECE, SG));
+        hipLaunchKernelGGL(bwd_small_kernel<T>, sgrid, dim3(NT), 0, st, (T*)g, (const T*)z, stats, gamma, slope, dgamma, dbeta,
+                           dbias, N, HW, C);
+        CU_LAUNCH_CHECK();
+        return 0;
+    }
+    int nchunks = 1;
+    const int chunk = pick_chunk(nimg, HW, rm.rows, &nchunks);
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)nimg * C, st);
+    CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_lrelu_bwd: memset failed: %s", hipGetErrorString(e));
+    const size_t lds = sizeof(float) * (size_t)rm.rows * rm.tpp * 2 * PIECE;
+    dim3 grid(nimg, nchunks);
+    hipLaunchKernelGGL(bwd_reduce_kernel<T>, grid, dim3(NT), lds, st, (const T*)g, (const T*)z, stats, slope, ws, N, HW, C,
+                       rm.tpp, rm.rows, chunk);
+    hipLaunchKernelGGL(bwd_apply_kernel<T>, grid, dim3(NT), lds, st, (T*)g, (const T*)z, stats, gamma, slope, ws, dgamma, dbeta,
+                       dbias, N, HW, C, rm.tpp, rm.rows, chunk);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int cu_instnorm_stats(int dtype, int N, int HW, int C, const void* z, const float* gamma, const float* beta,
                                  float eps, float* stats, float* ws, void* stream) {
     NORM_COMMON_CHECKS("cu_instnorm_stats");
     CU_CHECK_ARG(z && stats && ws, "cu_instnorm_stats: null pointer");
-    if (HW <= 1024) {       // small feature maps: one fused launch
-        dim3 sgrid(N, cdiv(C / PIECE, SG));
-        if (dtype == CU_BF16)
-            hipLaunchKernelGGL(stats_small_kernel<bf16_t>, sgrid, dim3(NT), 0, st, (const bf16_t*)z, gamma, beta, eps, stats, N, HW, C);
-        else
-            hipLaunchKernelGGL(stats_small_kernel<float>, sgrid, dim3(NT), 0, st, (const float*)z, gamma, beta, eps, stats, N, HW, C);
-        CU_LAUNCH_CHECK();
-        return 0;
-    }
-    hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)N * C, st);
-    CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_stats: memset failed: %s", hipGetErrorString(e));
-    const size_t lds = sizeof(float) * (size_t)rm.rows * rm.tpp * 2 * PIECE;
-    dim3 grid(N, nchunks);
-    const int fin_blocks = cdiv(N * C, 256);
-    if (dtype == CU_BF16) {
-        hipLaunchKernelGGL(stats_partial_kernel<bf16_t>, grid, dim3(NT), lds, st, (const bf16_t*)z, ws, HW, C, rm.tpp,
-                           rm.rows, chunk);
-        hipLaunchKernelGGL(stats_finalize_kernel<bf16_t>, dim3(fin_blocks), dim3(256), 0, st, (const bf16_t*)z, ws, gamma,
-                           beta, eps, stats, N, HW, C);
-    } else {
-        hipLaunchKernelGGL(stats_partial_kernel<float>, grid, dim3(NT), lds, st, (const float*)z, ws, HW, C, rm.tpp,
-                           rm.rows, chunk);
-        hipLaunchKernelGGL(stats_finalize_kernel<float>, dim3(fin_blocks), dim3(256), 0, st, (const float*)z, ws, gamma,
-                           beta, eps, stats, N, HW, C);
-    }
-    CU_LAUNCH_CHECK();
-    return 0;
+    return dtype == CU_BF16 ? launch_stats<bf16_t>(N, N, HW, C, z, gamma, beta, eps, stats, ws, st)
+                            : launch_stats<float>(N, N, HW, C, z, gamma, beta, eps, stats, ws, st);
 }
 
 extern "C" int cu_instnorm_apply(int dtype, int N, int HW, int C, const void* z, const float* stats, float slope,
                                  void* out, void* stream) {
     NORM_COMMON_CHECKS("cu_instnorm_apply");
     CU_CHECK_ARG(z && stats && out, "cu_instnorm_apply: null pointer");
-    dim3 grid(N, nchunks);
-    if (dtype == CU_BF16)
-        hipLaunchKernelGGL(apply_kernel<bf16_t>, grid, dim3(NT), 0, st, (const bf16_t*)z, stats, slope, (bf16_t*)out, N, HW,
-                           C, rm.tpp, rm.rows, chunk);
-    else
-        hipLaunchKernelGGL(apply_kernel<float>, grid, dim3(NT), 0, st, (const float*)z, stats, slope, (float*)out, N, HW, C,
-                           rm.tpp, rm.rows, chunk);
-    CU_LAUNCH_CHECK();
-    return 0;
+    return dtype == CU_BF16 ? launch_apply<bf16_t>(N, N, HW, C, z, stats, slope, out, st)
+                            : launch_apply<float>(N, N, HW, C, z, stats, slope, out, st);
 }
 
 extern "C" int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, const void* z, const float* stats,
@@ -1011,35 +1043,122 @@ extern "C" int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, c
                                      float* ws, void* stream) {
     NORM_COMMON_CHECKS("cu_instnorm_lrelu_bwd");
     CU_CHECK_ARG(g && z && stats && ws, "cu_instnorm_lrelu_bwd: null pointer");
-    if (HW <= 1024) {       // small feature maps: one fused launch
-        dim3 sgrid(N, cdiv(C / PIECE, SG));
-        if (dtype == CU_BF16)
-            hipLaunchKernelGGL(bwd_small_kernel<bf16_t>, sgrid, dim3(NT), 0, st, (bf16_t*)g, (const bf16_t*)z, stats, gamma, slope,
-                               dgamma, dbeta, dbias, N, HW, C);
-        else
-            hipLaunchKernelGGL(bwd_small_kernel<float>, sgrid, dim3(NT), 0, st, (float*)g, (const float*)z, stats, gamma, slope,
-                               dgamma, dbeta, dbias, N, HW, C);
+    return dtype == CU_BF16 ? launch_bwd<bf16_t>(N, N, HW, C, g, z, stats, gamma, slope, dgamma, dbeta, dbias, ws, st)
+                            : launch_bwd<float>(N, N, HW, C, g, z, stats, gamma, slope, dgamma, dbeta, dbias, ws, st);
+}
+
+// ---- production entry points: per shape, the one-launch resident kernels or the two-pass kernels run on GROUPS of images.
+// Grouping: the second pass of a group re-reads what the first pass has just pulled through the 256 MiB Infinity Cache, so
+// of the 3 (forward) / 5 (backward) passes over the tensor only 2 / 3 come from HBM.  A group is sized so that everything
+// touched between the two uses of a line (both tensors, twice, plus the output) stays far below the cache size.
+constexpr size_t GROUP_BYTES = 32u << 20;        // one tensor of one group
+
+static int rc_pick_np(int HW, int rows) {
+    int np = 8;
+    while (np > 1 && rows * (np / 2) >= HW) np >>= 1;      // a smaller chunk still covers the whole image
+    return np;
+}
+static int group_images(int N, int HW, int C, int esz) {
+    const size_t per_img = (size_t)HW * C * esz;
+    int g = (int)(GROUP_BYTES / per_img);
+    if (g < 1) g = 1;
+    return g > N ? N : g;
+}
+
+extern "C" size_t cu_instnorm_resident_ws_floats(int N, int C) {
+    const size_t a = (size_t)RC_HDR + (size_t)N * rc_block_words(C), b = (size_t)N * C * 2;
+    return a > b ? a : b;
+}
+
+template <typename T, int NP>
+static void launch_fwd_resident(int N, int HW, int C, const RowMap& rm, int nch, const void* z, const float* gamma,
+                                const float* beta, float eps, float slope, float* stats, void* out, float* ws, hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)(rm.rows > 4 ? rm.rows : 4) * rm.tpp * 2 * Elem<T>::PIECE;   // >= 2 C floats
+    hipLaunchKernelGGL((fwd_resident_kernel<T, NP>), dim3(N * nch), dim3(NT), lds, st, (const T*)z, gamma, beta, eps, slope,
+                       stats, (T*)out, ws, N, HW, C, rm.tpp, rm.rows, nch, cu_env_int("CU_NORM_DBG", 0));
+}
+template <typename T, int NP>
+static void launch_bwd_resident(int N, int HW, int C, const RowMap& rm, int nch, void* g, const void* z, const float* stats,
+                                const float* gamma, float slope, float* dgamma, float* dbeta, float* ws, hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)(rm.rows > 4 ? rm.rows : 4) * rm.tpp * 2 * Elem<T>::PIECE;
+    hipLaunchKernelGGL((bwd_resident_kernel<T, NP>), dim3(N * nch), dim3(NT), lds, st, (T*)g, (const T*)z, stats, gamma, slope,
+                       dgamma, dbeta, ws, N, HW, C, rm.tpp, rm.rows, nch, cu_env_int("CU_NORM_DBG", 0));
+}
+#define CU_RC_NP(fn, T, np, ...)                                \
+    do {                                                        \
+        if (np == 8) fn<T, 8>(__VA_ARGS__);                     \
+        else if (np == 4) fn<T, 4>(__VA_ARGS__);                \
+        else if (np == 2) fn<T, 2>(__VA_ARGS__);                \
+        else fn<T, 1>(__VA_ARGS__);                             \
+    } while (0)
+
+extern "C" int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* z, const float* gamma, const float* beta,
+                                     float eps, float slope, float* stats, void* out, float* ws, int mode, void* stream) {
+    NORM_COMMON_CHECKS("cu_instnorm_fwd_fused");
+    CU_CHECK_ARG(z && stats && out && ws, "cu_instnorm_fwd_fused: null pointer");
+    CU_CHECK_ARG(mode >= 0 && mode <= 2, "cu_instnorm_fwd_fused: mode %d", mode);
+    const int np = rc_pick_np(HW, rm.rows);
+    const int nch = cdiv(HW, rm.rows * np);
+    if (mode == 0) mode = (HW <= 256 && nch <= RC_MAX_CHUNKS) ? 1 : 2;      // measured crossover (see the kernels' header)
+    if (mode == 1) {
+        CU_CHECK_ARG(nch <= RC_MAX_CHUNKS, "cu_instnorm_fwd_fused: %d chunks per image exceed %d", nch, RC_MAX_CHUNKS);
+        hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * ((size_t)RC_HDR + (size_t)N * rc_block_words(C)), st);
+        CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_fwd_fused: memset failed: %s", hipGetErrorString(e));
+        if (dtype == CU_BF16) CU_RC_NP(launch_fwd_resident, bf16_t, np, N, HW, C, rm, nch, z, gamma, beta, eps, slope, stats, out, ws, st);
+        else CU_RC_NP(launch_fwd_resident, float, np, N, HW, C, rm, nch, z, gamma, beta, eps, slope, stats, out, ws, st);
         CU_LAUNCH_CHECK();
         return 0;
     }
-    hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)N * C, st);
-    CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_lrelu_bwd: memset failed: %s", hipGetErrorString(e));
-    const size_t lds = sizeof(float) * (size_t)rm.rows * rm.tpp * 2 * PIECE;
-    dim3 grid(N, nchunks);
-    if (dtype == CU_BF16) {
-        hipLaunchKernelGGL(bwd_reduce_kernel<bf16_t>, grid, dim3(NT), lds, st, (const bf16_t*)g, (const bf16_t*)z, stats,
-                           slope, ws, N, HW, C, rm.tpp, rm.rows, chunk);
-        hipLaunchKernelGGL(bwd_apply_kernel<bf16_t>, grid, dim3(NT), lds, st, (bf16_t*)g, (const bf16_t*)z, stats, gamma,
-                           slope, ws, dgamma, dbeta, dbias, N, HW, C, rm.tpp, rm.rows, chunk);
-    } else {
-        hipLaunchKernelGGL(bwd_reduce_kernel<float>, grid, dim3(NT), lds, st, (const float*)g, (const float*)z, stats,
-                           slope, ws, N, HW, C, rm.tpp, rm.rows, chunk);
-        hipLaunchKernelGGL(bwd_apply_kernel<float>, grid, dim3(NT), lds, st, (float*)g, (const float*)z, stats, gamma,
-                           slope, ws, dgamma, dbeta, dbias, N, HW, C, rm.tpp, rm.rows, chunk);
+    const int esz = dtype == CU_BF16 ? 2 : 4;
+    const int gi = group_images(N, HW, C, esz);
+    for (int n0 = 0; n0 < N; n0 += gi) {
+        const int ni = N - n0 < gi ? N - n0 : gi;
+        const char* zp = (const char*)z + (size_t)n0 * HW * C * esz;
+        char* op = (char*)out + (size_t)n0 * HW * C * esz;
+        float* sp = stats + (size_t)n0 * C;
+        int rc = dtype == CU_BF16 ? launch_stats<bf16_t>(ni, N, HW, C, zp, gamma, beta, eps, sp, ws + (size_t)n0 * C * 2, st)
+                                  : launch_stats<float>(ni, N, HW, C, zp, gamma, beta, eps, sp, ws + (size_t)n0 * C * 2, st);
+        if (rc) return rc;
+        rc = dtype == CU_BF16 ? launch_apply<bf16_t>(ni, N, HW, C, zp, sp, slope, op, st)
+                              : launch_apply<float>(ni, N, HW, C, zp, sp, slope, op, st);
+        if (rc) return rc;
     }
-    CU_LAUNCH_CHECK();
     return 0;
 }
+
+extern "C" int cu_instnorm_bwd_fused(int dtype, int N, int HW, int C, void* g, const void* z, const float* stats,
+                                     const float* gamma, float slope, float* dgamma, float* dbeta, float* ws, int mode,
+                                     void* stream) {
+    NORM_COMMON_CHECKS("cu_instnorm_bwd_fused");
+    CU_CHECK_ARG(g && z && stats && ws, "cu_instnorm_bwd_fused: null pointer");
+    CU_CHECK_ARG(mode >= 0 && mode <= 2, "cu_instnorm_bwd_fused: mode %d", mode);
+    const int np = rc_pick_np(HW, rm.rows);
+    const int nch = cdiv(HW, rm.rows * np);
+    if (mode == 0) mode = (HW > 1024 && HW <= 4096 && nch <= RC_MAX_CHUNKS) ? 1 : 2;
+    if (mode == 1) {
+        CU_CHECK_ARG(nch <= RC_MAX_CHUNKS, "cu_instnorm_bwd_fused: %d chunks per image exceed %d", nch, RC_MAX_CHUNKS);
+        hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * ((size_t)RC_HDR + (size_t)N * rc_block_words(C)), st);
+        CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_bwd_fused: memset failed: %s", hipGetErrorString(e));
+        if (dtype == CU_BF16) CU_RC_NP(launch_bwd_resident, bf16_t, np, N, HW, C, rm, nch, g, z, stats, gamma, slope, dgamma, dbeta, ws, st);
+        else CU_RC_NP(launch_bwd_resident, float, np, N, HW, C, rm, nch, g, z, stats, gamma, slope, dgamma, dbeta, ws, st);
+        CU_LAUNCH_CHECK();
+        return 0;
+    }
+    const int esz = dtype == CU_BF16 ? 2 : 4;
+    const int gi = group_images(N, HW, C, esz);
+    for (int n0 = 0; n0 < N; n0 += gi) {
+        const int ni = N - n0 < gi ? N - n0 : gi;
+        char* gp = (char*)g + (size_t)n0 * HW * C * esz;
+        const char* zp = (const char*)z + (size_t)n0 * HW * C * esz;
+        const float* sp = stats + (size_t)n0 * C;
+        const int rc = dtype == CU_BF16
+            ? launch_bwd<bf16_t>(ni, N, HW, C, gp, zp, sp, gamma, slope, dgamma, dbeta, nullptr, ws + (size_t)n0 * C * 2, st)
+            : launch_bwd<float>(ni, N, HW, C, gp, zp, sp, gamma, slope, dgamma, dbeta, nullptr, ws + (size_t)n0 * C * 2, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+#undef CU_RC_NP
 
 extern "C" int cu_act_bwd(int dtype, int N, int HW, int C, void* g, const void* z, float slope, float* dbias,
                           void* stream) {

@@ -214,26 +214,28 @@ def _resident_ws(n: int, c: int, device) -> Tensor:
 
 
 def instnorm_fwd_fused(z: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], slope: float, eps: float = 1e-5,
-                       ws: Optional[Tensor] = None) -> Act:
-    """statistics + LeakyReLU(z*scale + shift) in ONE launch, z read once (cu_instnorm_fwd_fused) -> Act(z, stats, a)."""
+                       ws: Optional[Tensor] = None, mode: int = 0) -> Act:
+    """statistics + LeakyReLU(z*scale + shift) in one call (cu_instnorm_fwd_fused; mode 0 auto, 1 resident-chunk
+    kernel, 2 two-pass kernels on cache-sized image groups) -> Act(z, stats, a)."""
     n, h, w_, c = z.shape
     stats = torch.empty((4, n, c), dtype=torch.float32, device=z.device)
     out = torch.empty_like(z)
     ws = _resident_ws(n, c, z.device) if ws is None else ws
     with _Prof("instnorm_fwd", 0.0, f"N{n} {h}x{w_} C{c}", 2 * z.numel() * z.element_size()):
         L.check(L.load().cu_instnorm_fwd_fused(L.dtype_code(z.dtype), n, h * w_, c, L.ptr(z), L.ptr(gamma), L.ptr(beta), eps,
-                                               slope, L.ptr(stats), L.ptr(out), L.ptr(ws), L.stream_ptr()),
+                                               slope, L.ptr(stats), L.ptr(out), L.ptr(ws), mode, L.stream_ptr()),
                 "cu_instnorm_fwd_fused")
     return Act(z, stats, slope, out, ws)
 
 
-def instnorm_bwd_fused(g: Tensor, act: Act, gamma: Optional[Tensor], dgamma, dbeta, ws: Optional[Tensor] = None):
-    """In place: g (dL/d activated) -> dL/dz, g and z read once (cu_instnorm_bwd_fused)."""
+def instnorm_bwd_fused(g: Tensor, act: Act, gamma: Optional[Tensor], dgamma, dbeta, ws: Optional[Tensor] = None,
+                       mode: int = 0):
+    """In place: g (dL/d activated) -> dL/dz (cu_instnorm_bwd_fused; modes as instnorm_fwd_fused)."""
     n, h, w_, c = g.shape
     ws = _resident_ws(n, c, g.device) if ws is None else ws
     with _Prof("instnorm_bwd", 0.0, f"N{n} {h}x{w_} C{c}", 3 * g.numel() * g.element_size()):
         L.check(L.load().cu_instnorm_bwd_fused(L.dtype_code(g.dtype), n, h * w_, c, L.ptr(g), L.ptr(act.z), L.ptr(act.stats),
-                                               L.ptr(gamma), act.slope, L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws),
+                                               L.ptr(gamma), act.slope, L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), mode,
                                                L.stream_ptr()), "cu_instnorm_bwd_fused")
     return ws
 

@@ -120,18 +120,22 @@ int cu_instnorm_apply(int dtype, int N, int HW, int C, const void* z, const floa
 int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, const void* z, const float* stats,
                           const float* gamma, float slope, float* dgamma, float* dbeta, float* dbias,
                           float* ws, void* stream);
-/* The same two operations with every tensor read ONCE (production path of the engine): workgroups keep their pixel
- * chunk in registers while the per-(image, channel) sums are combined with atomics behind an image-local arrival counter
- * (norm.hip, "resident-chunk kernels").
- *   forward : stats as above AND out = LeakyReLU(z*scale + shift) in one launch (z read once, out written once)
- *   backward: as cu_instnorm_lrelu_bwd without dbias (identically zero behind an InstanceNorm): g, z read once
- * ws: f32 workspace of cu_instnorm_resident_ws_floats(N, C) elements, zero-filled by the call.  After the stream has
- * drained, ((unsigned*)ws)[1] != 0 reports that the bounded arrival wait gave up (results then invalid). */
+/* Production entry points of the engine for the same two operations, in ONE call per direction:
+ *   forward : stats as above AND out = LeakyReLU(z*scale + shift)
+ *   backward: as cu_instnorm_lrelu_bwd without dbias (identically zero behind an InstanceNorm)
+ * mode 0 picks per shape between
+ *   1  "resident": one launch, every tensor read once -- workgroups keep their pixel chunk in registers while the
+ *      per-(image, channel) sums are combined with atomics behind an image-local arrival counter (norm.hip), and
+ *   2  "grouped": the two-pass kernels on groups of images small enough that the second pass re-reads the group from
+ *      the Infinity Cache instead of HBM.
+ * ws: f32 workspace of cu_instnorm_resident_ws_floats(N, C) elements (zero-filled by the call as needed).  After the
+ * stream has drained, ((unsigned*)ws)[1] != 0 after a mode-1 call reports that its bounded arrival wait gave up. */
 size_t cu_instnorm_resident_ws_floats(int N, int C);
 int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* z, const float* gamma, const float* beta,
-                          float eps, float slope, float* stats, void* out, float* ws, void* stream);
+                          float eps, float slope, float* stats, void* out, float* ws, int mode, void* stream);
 int cu_instnorm_bwd_fused(int dtype, int N, int HW, int C, void* g, const void* z, const float* stats,
-                          const float* gamma, float slope, float* dgamma, float* dbeta, float* ws, void* stream);
+                          const float* gamma, float slope, float* dgamma, float* dbeta, float* ws, int mode,
+                          void* stream);
 /* x[n][p][c] *= mask[n][c] in place: nn.Dropout2d(p) between conv and norm (layers.py:154-164,199-202), forward and
  * backward (mask entries are 0 or 1/(1-p)) */
 int cu_channel_scale(int dtype, int N, int HW, int C, void* x, const float* mask, void* stream);

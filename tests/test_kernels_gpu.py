@@ -241,10 +241,12 @@ def test_instnorm_fwd_bwd(dtype, shape):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(3, 32, 128), (2, 32, 64), (3, 480, 4), (2, 128, 16), (64, 480, 2), (5, 64, 48),
                                    (2, 256, 32), (3, 480, 16), (2, 480, 8)])
-def test_instnorm_resident_kernels(dtype, shape):
-    """One-launch forward (statistics + normalise + LeakyReLU, z read once) and one-launch backward (reduce + apply,
-    g and z read once) vs F.instance_norm -> leaky_relu autograd: images spanning 1 .. 256 chunks, a ragged last
-    chunk (48 x 48), 480 channels (threads-per-pixel not a power of two), tiny maps."""
+@pytest.mark.parametrize("mode", [1, 2, 0])
+def test_instnorm_fused_entry_points(dtype, shape, mode):
+    """cu_instnorm_fwd_fused / cu_instnorm_bwd_fused in their resident-chunk form (mode 1: one launch, every tensor read
+    once), their grouped two-pass form (mode 2) and as the engine calls them (mode 0) vs F.instance_norm -> leaky_relu
+    autograd: images spanning 1 .. 256 chunks, a ragged last chunk (48 x 48), 480 channels (threads-per-pixel not a power
+    of two), tiny maps."""
     ops = _ops()
     n, c, size = shape
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -256,8 +258,8 @@ def test_instnorm_resident_kernels(dtype, shape):
     gm = gamma.clone().requires_grad_(True)
     bt = beta.clone().requires_grad_(True)
     ref = F.leaky_relu(F.instance_norm(zf, weight=gm, bias=bt, eps=1e-5), 0.01)
-    act = ops.instnorm_fwd_fused(z, gamma, beta, 0.01, 1e-5)
-    assert not ops.resident_wait_failed(act.ws, n, c)
+    act = ops.instnorm_fwd_fused(z, gamma, beta, 0.01, 1e-5, mode=mode)
+    assert mode != 1 or not ops.resident_wait_failed(act.ws, n, c)
     mean = zf.detach().mean((2, 3))
     var = zf.detach().var((2, 3), unbiased=False)
     assert torch.allclose(act.stats[0], mean, rtol=1e-5, atol=1e-5)
@@ -272,8 +274,8 @@ def test_instnorm_resident_kernels(dtype, shape):
     gt = nhwc(go, dtype)
     dgamma = torch.zeros(c, device=DEV)
     dbeta = torch.zeros(c, device=DEV)
-    ws = ops.instnorm_bwd_fused(gt, act, gamma, dgamma, dbeta)
-    assert not ops.resident_wait_failed(ws, n, c)
+    ws = ops.instnorm_bwd_fused(gt, act, gamma, dgamma, dbeta, mode=mode)
+    assert mode != 1 or not ops.resident_wait_failed(ws, n, c)
     t = 2e-4 if dtype == torch.float32 else 1.5e-2
     assert rel_err(nchw(gt), zf.grad) < t
     assert rel_err(dgamma, gm.grad) < 2e-4 and rel_err(dbeta, bt.grad) < 2e-4

@@ -29,8 +29,8 @@ def timed(fn):
     return e0.elapsed_time(e1) / REP * 1e3
 
 
-print("# size C | fwd two-pass us | fwd resident us | bwd two-pass us | bwd resident us | tensor MB")
-tot = [0.0] * 4
+print("# size C | fwd: two-pass, resident, grouped, auto us | bwd: two-pass, resident, grouped, auto us | tensor MB")
+tot = [0.0] * 8
 for size, c in shapes:
     z = torch.randn(N, size, size, c, device=dev).bfloat16()
     g = torch.randn(N, size, size, c, device=dev).bfloat16()
@@ -44,13 +44,17 @@ for size, c in shapes:
         return a
     act = fwd2()
     ws = ops._resident_ws(N, c, dev)
-    t = [timed(fwd2), timed(lambda: ops.instnorm_fwd_fused(z, gamma, beta, 0.01, ws=ws)),
-         timed(lambda: ops.instnorm_lrelu_bwd(g, act, gamma, dg, db, None)),
-         timed(lambda: ops.instnorm_bwd_fused(g, act, gamma, dg, db, ws))]
+    t = [timed(fwd2)] + [timed(lambda m=m: ops.instnorm_fwd_fused(z, gamma, beta, 0.01, ws=ws, mode=m)) for m in (1, 2, 0)]
     failed = ops.resident_wait_failed(ws, N, c)
+    t += [timed(lambda: ops.instnorm_lrelu_bwd(g, act, gamma, dg, db, None))]
+    for m in (1, 2, 0):
+        t.append(timed(lambda m=m: ops.instnorm_bwd_fused(g, act, gamma, dg, db, ws, mode=m)))
+        failed = failed or (m == 1 and ops.resident_wait_failed(ws, N, c))
     mb = z.numel() * 2 / 1e6
-    print(f"{size:4d} {c:4d} | {t[0]:8.1f} | {t[1]:8.1f} | {t[2]:8.1f} | {t[3]:8.1f} | {mb:7.1f}" + ("  WAIT FAILED" if failed else ""))
+    print(f"{size:4d} {c:4d} | " + " ".join(f"{v:7.1f}" for v in t[:4]) + " | " + " ".join(f"{v:7.1f}" for v in t[4:]) +
+          f" | {mb:7.1f}" + ("  WAIT FAILED" if failed else ""))
     mult = 4 if size > 2 else 2
-    for i in range(4):
+    for i in range(8):
         tot[i] += mult * t[i]
-print(f"# per step (4 layers per level): fwd {tot[0]/1e3:.2f} -> {tot[1]/1e3:.2f} ms, bwd {tot[2]/1e3:.2f} -> {tot[3]/1e3:.2f} ms")
+print("# per step (4 layers per level), ms: fwd " + " ".join(f"{v/1e3:.2f}" for v in tot[:4]) + " | bwd " +
+      " ".join(f"{v/1e3:.2f}" for v in tot[4:]))

@@ -1047,11 +1047,12 @@ extern "C" int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, c
                             : launch_bwd<float>(N, N, HW, C, g, z, stats, gamma, slope, dgamma, dbeta, dbias, ws, st);
 }
 
-// ---- production entry points: per shape, the one-launch resident kernels or the two-pass kernels run on GROUPS of images.
-// Grouping: the second pass of a group re-reads what the first pass has just pulled through the 256 MiB Infinity Cache, so
-// of the 3 (forward) / 5 (backward) passes over the tensor only 2 / 3 come from HBM.  A group is sized so that everything
-// touched between the two uses of a line (both tensors, twice, plus the output) stays far below the cache size.
-constexpr size_t GROUP_BYTES = 32u << 20;        // one tensor of one group
+// ---- production entry points: per shape, the one-launch resident kernels or the two-pass kernels.
+// The two-pass form can run on GROUPS of images so that the second pass of a group re-reads what the first pass has just
+// pulled through the 256 MiB Infinity Cache.  Measured (profiles/r02_norm_bench.txt): with 32 MiB groups the 4 launches
+// per group cost more than the cache saves (256^2 x 32 x 64 images: forward 400 us against 177 us ungrouped, backward
+// 544 against 305), so one group = the whole batch is the default; the mechanism stays for larger batches.
+constexpr size_t GROUP_BYTES = (size_t)1 << 40;  // one tensor of one group
 
 static int rc_pick_np(int HW, int rows) {
     int np = 8;

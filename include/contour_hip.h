@@ -126,8 +126,7 @@ int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, const void* 
  * mode 0 picks per shape between
  *   1  "resident": one launch, every tensor read once -- workgroups keep their pixel chunk in registers while the
  *      per-(image, channel) sums are combined with atomics behind an image-local arrival counter (norm.hip), and
- *   2  "grouped": the two-pass kernels on groups of images small enough that the second pass re-reads the group from
- *      the Infinity Cache instead of HBM.
+ *   2  the two-pass kernels (statistics / reduction pass, then apply pass).
  * ws: f32 workspace of cu_instnorm_resident_ws_floats(N, C) elements (zero-filled by the call as needed).  After the
  * stream has drained, ((unsigned*)ws)[1] != 0 after a mode-1 call reports that its bounded arrival wait gave up. */
 size_t cu_instnorm_resident_ws_floats(int N, int C);

@@ -11,6 +11,7 @@ import torch
 from contour_uncertainty._compat import ContourTags, Tags, to_absolute_path
 from contour_uncertainty.data.config import BatchResult
 from contour_uncertainty.task.regression.contour_uncertainty import ContourUncertaintyTask
+from contour_uncertainty.utils.posterior_stats import sample_moments_per_member, total_moments
 
 
 class AleatoricUncertaintyTask(ContourUncertaintyTask):
@@ -60,23 +61,9 @@ class AleatoricUncertaintyTask(ContourUncertaintyTask):
         n = img.shape[0]
         mu, cov = self.predict(img)                      # (N, T_e, K, 2), (N, T_e, K, 2, 2) on CPU
         contour_samples = self.sample(mu, cov, self.hparams.t_a)
-        mu_mean = mu.mean(dim=1, keepdim=True)
-        cov_al = cov.mean(1)
-        d = (mu - mu_mean)[..., None]
-        cov_ep = torch.mean(d * d.swapaxes(-1, -2), dim=1)
-        mu_np = mu.mean(dim=1).cpu().numpy()
-        cov_np = (cov_al + cov_ep).cpu().numpy()
-        post_mu = contour_samples.mean(axis=2)
-        k = contour_samples.shape[3]
-        post_cov = np.zeros((n, contour_samples.shape[1], k, 2, 2))
-        for idx in range(n):
-            for i in range(contour_samples.shape[1]):
-                for kk in range(k):
-                    post_cov[idx, i, kk] = np.cov(contour_samples[idx, i, :, kk].reshape(-1, 2).T)
-        pm = post_mu.mean(axis=1, keepdims=True)
-        dd = (post_mu - pm)[..., None]
-        post_cov = np.mean(dd * dd.swapaxes(-1, -2), axis=1) + post_cov.mean(1)
-        post_mu = post_mu.mean(axis=1)
+        mu_np, cov_al, cov_ep = total_moments(mu, cov)
+        cov_np = cov_al + cov_ep
+        post_mu, post_cov = sample_moments_per_member(contour_samples)
         pred, pred_samples = self.convert_to_mask(mu_np, img.shape, contour_samples)
         pred = pred_samples.mean(axis=(1, 2)).squeeze().round().astype(int)
         umap = None

@@ -10,6 +10,7 @@ import torch
 from contour_uncertainty._compat import ContourTags, Tags, to_absolute_path
 from contour_uncertainty.data.config import BatchResult
 from contour_uncertainty.task.regression.aleatoric import AleatoricUncertaintyTask
+from contour_uncertainty.utils.posterior_stats import sample_moments_pooled, total_moments
 
 
 class SkewUncertaintyTask(AleatoricUncertaintyTask):
@@ -52,19 +53,10 @@ class SkewUncertaintyTask(AleatoricUncertaintyTask):
         n = img.shape[0]
         mu, cov, alpha = self.predict(img)
         contour_samples = self.sample(mu, cov, alpha, 25)            # T hard-coded in the reference (:63)
-        mu_mean = mu.mean(dim=1, keepdim=True)
-        cov_al = cov.mean(1)
-        d = (mu - mu_mean)[..., None]
-        cov_ep = torch.mean(d * d.swapaxes(-1, -2), dim=1)
-        mu_np = mu.mean(dim=1).cpu().numpy()
+        mu_np, cov_al, cov_ep = total_moments(mu, cov)
+        cov_np = cov_ep + cov_al
         alpha_np = alpha.mean(dim=1).cpu().numpy()
-        cov_np = (cov_ep + cov_al).cpu().numpy()
-        post_mu = contour_samples.mean(axis=(1, 2))
-        k = contour_samples.shape[3]
-        post_cov = np.zeros((n, k, 2, 2))
-        for idx in range(n):
-            for kk in range(k):
-                post_cov[idx, kk] = np.cov(contour_samples[idx, :, :, kk].reshape(-1, 2).T)
+        post_mu, post_cov = sample_moments_pooled(contour_samples)
         mode, umap = mu_np, None
         if self.skew_umap_fn is not None:
             mm, uu = zip(*[self.skew_umap_fn(mu_np[i], cov_np[i], alpha_np[i], self.hparams.data_params.labels)

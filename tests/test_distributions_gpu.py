@@ -62,3 +62,17 @@ def test_skew_rvs_moments():
     z = eps[0] @ torch.linalg.cholesky(cs).T
     ref = torch.where(z[:, :1] <= 0, -z[:, 1:], z[:, 1:]) + mu.cpu()
     assert torch.allclose(got, ref, atol=1e-3)
+
+
+def test_skew_rvs_vs_reference_golden(golden_dir):
+    """cu_skew_rvs against BivariateSkewNormal.rvs_fast of the imported reference with the generator state pinned
+    (tests/golden/skew_grid.npz: rvs_eps are the normals MultivariateNormal.sample drew, rvs_x what it returned;
+    reference distributions/bivariateskewnormal.py:159-191)."""
+    from contour_uncertainty.distributions.bivariateskewnormal import BivariateSkewNormal
+    g = np.load(golden_dir / "skew_grid.npz")
+    mu, cov, alpha = (torch.from_numpy(g[k]).cuda() for k in ("rvs_mu", "rvs_cov", "rvs_alpha"))
+    eps = torch.from_numpy(g["rvs_eps"]).float()[None].cuda()           # (1, 64, 3)
+    got = BivariateSkewNormal.rvs_fast(mu, cov, alpha, size=(64,), eps=eps).cpu()
+    ref = torch.from_numpy(g["rvs_x"])
+    assert got.shape == ref.shape == (64, 2)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5

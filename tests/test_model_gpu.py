@@ -386,6 +386,21 @@ def test_predict_step_sampling_fanout(golden_dir, kind, seq):
     assert res.mu.shape == (n, k, 2) and res.cov.shape == (n, k, 2, 2)
     assert res.post_mu.shape[-2:] == (k, 2) and np.isfinite(res.post_cov).all()
     assert set(res.point_uncertainty) >= {"cov_xx", "cov_yy", "cov_det", "cov_eigval_sum"}
+    # a15: al / ep split and the sample covariances of THIS step's draws vs the loop-for-loop restatement of the
+    # reference (oracle/predict_stats.py; aleatoric.py:88-108, aleatoric_skew.py:65-82).  predict() is deterministic at
+    # t_e = 1 without dropout, so the step's (mu, cov[, alpha]) are `out`.
+    from oracle import predict_stats as PS
+    if kind == "dsnt-al":
+        ref = PS.aleatoric_stats(out[0], out[1], cs)
+    else:
+        ref = PS.aleatoric_skew_stats(out[0], out[1], out[2], cs)
+        assert np.allclose(res.alpha, ref["alpha"], rtol=1e-5, atol=1e-6)
+    # two predict() calls differ by the rounding order of the f32 atomics in the InstanceNorm statistics (~1e-5 of a
+    # covariance's scale), so the tolerances are relative to each tensor's largest entry
+    def close(a, b, tol):
+        return np.abs(np.asarray(a, dtype=np.float64) - b).max() <= tol * np.abs(b).max()
+    assert close(res.mu, ref["mu"], 1e-4) and close(res.cov, ref["cov"], 2e-4)
+    assert close(res.post_mu, ref["post_mu"], 1e-5) and close(res.post_cov, ref["post_cov"], 1e-5)
 
 
 @pytest.mark.parametrize("kind", ["dsnt-al", "dsnt-skew"])

@@ -721,6 +721,8 @@ int launch(const ConvKArgs& a, size_t lds, int grid_x, int grid_y, hipStream_t s
 
 }  // namespace
 
+int cu_pconv_try(const cu_conv_desc* d, const void* src0, const void* w, const float* bias, void* dst0, void* stream);
+
 extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float* scale0, const float* shift0,
                             const void* src1, const float* scale1, const float* shift1, const void* w,
                             const float* bias, void* dst0, void* dst1, void* stream) {
@@ -766,6 +768,12 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
                  "cu_conv_gemm: bad parity-column mode (par_co=%d)", d->par_co);
     const int CI = d->C0 + d->C1;
     a.dbg = cu_env_int("CU_CONV_DBG", 0);
+
+    // ---- few-tap / strided bf16 gathers of plain operands: the lean gather-GEMM (pconv.hip)
+    if (bf && !scale0 && !scale1 && !cu_env_set("CU_CONV_NOPCONV")) {
+        const int rc = cu_pconv_try(d, src0, w, bias, dst0, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
 
     // ---- wide bf16 3x3 stride-1 layers whose weight slice cannot stay in LDS: 8-wave LDS-DMA kernel
     {

@@ -48,7 +48,7 @@ def _s2_parity_taps():
 
 
 S2_PARITY_TAPS = _s2_parity_taps()
-ONE_PASS_S2_DGRAD = False
+ONE_PASS_S2_DGRAD = True      # bf16: one pass on the lean gather-GEMM (pconv.hip); f32 parity mode keeps four launches
 
 
 @dataclass
@@ -300,11 +300,11 @@ class UNetEngine:
         if rec.stride == 1:
             ops.conv_gemm([gz], wd, None, grid=(sh, sw), in_stride=1, taps=TAPS3_D, dsts=dsts, dst_cols=cols,
                           accum=acc)
-        elif ONE_PASS_S2_DGRAD and len(dsts) == 1 and cols[0] % 32 == 0:
+        elif ONE_PASS_S2_DGRAD and self.dtype == torch.bfloat16 and len(dsts) == 1 and cols[0] % 32 == 0:
             # all four input parities in one pass: gather taps = the 2x2 neighbourhood of dz, the weight tap of
-            # (gather tap, parity) from S2_PARITY_TAPS (9 of the 16 pairs exist); dz is read once.  Measured SLOWER than
-            # the four parity launches below (128^2 x 64->32: 271 vs 194 us; 16/9 of the MFMA work and the 64-byte
-            # half-line stores of the parity epilogue), so it is off; tools/conv_bench.py s2dgrad compares the two.
+            # (gather tap, parity) from S2_PARITY_TAPS (9 of the 16 pairs exist, the others are skipped); dz is read once.
+            # (On the tile-generic kernel this form was slower than four parity launches -- 16/9 of the MFMA work; the
+            # lean gather-GEMM skips the absent pairs.  tools/conv_bench.py s2dgrad compares the two.)
             ops.conv_gemm([gz], wd, None, grid=(sh // 2, sw // 2), in_stride=1,
                           taps=[(u, v, 0) for u in range(2) for v in range(2)], dsts=dsts, dst_cols=cols, out_stride=2,
                           accum=acc, n_cols=4 * cols[0], parity_cols=cols[0], parity_taps=S2_PARITY_TAPS)

@@ -20,7 +20,7 @@
 //   * LDS images are [128 rows][128 bytes] (64 channels of a pixel / of a weight row), 16-byte piece p of row r stored at
 //     slot p ^ ((r >> 1) & 7) (swizzle on the DMA source address and on the read): conflict-free ds_read_b128 fragments;
 //   * the weights stay resident in LDS when the whole slice is small (thin layers), else they stream with the pixels;
-//   * two LDS stages: the DMA of iteration i + 1 flies under the MFMAs of iteration i; <= 128 VGPRs, 2+ workgroups per CU.
+//   * a ring of LDS stages with counted waits: three blocks are always in flight, across taps, chunks and tiles.
 #include "common.h"
 
 namespace {
@@ -58,13 +58,13 @@ __device__ __forceinline__ void col_block(const PcArgs& p, int ct, int b, int& g
     }
 }
 
-template <bool WRES>
+template <bool WRES, int PRING>
 __global__ __launch_bounds__(256, 2) void pconv_kernel(const PcArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int ct = blockIdx.y;
-    const unsigned a_base = lds_addr(smem);                                  // 2 stages of pixels
-    const unsigned w_base = a_base + 2 * PSTAGE;                             // weights: resident slice or 2 stages
+    const unsigned a_base = lds_addr(smem);                                  // ring of pixel blocks
+    const unsigned w_base = a_base + PRING * PSTAGE;                         // weights: resident slice or their own ring
     const i32x4 rs = make_rsrc(p.src, p.src_bytes);
     const i32x4 rw = make_rsrc(p.w, p.w_bytes);
     constexpr unsigned OOB = 0x7ffffff0u;
@@ -98,20 +98,34 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const PcArgs p) {
         for (int t = 0; t < p.ntaps; ++t)
             if (wgrp[b] < p.ngroups && wc0[b] < p.gcols && s_wrow[t * 4 + wgrp[b]] >= 0) benable |= 1ull << (t * 4 + b);
     }
+    // resident weights are PACKED: only the (iteration, block) pairs that exist get a 4-KiB slot (the stride-2 input gradient
+    // uses 9 of its 16 (gather tap, parity) pairs), which is what lets two workgroups share a CU on the thin layers
+    __shared__ unsigned char s_wslot[PMAXT * 8 * 4];
+    if constexpr (WRES) {
+        if (tid == 0) {
+            int cnt = 0;
+            for (int i = 0; i < niter; ++i)
+                for (int b = 0; b < 4; ++b)
+                    s_wslot[i * 4 + b] = (unsigned char)(((benable >> ((i / p.kchunks) * 4 + b)) & 1ull) ? cnt++ : 0);
+        }
+        __syncthreads();
+    }
     auto issue_w = [&](int t, int kc, unsigned dst) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 4; ++s) {                    // slot s of this thread = block s of the 128 weight rows
+            if (WRES && !((benable >> (t * 4 + s)) & 1ull)) continue;       // uniform
             const int row = prow[s], b = row >> 5;
             const int col = wc0[b] + (row & 31);
             const int k = kc * PKC + ppiece[s] * 8;
             const int wr = s_wrow[t * 4 + (wgrp[b] < p.ngroups ? wgrp[b] : 0)];
             const bool ok = ((benable >> (t * 4 + b)) & 1u) && col < p.gcols && k < p.C;
             const unsigned off = ok ? (unsigned)(((wr + col) * p.C + k) * 2) : OOB;
-            dma16(rw, off, dst + (unsigned)(s * 4096 + wave * 1024));
+            const unsigned slot = WRES ? (unsigned)s_wslot[(t * p.kchunks + kc) * 4 + s] : (unsigned)s;
+            dma16(rw, off, dst + slot * 4096u + (unsigned)(wave * 1024));
         }
     };
     if constexpr (WRES) {
-        for (int it = 0; it < niter; ++it) issue_w(it / p.kchunks, it % p.kchunks, w_base + (unsigned)it * PSTAGE);
+        for (int it = 0; it < niter; ++it) issue_w(it / p.kchunks, it % p.kchunks, w_base);
     }
 
     // ---- fragment read offsets (bytes inside a block): row = 32 * wave + r (pixels) / 32 * b + r (weights)
@@ -121,50 +135,86 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const PcArgs p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) wsw[b] = ((b * 32 + r) >> 1) & 7;
 
+    // ---- the workgroup's work as ONE flat sequence of iterations (tile k, tap t, chunk kc), staged through a ring of
+    //      PRING LDS stages: the DMA of iteration j + PRING - 1 is issued when iteration j starts, so PRING - 1 blocks are
+    //      always in flight -- across taps, chunks AND tile boundaries (the epilogue of a tile runs under the next tile's
+    //      loads).  Waits are COUNTED: vmcnt(D * younger) leaves the younger iterations' DMAs in flight.  (First version:
+    //      two stages and s_waitcnt vmcnt(0) per iteration = one exposed L2/HBM round trip per 16 KiB block; the stride-2
+    //      input gradient at 128^2 took 347 us against 306 us for four launches of the tile-generic kernel.)
+    constexpr int D = WRES ? 4 : 8;                  // DMA wave-instructions per iteration and wave
     const int pw = 1 << p.pwl, ph = 1 << p.phl;
-    for (int tile = blockIdx.x; tile < p.mtiles; tile += gridDim.x) {
-        // ---- per-tile geometry of this thread's 4 staging rows
-        int sy0[4], sx0[4], nb[4];
-        unsigned rvalid = 0;
+    const int my_tiles = blockIdx.x < p.mtiles ? (p.mtiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    const int T = my_tiles * niter;
+    // issue-side cursor
+    int iss = 0, iss_it = 0, iss_tile = blockIdx.x, iss_st = 0;
+    int sy0[4], sx0[4], nb[4];
+    unsigned rvalid = 0;
+    auto issue_geo = [&]() {
+        rvalid = 0;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int m = tile * PBM + prow[s];
+            const int m = iss_tile * PBM + prow[s];
             const int px = m & (pw - 1), py = (m >> p.pwl) & (ph - 1), n = m >> (p.pwl + p.phl);
             sy0[s] = py * p.IS; sx0[s] = px * p.IS; nb[s] = n * p.SH;
             rvalid |= (m < p.M ? 1u : 0u) << s;
         }
-        auto issue_a = [&](int t, int kc, unsigned dst) {
-            const int dy = s_tab[t], dx = s_tab[PMAXT + t];
+    };
+    auto issue_next = [&]() {
+        const int t = iss_it / p.kchunks, kc = iss_it - t * p.kchunks;
+        const unsigned stg = (unsigned)iss_st * PSTAGE;
+        iss_st = iss_st + 1 == PRING ? 0 : iss_st + 1;
+        const int dy = s_tab[t], dx = s_tab[PMAXT + t];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int sy = sy0[s] + dy, sx = sx0[s] + dx;
-                const int k = kc * PKC + ppiece[s] * 8;
-                const bool ok = ((rvalid >> s) & 1u) && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW && k < p.C;
-                const unsigned off = ok ? (unsigned)((((nb[s] + sy) * p.SW + sx) * p.C + k) * 2) : OOB;
-                dma16(rs, off, dst + (unsigned)(s * 4096 + wave * 1024));
-            }
-        };
-        f32x16 acc[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+        for (int s = 0; s < 4; ++s) {
+            const int sy = sy0[s] + dy, sx = sx0[s] + dx;
+            const int k = kc * PKC + ppiece[s] * 8;
+            const bool ok = ((rvalid >> s) & 1u) && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW && k < p.C;
+            const unsigned off = ok ? (unsigned)((((nb[s] + sy) * p.SW + sx) * p.C + k) * 2) : OOB;
+            dma16(rs, off, a_base + stg + (unsigned)(s * 4096 + wave * 1024));
+        }
+        if constexpr (!WRES) issue_w(t, kc, w_base + stg);
+        ++iss;
+        if (++iss_it == niter) { iss_it = 0; iss_tile += gridDim.x; issue_geo(); }
+    };
+    if (T > 0) issue_geo();
+    for (int k = 0; k < PRING - 1 && iss < T; ++k) issue_next();
 
-        __syncthreads();                 // the previous tile's fragment reads are done: stage 0 may be refilled
-        issue_a(0, 0, a_base);
-        if constexpr (!WRES) issue_w(0, 0, w_base);
-        for (int it = 0; it < niter; ++it) {
-            const int st = it & 1;
-            const int t = it / p.kchunks;
-            dma_wait();                  // this wave's share of iteration `it` (and of the resident weights) has landed
-            __syncthreads();             // ... everybody's has; the other stage is no longer being read
-            if (it + 1 < niter) {
-                const int t1 = (it + 1) / p.kchunks, k1 = (it + 1) - t1 * p.kchunks;
-                issue_a(t1, k1, a_base + (unsigned)((st ^ 1) * PSTAGE));
-                if constexpr (!WRES) issue_w(t1, k1, w_base + (unsigned)((st ^ 1) * PSTAGE));
+    f32x16 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+    u32x4 old_lo[4], old_hi[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) old_lo[b] = old_hi[b] = u32x4{0u, 0u, 0u, 0u};
+    int tile = blockIdx.x, it = 0, st = 0;
+    for (int j = 0; j < T; ++j) {
+        const int younger = iss - j - 1;          // iterations issued after j: 0 .. PRING - 2
+        if (PRING > 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * D) : "memory");
+        else if (PRING > 2 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();             // iteration j has landed for every wave; stage (j - 1) % PRING is no longer being read
+        if (iss < T) issue_next();
+        if (it == 0 && p.accum) {
+            // accumulate: the old destination values are fetched NOW, under the tile's MFMAs (fetched in the epilogue they
+            // cost one exposed HBM round trip per tile)
+            const int m = tile * PBM + wave * 32 + r;
+            const int px = m & (pw - 1), py = (m >> p.pwl) & (ph - 1), n = m >> (p.pwl + p.phl);
+            const long obase = (((long)n * p.OH + py * p.OS + p.OY0) * p.OW + px * p.OS + p.OX0) * p.DC;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int c = wc0[b] + 16 * h;
+                const bool ok = ((benable >> b) & 0x111111111ull) && m < p.M && c < p.gcols;
+                const long poff = p.ngroups > 1 ? ((long)(wgrp[b] >> 1) * p.OW + (wgrp[b] & 1)) * p.DC : 0;
+                const bf16_t* o = reinterpret_cast<const bf16_t*>(p.dst) + (ok ? obase + poff + c : 0);
+                old_lo[b] = *reinterpret_cast<const u32x4*>(o);
+                old_hi[b] = *reinterpret_cast<const u32x4*>(o + 8);
             }
+        }
+        {
+            const int t = it / p.kchunks;
             const unsigned char* A = smem + st * PSTAGE;
-            const unsigned char* W = smem + 2 * PSTAGE + (WRES ? it : st) * PSTAGE;
+            const unsigned char* W = smem + PRING * PSTAGE + (WRES ? 0 : st) * PSTAGE;
             const unsigned en = (unsigned)(benable >> (t * 4)) & 15u;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -172,12 +222,16 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const PcArgs p) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     if ((en >> b) & 1u) {            // uniform
-                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(W + (b * 32 + r) * 128 + (((2 * kk + h) ^ wsw[b]) << 4));
+                        const int wb = WRES ? (int)s_wslot[it * 4 + b] : b;
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(W + (wb * 32 + r) * 128 + (((2 * kk + h) ^ wsw[b]) << 4));
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[b], 0, 0, 0);
                     }
                 }
             }
         }
+        st = st + 1 == PRING ? 0 : st + 1;
+        if (++it < niter) continue;
+        it = 0;
 
         // ---- epilogue.  D[row = column][col = pixel]: lane -> pixel (lane & 31); register i -> column
         //      (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); two v_permlane32_swap give every lane 16 consecutive channels.
@@ -219,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const PcArgs p) {
                 u32x4 lo = u32x4{q[0][0], q[0][1], q[2][0], q[2][1]};
                 u32x4 hi = u32x4{q[1][0], q[1][1], q[3][0], q[3][1]};
                 if (p.accum) {
-                    const u32x4 ol = *reinterpret_cast<const u32x4*>(o), oh = *reinterpret_cast<const u32x4*>(o + 8);
+                    const u32x4 ol = old_lo[b], oh = old_hi[b];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float a0 = __uint_as_float(lo[e] << 16) + __uint_as_float(ol[e] << 16);
@@ -233,7 +287,10 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const PcArgs p) {
                 *reinterpret_cast<u32x4*>(o) = lo;
                 if (c + 8 < p.gcols) *reinterpret_cast<u32x4*>(o + 8) = hi;
             }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
         }
+        tile += gridDim.x;
     }
 }
 
@@ -245,7 +302,10 @@ int cu_pconv_try(const cu_conv_desc* d, const void* src0, const void* w, const f
     if (d->dtype != CU_BF16 || d->C1 != 0 || d->out_nchw_f32 || d->D0 != d->CO) return 0;
     if (d->slope0 != 1.0f) return 0;
     const bool parity = d->par_co > 0;
-    const bool few = d->ntaps <= 4, s2fwd = d->ntaps == 9 && d->IS == 2 && !parity;
+    // 3x3 stride-2 forward (9 taps, IS = 2) computes correctly here (tests/test_kernels_gpu.py runs it under
+    // CU_PCONV_S2FWD=1 in the tuning build) but re-fetches every pixel row 9 times through L2 and lost to the halo kernels
+    // on all levels but one (profiles/r02_layers_pconv.txt): off.
+    const bool few = d->ntaps <= 4, s2fwd = d->ntaps == 9 && d->IS == 2 && !parity && cu_env_set("CU_PCONV_S2FWD");
     if (!few && !s2fwd) return 0;
     if (d->C0 % 32 != 0 || d->C0 < 64) return 0;
     const int gcols = parity ? d->par_co : d->CO;
@@ -263,7 +323,11 @@ int cu_pconv_try(const cu_conv_desc* d, const void* src0, const void* w, const f
     const size_t wb = (size_t)wrows_total * d->C0 * 2;
     if (sb >= 0x7fff0000ull || wb >= 0x7fff0000ull) return 0;
     const long M = (long)d->N * d->PH * d->PW;
-    if (M < PBM || M >= (1l << 30)) return 0;
+    // few pixel tiles: every workgroup stages its weight slice for a handful of tiles and the tile-generic kernel's
+    // narrow-column tiling wins (measured in the step, 64 images: transposed conv forward from 8x8 up, the gradients
+    // from 16x16 up)
+    const long min_m = (parity && !d->par_taps && d->ntaps == 1) ? 4096 : 16384;
+    if (M < min_m || M >= (1l << 30)) return 0;
 
     PcArgs a;
     memset(&a, 0, sizeof(a));
@@ -290,13 +354,31 @@ int cu_pconv_try(const cu_conv_desc* d, const void* src0, const void* w, const f
     a.mtiles = cdiv((int)M, PBM);
     a.coltiles = gcols >= PBN ? a.ngroups * cdiv(gcols, PBN) : cdiv(a.CO, PBN);
     const int niter = a.ntaps * a.kchunks;
-    a.wres = niter * PSTAGE <= 64 * 1024;
-    const size_t lds = (size_t)2 * PSTAGE + (size_t)(a.wres ? niter : 2) * PSTAGE;
+    // resident weights: the largest packed slice over the column tiles (4 KiB per existing (iteration, block) pair)
+    int max_blocks = 0;
+    for (int ct = 0; ct < a.coltiles; ++ct) {
+        int blocks = 0;
+        for (int b = 0; b < 4; ++b) {
+            int group, c0;
+            if (gcols >= PBN) { const int tpg = cdiv(gcols, PBN); group = ct / tpg; c0 = (ct - group * tpg) * PBN + b * 32; }
+            else { const int col = ct * PBN + b * 32; group = col / gcols; c0 = col - group * gcols; }
+            if (group >= a.ngroups || c0 >= gcols) continue;
+            for (int t = 0; t < a.ntaps; ++t) blocks += a.wrow[t * 4 + group] >= 0 ? a.kchunks : 0;
+        }
+        max_blocks = blocks > max_blocks ? blocks : max_blocks;
+    }
+    a.wres = max_blocks * 4096 <= 48 * 1024 && niter <= PMAXT * 8;
+    // ring depth: measured (profiles/r02_pconv_ring.txt) -- occupancy beats depth: two stages with 2-3 workgroups per CU
+    // (their loads interleave) outrun four stages with one workgroup per CU
+    int ring = cu_env_int("CU_PCONV_RING", 2);
+    if (ring != 2 && ring != 3 && ring != 4) ring = 2;
+    const size_t lds = (size_t)ring * PSTAGE + (a.wres ? (size_t)max_blocks * 4096 : (size_t)ring * PSTAGE);
     int grid_x = a.mtiles;
-    const int cap = 256 * 4 / (a.coltiles < 4 ? a.coltiles : 4);
+    const int cap = 256 * cu_env_int("CU_PCONV_CAP", 2) / (a.coltiles < 4 ? a.coltiles : 4);
     if (grid_x > cap && cap > 0) grid_x = cap;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    auto k = a.wres ? pconv_kernel<true> : pconv_kernel<false>;
+    auto k = a.wres ? (ring == 2 ? pconv_kernel<true, 2> : ring == 3 ? pconv_kernel<true, 3> : pconv_kernel<true, 4>)
+                    : (ring == 2 ? pconv_kernel<false, 2> : ring == 3 ? pconv_kernel<false, 3> : pconv_kernel<false, 4>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         CU_CHECK_ARG(e == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));

@@ -545,3 +545,52 @@ def test_stride2_dgrad_single_pass(dtype, case):
                   parity_taps=S2_PARITY_TAPS)
     ref = xin.grad + (base if accum else 0)
     assert rel_err(nchw(d0), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("case", [(4, 64, 32, 64), (3, 128, 64, 128), (16, 480, 256, 16), (8, 256, 128, 32)])
+def test_lean_gather_gemm_shapes(case):
+    """The shapes cu_conv_gemm hands to the lean gather-GEMM (pconv.hip; bf16, >= 4096 / 16384 loop pixels): transposed
+    conv forward (one pass, parity scatter), its input gradient (4 taps, stride-2 gather), and the stride-2 3x3 input
+    gradient in one pass (9 of 16 (tap, parity) pairs) with and without accumulation -- vs autograd of the PyTorch ops.
+    480 channels = 7.5 K-chunks (zero-filled tail), 256 / 480 output columns = several / ragged column tiles."""
+    ops = _ops()
+    from cu_hip.engine import S2_PARITY_TAPS
+    n, ci, co, size = case
+    dtype = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(21)
+    # ---- transposed conv forward + input gradient
+    x = torch.randn(n, ci, size, size, device=DEV, generator=g)
+    a, r = make_act(x, dtype, False, 1.0, g)
+    w = torch.randn(ci, co, 2, 2, device=DEV, generator=g) / math.sqrt(ci)
+    wq = rq(w, dtype)
+    rin = r.clone().requires_grad_(True)
+    ref = F.conv_transpose2d(rin, wq, None, stride=2)
+    wf, wd = ops.weight_prep(w, "convT", dtype)
+    u = torch.empty(n, 2 * size, 2 * size, co, device=DEV, dtype=dtype)
+    ops.conv_gemm([a], wf.view(1, 4 * co, ci), None, grid=(size, size), in_stride=1, taps=[(0, 0, 0)], dsts=[u],
+                  dst_cols=[co], out_stride=2, n_cols=4 * co, parity_cols=co)
+    assert rel_err(nchw(u), ref) < tol(dtype)
+    du = rq(torch.randn(n, co, 2 * size, 2 * size, device=DEV, generator=g), dtype)
+    ref.backward(du)
+    base = rq(torch.randn(n, ci, size, size, device=DEV, generator=g), dtype)
+    for accum in (0, 1):
+        din = nhwc(base, dtype)
+        ops.conv_gemm([ops.Act(nhwc(du, dtype), None, 1.0)], wd, None, grid=(size, size), in_stride=2,
+                      taps=[(dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)], dsts=[din], dst_cols=[ci],
+                      accum=[accum])
+        assert rel_err(nchw(din), rin.grad + (base if accum else 0)) < tol(dtype)
+    # ---- stride-2 3x3 conv (cx -> cz): input gradient in one pass
+    cx, cz, os_ = co, ci, size
+    w3 = torch.randn(cz, cx, 3, 3, device=DEV, generator=g) / math.sqrt(9 * cx)
+    xin = torch.zeros(n, cx, 2 * os_, 2 * os_, device=DEV, requires_grad=True)
+    dz = rq(torch.randn(n, cz, os_, os_, device=DEV, generator=g), dtype)
+    F.conv2d(xin, rq(w3, dtype), None, stride=2, padding=1).backward(dz)
+    _, wd3 = ops.weight_prep(w3, "conv", dtype)
+    base = rq(torch.randn(n, cx, 2 * os_, 2 * os_, device=DEV, generator=g), dtype)
+    gz = ops.Act(nhwc(dz, dtype), None, 1.0)
+    for accum in (0, 1):
+        d0 = nhwc(base, dtype)
+        ops.conv_gemm([gz], wd3, None, grid=(os_, os_), in_stride=1, taps=[(u_, v_, 0) for u_ in range(2) for v_ in range(2)],
+                      dsts=[d0], dst_cols=[cx], out_stride=2, accum=[accum], n_cols=4 * cx, parity_cols=cx,
+                      parity_taps=S2_PARITY_TAPS)
+        assert rel_err(nchw(d0), xin.grad + (base if accum else 0)) < tol(dtype)

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
 }
 
 // kernel-layout f32 gradient dWk[T][COP][CI] -> logical gradient (same strides as above), rows >= CO dropped
-__global__ __launch_bounds__(256) void grad_unprep_kernel(const float* __restrict__ dwk, float* __restrict__ g, int CO,
+__global__ __launch_bounds__(256) void grad_unprep_kernel(float* __restrict__ dwk, float* __restrict__ g, int CO,
                                                           int CI, int COP, long s_co, long s_ci, int accumulate) {
     const int t = blockIdx.z;
     const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
@@ -148,9 +148,11 @@ __global__ __launch_bounds__(256) void grad_unprep_kernel(const float* __restric
     for (int k = 0; k < 4; ++k) {
         const int co = co0 + ty + 8 * k, ci = ci0 + tx;
         if (co < CO && ci < CI) {
-            const float v = dwk[((size_t)t * COP + co) * CI + ci];
+            float* src = dwk + ((size_t)t * COP + co) * CI + ci;
+            const float v = *src;
+            if (accumulate & 2) *src = 0.f;
             float* o = g + (size_t)co * s_co + (size_t)ci * s_ci + t;
-            *o = accumulate ? *o + v : v;
+            *o = (accumulate & 1) ? *o + v : v;
         }
     }
 }
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void grad_unprep_kernel(const float* __restric
 // 8 x 32 block of (slow channel, fast channel) with ALL its taps in LDS and writes the logical gradient in contiguous
 // rows of 32*T floats (the per-tap kernel above touches every logical line T times, 4 useful bytes per 36).
 constexpr int UNPREP_MAXT = 9;
-__global__ __launch_bounds__(256) void grad_unprep_rows_kernel(const float* __restrict__ dwk, float* __restrict__ g, int NT,
+__global__ __launch_bounds__(256) void grad_unprep_rows_kernel(float* __restrict__ dwk, float* __restrict__ g, int NT,
                                                                int CO, int CI, int COP, long s_co, long s_ci, int accumulate) {
     __shared__ float tile[8 * (32 * UNPREP_MAXT + 1)];
     const bool co_rows = s_co > s_ci;                  // conv: rows = co, columns = ci; transposed conv: the other way
@@ -172,7 +174,11 @@ __global__ __launch_bounds__(256) void grad_unprep_rows_kernel(const float* __re
         const int co = co_rows ? r : c, ci = co_rows ? c : r;
         const bool ok = r < RN && c < CN;
         for (int t = 0; t < NT; ++t)
-            tile[ty * pitch + tx * NT + t] = ok ? dwk[((size_t)t * COP + co) * CI + ci] : 0.f;
+        {
+            float* src = dwk + ((size_t)t * COP + co) * CI + ci;
+            tile[ty * pitch + tx * NT + t] = ok ? *src : 0.f;
+            if (ok && (accumulate & 2)) *src = 0.f;      // read-and-clear: the accumulator is ready for the next layer
+        }
     }
     __syncthreads();
     const long s_r = co_rows ? s_co : s_ci;
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(256) void grad_unprep_rows_kernel(const float* __re
         float* dst = g + (size_t)(r0 + ty) * s_r + (size_t)c0 * NT;
         for (int k = tx; k < cvalid; k += 32) {
             const float v = tile[ty * pitch + k];
-            dst[k] = accumulate ? dst[k] + v : v;
+            dst[k] = (accumulate & 1) ? dst[k] + v : v;
         }
     }
 }
@@ -329,7 +335,7 @@ extern "C" int cu_weight_prep(int dtype, int T, int CO, int CI, int COP, long s_
     return 0;
 }
 
-extern "C" int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_ci, const float* dwk, float* grad,
+extern "C" int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_ci, float* dwk, float* grad,
                               int accumulate, void* stream) {
     CU_CHECK_ARG(T > 0 && CO > 0 && CI > 0 && COP >= CO && dwk && grad, "cu_grad_unprep: bad argument");
     const bool co_rows = s_co > s_ci;

@@ -104,6 +104,7 @@ class UNetEngine:
         self.drop_mask_fn: Optional[Callable[[str, int, int, torch.device], Tensor]] = None   # tests inject masks
         self.debug: Optional[Dict[str, Tensor]] = None    # tests/tools: set to {} to capture per-layer gradients (NHWC)
         self._prep_state = None     # (pointer key, item table, blocks, names) of the batched operand preparation
+        self._dwk_ws: Optional[Tensor] = None
 
     # ------------------------------------------------------------------------------------------ operand copies
     def _operands(self, name: str, w: Tensor, kind: str, cop: Optional[int] = None):
@@ -253,11 +254,22 @@ class UNetEngine:
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(prefix)
 
+    def _dwk(self, shape, device) -> Tensor:
+        """Weight-gradient accumulator (kernel layout, f32, atomics target) of one layer: a view of ONE persistent
+        workspace that is zeroed once and handed back clean by every un-preparation (read-and-clear), so a step launches
+        no per-layer memset and every layer's atomics land in the same cache-resident block."""
+        n = 1
+        for d in shape:
+            n *= d
+        ws = self._dwk_ws
+        if ws is None or ws.numel() < n or ws.device != device:
+            ws = self._dwk_ws = torch.zeros(max(n, 9 * 480 * 960), dtype=torch.float32, device=device)
+        return ws[:n].view(shape)
+
     def _unprep(self, dwk: Tensor, grad: Tensor, kind: str, prefix: str):
-        """kernel-layout dWk -> logical gradient, layer by layer: dWk is then freed at once and the next layer's
-        accumulator reuses the same (cache-resident) block.  Measured: one batched launch at the end of the backward
-        made the un-preparation itself 0.5 ms cheaper and the step 0.8 ms slower (cold accumulators for the atomics)."""
-        ops.grad_unprep(dwk, grad, kind, accumulate=True)
+        """kernel-layout dWk -> logical gradient, layer by layer (measured in round 1: one batched launch at the end of the
+        backward made the un-preparation itself 0.5 ms cheaper and the step 0.8 ms slower: cold accumulators)."""
+        ops.grad_unprep(dwk, grad, kind, accumulate=True, clear=True)
         self._ready(prefix)
 
     def _conv_layer_bwd(self, P, G, ctx: UNetCtx, prefix: str, g: Tensor,
@@ -281,12 +293,12 @@ class UNetEngine:
         w = P[f"{prefix}.conv.weight"]
         n, oh, ow, co = g.shape
         if rec.first:
-            dw9 = torch.zeros((9, co), dtype=torch.float32, device=g.device)
+            dw9 = self._dwk((9, co), g.device)
             ops.conv_c1_wgrad(ctx.img, g, dw9)
             self._unprep(dw9.view(9, co, 1), G[f"{prefix}.conv.weight"], "conv", prefix)
             return
         ci = w.shape[1]
-        dwk = torch.zeros((9, co, ci), dtype=torch.float32, device=g.device)
+        dwk = self._dwk((9, co, ci), g.device)
         ops.conv_wgrad(rec.srcs, g, dwk, grid=(oh, ow), in_stride=rec.stride, z_stride=1, taps=TAPS3_W, n_cols=co)
         self._unprep(dwk, G[f"{prefix}.conv.weight"], "conv", prefix)
         if dsrc is None:
@@ -319,7 +331,7 @@ class UNetEngine:
         w = P[f"{rec.prefix}.weight"]
         ci, co = w.shape[0], w.shape[1]
         n, h, w_, _ = rec.src.z.shape
-        dwk = torch.zeros((4, co, ci), dtype=torch.float32, device=du.device)
+        dwk = self._dwk((4, co, ci), du.device)
         taps = [(0, 0, dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)]
         ops.conv_wgrad([rec.src], du, dwk, grid=(h, w_), in_stride=1, z_stride=2, taps=taps, n_cols=co)
         self._unprep(dwk, G[f"{rec.prefix}.weight"], "convT", rec.prefix)
@@ -338,7 +350,7 @@ class UNetEngine:
         # ---- 1x1 output conv
         dl = ops.nchw_f32_to_nhwc(dlogits.contiguous(), dt, cp=32)
         w = P["output_block.conv.weight"]
-        dwk = torch.zeros((1, 32, c_last), dtype=torch.float32, device=dl.device)
+        dwk = self._dwk((1, 32, c_last), dl.device)
         ops.conv_wgrad([last], dl, dwk, grid=(h, w_), in_stride=1, z_stride=1, taps=[(0, 0, 0, 0, 0)], n_cols=32)
         self._unprep(dwk, G["output_block.conv.weight"], "conv", "output_block")
         _, wd = self._operands("output_block.conv.weight", w, "conv", cop=32)

@@ -368,7 +368,8 @@ def weight_prep(master: Tensor, kind: str, dtype: torch.dtype, cop: Optional[int
     return wf, wd
 
 
-def grad_unprep(dwk: Tensor, grad: Tensor, kind: str, accumulate: bool = False):
+def grad_unprep(dwk: Tensor, grad: Tensor, kind: str, accumulate: bool = False, clear: bool = False):
+    """kernel-layout dWk -> logical gradient; ``clear`` zeroes what it reads (the accumulator stays clean for re-use)."""
     if kind == "conv":
         co, ci, kh, kw = grad.shape
         t = kh * kw
@@ -379,8 +380,8 @@ def grad_unprep(dwk: Tensor, grad: Tensor, kind: str, accumulate: bool = False):
         s_co, s_ci = t, co * t
     cop = dwk.shape[1]
     with _Prof("weight_prep"):
-        L.check(L.load().cu_grad_unprep(t, co, ci, cop, s_co, s_ci, L.ptr(dwk), L.ptr(grad), int(accumulate),
-                                        L.stream_ptr()), "cu_grad_unprep")
+        L.check(L.load().cu_grad_unprep(t, co, ci, cop, s_co, s_ci, L.ptr(dwk), L.ptr(grad),
+                                        int(accumulate) | (int(clear) << 1), L.stream_ptr()), "cu_grad_unprep")
 
 
 _PREP_ITEM = None

@@ -182,8 +182,10 @@ int cu_linear_bwd(int N, int IN, int OUT, const float* x, const float* w, const 
  * [T][CI][COP] (dtype), rows co >= CO zero-filled; either output may be NULL. */
 int cu_weight_prep(int dtype, int T, int CO, int CI, int COP, long s_co, long s_ci, const float* master, void* w_fwd,
                    void* w_dgrad, void* stream);
-/* kernel-layout gradient dWk [T][COP][CI] f32 (what cu_conv_wgrad accumulates) -> logical-layout gradient */
-int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_ci, const float* dwk, float* grad, int accumulate,
+/* kernel-layout gradient dWk [T][COP][CI] f32 (what cu_conv_wgrad accumulates) -> logical-layout gradient.
+ * accumulate: bit 0 = add to grad instead of overwriting it; bit 1 = zero every dWk element read (the accumulator is left
+ * clean for the next layer: one persistent workspace, no per-layer memset). */
+int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_ci, float* dwk, float* grad, int accumulate,
                    void* stream);
 
 /* Batched form: one launch for every conv layer of the network.  `items` is a DEVICE array (blk0 ascending, blk0 of

@@ -597,6 +597,11 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs
                 int tw;
                 if constexpr (NB == 4) {
                     tw = p.tap_w[j < NTAPS ? j : 0];
+                } else if constexpr (NB == 1) {      // four taps per round of 128 rows: tap 4 j + (tid >> 7)
+                    const int T0 = 4 * j < NTAPS ? 4 * j : 0, T1 = 4 * j + 1 < NTAPS ? 4 * j + 1 : 0;
+                    const int T2 = 4 * j + 2 < NTAPS ? 4 * j + 2 : 0, T3 = 4 * j + 3 < NTAPS ? 4 * j + 3 : 0;
+                    const int q4 = tid >> 7;
+                    tw = q4 == 0 ? p.tap_w[T0] : (q4 == 1 ? p.tap_w[T1] : (q4 == 2 ? p.tap_w[T2] : p.tap_w[T3]));
                 } else {
                     const int T0 = 2 * j < NTAPS ? 2 * j : 0, T1 = 2 * j + 1 < NTAPS ? 2 * j + 1 : 0;   // constants after unrolling
                     tw = (tid >> 8) ? p.tap_w[T1] : p.tap_w[T0];
@@ -786,8 +791,13 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
         if (dnb == 4 && (px_all / dbm) * cdiv(d->CO, 128) < 256)
             dnb = 2;                                                     // ... or leaves CUs without a workgroup
         if (d->IS == 2) dnb = 4;
+        if (d->IS == 1 && d->CO <= 32) dnb = 1;                          // thin layers (256^2 x 32 channels)
+        // Thin layers too, from 64 input channels on (measured, tools/thin_bench.py, profiles/r02_thin_bench.txt: 128^2 x 64
+        // concat forward 313 -> 227 us, 256^2 x 32+32 -> 32 322 -> 286 us; with 32 input channels the one-tile-per-workgroup
+        // structure loses to the persistent register-staged kernel, 173 vs 150 us)
+        const int min_ci = d->IS == 1 ? cu_env_int("CU_CONV_DMA_MINC", 64) : 64;
         if (bf && plain0 && (d->IS == 1 || (d->IS == 2 && d->CO % 128 == 0)) && d->ntaps == 9 &&
-            !d->out_nchw_f32 && d->CO >= 128 && CI >= (d->IS == 1 ? 128 : 64) && d->C0 % 32 == 0 &&
+            !d->out_nchw_f32 && d->CO >= (d->IS == 1 ? 32 : 128) && CI >= min_ci && d->C0 % 32 == 0 &&
             d->D0 % 32 == 0 && d->CO % 16 == 0 && !d->par_co && b0 < lim && b1 < lim && bw < lim &&
             (px_all / dbm) * cdiv(d->CO, 32 * dnb) >= 128 && !cu_env_set("CU_CONV_NODMA")) {
             int tw = d->PW < 32 ? d->PW : 32;
@@ -817,7 +827,8 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
                     CU_CHECK_ARG(d->tap_w[t] >= 0, "cu_conv_gemm: negative weight tap index");
                 }
                 auto k = d->IS == 2 ? igemm_conv_dma_kernel<9, 4, 1>
-                                    : (dnb == 4 ? igemm_conv_dma_kernel<9, 4, 2> : igemm_conv_dma_kernel<9, 2, 2>);
+                                    : (dnb == 4 ? igemm_conv_dma_kernel<9, 4, 2>
+                                                : (dnb == 2 ? igemm_conv_dma_kernel<9, 2, 2> : igemm_conv_dma_kernel<9, 1, 2>));
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 CU_CHECK_ARG(e == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));

@@ -391,6 +391,10 @@ def test_linear(golden_dir):
     (64, 480, 0, 960, 16, 480, 1),        # input gradient of a decoder conv: two destinations, the second accumulated
     (32, 64, 0, 128, 128, 64, 0),         # 64 input channels (two chunks), two destinations of 64 columns
     (32, 128, 0, 192, 64, None, 0),       # 192 columns: the 64-column variant (two taps per staging round)
+    (6, 32, 0, 32, 256, None, 0),         # thin layers on the same kernel: 32-column variant (four taps per staging round)
+    (5, 32, 32, 32, 256, None, 0),        # ... decoder concat 32 + 32 -> 32
+    (6, 32, 0, 64, 256, 32, 1),           # ... its input gradient: two destinations of 32 columns, the second accumulated
+    (12, 64, 64, 64, 128, None, 0),       # 128 x 128 level
 ])
 def test_conv_wide_dma_kernel(case):
     """bf16 3x3 stride-1 layers with >= 128 channels take the 8-wave LDS-DMA kernel (igemm_conv_dma_kernel): compare

@@ -56,10 +56,10 @@ except ImportError:
     def instantiate(cfg, *args, **kwargs):
         """Minimal ``hydra.utils.instantiate``: ``_target_`` + keyword merge, non-recursive."""
         cfg = dict(cfg)
+        cfg.update(kwargs)
         target = cfg.pop("_target_")
         cfg.pop("_recursive_", None)
         cfg.pop("_partial_", None)
-        cfg.update(kwargs)
         return _locate(target)(*args, **cfg)
 
     def to_absolute_path(path: str) -> str:
@@ -231,3 +231,193 @@ def fused_optimizer_cfg(optim_cfg):
     if cfg.get("_target_") == "torch.optim.Adam" and not cfg.get("amsgrad", False):
         cfg["_target_"] = "cu_hip.optim.FusedAdam"
     return to_attr(cfg)
+
+
+# ------------------------------------------------------------------------------------------------ Trainer stand-in
+class GradSyncCallback:
+    """Hooks the bucketed gradient exchange of ``cu_hip.ddp.GradSync`` into a training loop: a Lightning ``Callback`` by
+    duck typing (``on_fit_start`` / ``on_before_optimizer_step`` are the hook names of pytorch_lightning >= 1.5) and the
+    multi-process path of the stand-in ``Trainer`` below.  Use it with a strategy that does NOT wrap the module in
+    ``torch.nn.parallel.DistributedDataParallel`` (under Lightning's own ``strategy="ddp"`` torch DDP already exchanges
+    the gradients -- the HIP path works there unchanged -- and this callback stays passive)."""
+
+    def __init__(self, bucket_elems: int = 8 * 1024 * 1024):
+        self.bucket_elems = bucket_elems
+        self.sync = None
+
+    def on_fit_start(self, trainer, pl_module):
+        import torch.distributed as dist
+        from torch.nn.parallel import DistributedDataParallel
+        from cu_hip.ddp import GradSync
+        wrapped = isinstance(getattr(getattr(trainer, "strategy", None), "model", None), DistributedDataParallel)
+        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1 or wrapped:
+            return
+        self.sync = GradSync(pl_module, self.bucket_elems)
+        self.sync.overlap = int(getattr(trainer, "accumulate_grad_batches", 1) or 1) == 1
+        self.sync.broadcast_parameters()
+
+    def on_before_optimizer_step(self, trainer, pl_module, optimizer, *args):
+        if self.sync is None:
+            return
+        self.sync.finish()
+        if hasattr(optimizer, "grad_scale"):
+            optimizer.grad_scale = self.sync.grad_scale
+        else:                                   # any other optimizer: scale the summed gradients in place
+            for group in optimizer.param_groups:
+                for p in group["params"]:
+                    if p.grad is not None:
+                        p.grad.mul_(self.sync.grad_scale)
+
+
+def _to_device(x, device):
+    if torch.is_tensor(x):
+        return x.to(device, non_blocking=True)
+    if isinstance(x, Mapping):
+        return type(x)((k, _to_device(v, device)) for k, v in x.items()) if not isinstance(x, dict) else \
+            {k: _to_device(v, device) for k, v in x.items()}
+    return x
+
+
+class Trainer:
+    """The slice of ``pytorch_lightning.Trainer`` the reference's runner touches (vital/vital/runner.py:94-145): ``fit`` and
+    ``predict`` on ONE device per process.  Launched by ``torch.distributed.run`` (``trainer.devices`` ranks) the
+    minibatches / the predict views are dealt round-robin to the ranks, gradients go through ``GradSyncCallback``
+    (RCCL over xGMI with backend "nccl"), and ``predict`` can gather every rank's results."""
+
+    def __init__(self, max_epochs: int = 1000, max_steps: int = -1, devices=1, fast_dev_run=False, accelerator="auto",
+                 default_root_dir=None, logger=None, callbacks=None, accumulate_grad_batches: int = 1,
+                 limit_val_batches=None, device=None, **_unused):
+        self.max_epochs, self.max_steps = max_epochs, max_steps
+        self.devices = devices
+        self.fast_dev_run = int(fast_dev_run) if fast_dev_run else 0
+        self.accumulate_grad_batches = accumulate_grad_batches
+        self.limit_val_batches = limit_val_batches
+        self.logger, self.callbacks = logger, list(callbacks or [])
+        self.default_root_dir = default_root_dir
+        self.datamodule = None
+        self.callback_metrics: Dict[str, Any] = {}
+        self.global_step = 0
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self._forced_device = device     # tests of the loop logic with stub modules; the DSNT tasks need a GPU regardless
+
+    # -- plumbing
+    def _device(self):
+        if self._forced_device is not None:
+            return torch.device(self._forced_device)
+        if not torch.cuda.is_available():
+            from cu_hip.lib import ContourHipError
+            raise ContourHipError("Trainer: no MI355X visible (the HIP path has no CPU fallback)")
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(self.local_rank % ndev)
+        return torch.device("cuda", self.local_rank % ndev)
+
+    def _init_distributed(self):
+        import torch.distributed as dist
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(os.environ.get("CONTOUR_DIST_BACKEND", "nccl"))
+
+    def _call(self, hook, *args):
+        for cb in self.callbacks:
+            fn = getattr(cb, hook, None)
+            if fn is not None:
+                fn(self, *args)
+
+    def _mine(self, iterable):
+        """this rank's share of an iterable, dealt round-robin; every rank gets the same count (the tail is dropped)"""
+        items = []
+        for i, item in enumerate(iterable):
+            items.append(item)
+            if len(items) == self.world:
+                yield i // self.world, items[self.rank]
+                items = []
+
+    # -- fit
+    def fit(self, model, datamodule=None):
+        device = self._device()
+        self._init_distributed()
+        self.datamodule = datamodule
+        model.trainer = self
+        model.to(device)
+        datamodule.setup("fit")
+        if not any(isinstance(c, GradSyncCallback) for c in self.callbacks) and self.world > 1:
+            self.callbacks.append(GradSyncCallback())
+        model.on_fit_start()
+        self._call("on_fit_start", model)
+        optimizer = model.configure_optimizers()["optimizer"]
+        epochs = 1 if self.fast_dev_run else self.max_epochs
+        done = False
+        for epoch in range(epochs):
+            model.current_epoch = epoch
+            model.train()
+            for idx, batch in self._mine(datamodule.train_dataloader()):
+                out = model.training_step(_to_device(batch, device), idx)
+                (out["loss"] / self.accumulate_grad_batches).backward()
+                if (idx + 1) % self.accumulate_grad_batches == 0:
+                    self._call("on_before_optimizer_step", model, optimizer)
+                    optimizer.step()
+                    optimizer.zero_grad(set_to_none=True)
+                    self.global_step += 1
+                self.callback_metrics.update({k: v.detach() if torch.is_tensor(v) else v for k, v in out.items()})
+                if (self.fast_dev_run and idx + 1 >= self.fast_dev_run) or 0 < self.max_steps <= self.global_step:
+                    done = True
+                    break
+            model.eval()
+            with torch.no_grad():
+                for idx, batch in self._mine(datamodule.val_dataloader()):
+                    out = model.validation_step(_to_device(batch, device), idx)
+                    self.callback_metrics.update({k: v.detach() if torch.is_tensor(v) else v for k, v in out.items()})
+                    if self.fast_dev_run and idx + 1 >= self.fast_dev_run:
+                        break
+            if done:
+                break
+        if hasattr(model, "on_fit_end"):
+            model.on_fit_end()
+        return self.callback_metrics
+
+    # -- predict: views are independent (an ED / ES pair stays on one rank); deterministic per view whatever the sharding
+    def predict(self, model, datamodule=None, gather: bool = False, seed: int = 0):
+        device = self._device()
+        self._init_distributed()
+        self.datamodule = datamodule
+        model.trainer = self
+        model.to(device).eval()
+        datamodule.setup("predict")
+        model.on_predict_start()
+        results = []
+        loader = datamodule.predict_dataloader()
+        with torch.no_grad():
+            for view, batch in enumerate(loader):
+                if view % self.world != self.rank:
+                    continue
+                if self.fast_dev_run and len(results) >= self.fast_dev_run:
+                    break
+                torch.manual_seed(seed + view)              # the samplers draw from torch's generator: same draws per view
+                res = model.predict_step(_to_device(batch, device), view)
+                res.view_index = view
+                results.append(res)
+        if gather and self.world > 1:
+            import torch.distributed as dist
+            slim = [_slim(r) for r in results]
+            every = [None] * self.world
+            dist.all_gather_object(every, slim)
+            results = sorted((r for part in every for r in part), key=lambda r: r.view_index)
+        return results
+
+    def save_checkpoint(self, path):
+        if self.rank == 0 and self._model is not None:
+            self._model.save_checkpoint(path)
+
+    _model = None
+
+
+def _slim(res):
+    """a BatchResult without its device tensors (what travels between ranks)"""
+    import copy
+    out = copy.copy(res)
+    for k, v in list(vars(out).items()):
+        if torch.is_tensor(v):
+            setattr(out, k, v.detach().cpu().numpy())
+    return out

@@ -36,6 +36,7 @@ class FusedAdam(torch.optim.Optimizer):
         # flat moment buffers per run, keyed by the run's first parameter (NOT part of state_dict: the per-parameter
         # views in self.state are)
         self._flat: Dict[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.grad_scale = 1.0          # multiplies every gradient inside the kernel (1 / world after a SUM all-reduce)
 
     @staticmethod
     def _runs(params: List[torch.Tensor]):
@@ -110,8 +111,10 @@ class FusedAdam(torch.optim.Optimizer):
         return m, v
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: float = 1.0):
+    def step(self, closure=None, grad_scale: float = None):
         loss = None
+        if grad_scale is None:
+            grad_scale = self.grad_scale
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()

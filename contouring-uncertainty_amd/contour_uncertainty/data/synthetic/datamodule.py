@@ -79,7 +79,10 @@ class SyntheticContourDataModule:
                  batch_size: int = 32, num_workers: int = 0, n_train: int = 64, n_val: int = 8, n_predict: int = 4,
                  seed: int = 1234, **_unused):
         nb_points = 2 * points_per_side - 1                       # reference datamodule.py:76-84 (one LV contour)
-        self.data_params = DataParameters(in_shape=(1, size, size), out_shape=(nb_points, 2), labels=list(labels))
+        # label names -> vital.data.camus.config.Label values, like Label.from_proto_labels does for the CAMUS module
+        names = {"bg": 0, "lv": 1, "myo": 2, "atrium": 3}
+        labels = [names[lb.lower()] if isinstance(lb, str) else int(getattr(lb, "value", lb)) for lb in labels]
+        self.data_params = DataParameters(in_shape=(1, size, size), out_shape=(nb_points, 2), labels=labels)
         self.size, self.k, self.batch_size, self.num_workers, self.seed = size, nb_points, batch_size, num_workers, seed
         self.counts = {"train": n_train, "val": n_val, "predict": n_predict}
         self.datasets = {}

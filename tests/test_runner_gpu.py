@@ -21,9 +21,10 @@ SIX = ["task.model.kernels=[[3,3],[3,3],[3,3],[3,3],[3,3],[3,3]]",
        "task.model.strides=[[1,1],[2,2],[2,2],[2,2],[2,2],[2,2]]"]
 
 
-def _argv(task, golden_dir, extra=()):
+def _argv(task, golden_dir, tmp, extra=()):
     return [f"task={task}", "data=synthetic", "data.size=64", "data.batch_size=2", "data.n_train=8", "data.n_val=4",
-            "data.n_predict=3", "trainer.fast_dev_run=2", "task.t_a=5", "task.model.compute_dtype=f32",
+            "data.n_predict=3", "trainer.fast_dev_run=False", "trainer.max_epochs=1", "trainer.max_steps=2",
+            f"model_path={tmp}", "task.t_a=5", "task.model.compute_dtype=f32",
             f"task.psm_path={golden_dir / 'camus-cont_psm_11_no_std.npz'}",
             f"task.seq_psm_path={golden_dir / 'camus-cont_sequence_psm_11_no_std.npz'}"] + SIX + list(extra)
 
@@ -33,7 +34,7 @@ def test_config_c1_fit_and_predict_through_the_runner(golden_dir, task, tmp_path
     import runner
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         os.environ.pop(k, None)
-    model, trainer, preds = runner.main(_argv(task, golden_dir))
+    model, trainer, preds = runner.main(_argv(task, golden_dir, tmp_path))
     m = trainer.callback_metrics
     assert trainer.global_step == 2
     for key in ("train/loss", "train/distance_loss", "train/loss_term1", "train/loss_term2", "val/loss", "val/dice"):
@@ -49,12 +50,18 @@ def test_config_c1_fit_and_predict_through_the_runner(golden_dir, task, tmp_path
         assert p.contour_samples.shape == (2, 1, t_a, 21, 2) and np.isfinite(p.contour_samples).all()
         assert p.pred_samples.shape == (2, 1, t_a, 64, 64) and p.entropy_map.shape == (2, 64, 64)
         assert p.post_cov.shape == (2, 21, 2, 2) and p.id.startswith("synthetic")
-    # checkpoint in Lightning's layout -> `ckpt=` of the runner (vital/vital/runner.py:114-116) -> same predictions
-    ckpt = tmp_path / "c1.ckpt"
-    model.save_checkpoint(ckpt)
-    _, _, again = runner.main(_argv(task, golden_dir, [f"ckpt={ckpt}", "train=False"]))
+    # the runner saved the model where best_model_save_path says (Lightning's checkpoint layout); `ckpt=` of the runner
+    # (vital/vital/runner.py:114-116) loads it back -> same predictions
+    saved = list(Path(tmp_path).glob("*.ckpt"))
+    assert len(saved) == 1 and saved[0].name.startswith("synthetic-lv_")
+    ckpt = saved[0]
+    _, _, again = runner.main(_argv(task, golden_dir, tmp_path, [f"ckpt={ckpt}", "train=False"]))
     for a, b in zip(preds, again):
-        assert np.allclose(a.mu, b.mu, rtol=1e-4, atol=1e-3) and np.allclose(a.contour_samples, b.contour_samples, atol=2e-2)
+        assert np.allclose(a.mu, b.mu, rtol=1e-4, atol=1e-3)
+        # same per-view seed -> same draws; the skew sampler picks grid cells, so the ~1e-6 run-to-run noise of mu (f32
+        # atomics in the InstanceNorm statistics) may move an isolated draw by a cell
+        d = np.abs(a.contour_samples - b.contour_samples)
+        assert (d > 2e-2).mean() < (0.02 if task == "dsnt-skew" else 1e-9)
 
 
 def _free_port():
@@ -81,10 +88,10 @@ def test_frame_sharded_predict_equals_single_rank(golden_dir, tmp_path):
     import runner
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         os.environ.pop(k, None)
-    model, _, _ = runner.main(_argv("dsnt-al", golden_dir, ["predict=False", "data.n_predict=4"]))
+    model, _, _ = runner.main(_argv("dsnt-al", golden_dir, tmp_path, ["predict=False", "data.n_predict=4"]))
     ckpt = tmp_path / "w.ckpt"
     model.save_checkpoint(ckpt)
-    argv = _argv("dsnt-al", golden_dir, [f"ckpt={ckpt}", "train=False", "data.n_predict=4", "task.t_a=16"])
+    argv = _argv("dsnt-al", golden_dir, tmp_path, [f"ckpt={ckpt}", "train=False", "data.n_predict=4", "task.t_a=16"])
     _, _, single = runner.main(argv)
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(2, _free_port(), argv, ret), nprocs=2, join=True)

@@ -16,6 +16,7 @@ xGMI is point-to-point (7 links x ~153 GB/s per GPU): few large buckets (default
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -23,10 +24,11 @@ import torch.distributed as dist
 
 
 class BucketedAllReduce:
-    def __init__(self, total: int, bucket_elems: int = 8 * 1024 * 1024, group=None):
+    def __init__(self, total: int, bucket_elems: int = 8 * 1024 * 1024, group=None, native=None):
         self.total = total
         self.bucket = bucket_elems
         self.group = group
+        self.native = native            # cu_hip.comm.NativeComm: the cu_comm_* C ABI instead of torch.distributed
         self.flat: Optional[torch.Tensor] = None
         self._done: List[Tuple[int, int]] = []
         self._frontier = total          # everything in [frontier, total) has been handed to a collective
@@ -59,7 +61,9 @@ class BucketedAllReduce:
         self._done = [(a, b) for a, b in self._done if not (a >= lo and b <= hi)]
         self.launched.append((lo, hi))
         self._frontier = lo
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if self.native is not None:
+            self.native.allreduce_async(self.flat[lo:hi])
+        elif dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
                                                async_op=True))
 
@@ -79,6 +83,8 @@ class BucketedAllReduce:
         for w in self._works:
             w.wait()
         self._works = []
+        if self.native is not None:
+            self.native.wait()
 
 
 def prefix_ranges(names: Sequence[str], sizes: Sequence[int]) -> Dict[str, Tuple[int, int]]:
@@ -123,7 +129,11 @@ class GradSync:
         sizes = [params[n].numel() for n in names]
         self._used = [params[n] for n in names]
         self.ranges = prefix_ranges(names, sizes)
-        self.bar = BucketedAllReduce(sum(sizes), bucket_elems, group)
+        self.native = None
+        if self.world > 1 and os.environ.get("CONTOUR_COMM", "torch") == "native":
+            from .comm import NativeComm
+            self.native = NativeComm.create(group=group)
+        self.bar = BucketedAllReduce(sum(sizes), bucket_elems, group, self.native)
         self.overlap = True               # False: never reduce during a backward (gradient accumulation)
         self.overlapped = False           # mode of the backward in flight
         self.deferred_steps = 0           # statistics (tests): backwards that could not overlap
@@ -157,6 +167,13 @@ class GradSync:
         lo, hi = self.ranges[prefix]
         self.bar.ready(lo, hi)
 
+    def _allreduce_now(self, buf: torch.Tensor):
+        if self.native is not None:
+            self.native.allreduce_async(buf)
+            self.native.wait()
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+
     @staticmethod
     def _aliased(plist, flat) -> bool:
         """every p.grad is the view of ``flat`` at the parameter's offset"""
@@ -180,7 +197,7 @@ class GradSync:
             if p.grad is not None:
                 buf[off:off + p.numel()].copy_(p.grad.reshape(-1))
             off += p.numel()
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        self._allreduce_now(buf)
         off = 0
         for p in plist:
             if p.grad is None:
@@ -197,7 +214,7 @@ class GradSync:
             splist = [p for _, p in self.skew.named_parameters()]
             if any(p.grad is not None for p in splist):
                 if self._aliased(splist, self.skew.last_flat_grad):
-                    dist.all_reduce(self.skew.last_flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+                    self._allreduce_now(self.skew.last_flat_grad)
                 else:
                     self._reduce_packed(splist, splist[0])
         if self.overlapped:

@@ -82,6 +82,12 @@ _SIGS = {
     "cu_mask_weighted_entropy": (C.c_int, [C.c_int] * 4 + [_P] * 5),
     "cu_logpdf_grid": (C.c_int, [C.c_int] * 3 + [_P] * 6),
     "cu_skew_rvs": (C.c_int, [C.c_int] * 2 + [_P] * 4 + [C.c_uint64, _P, _P]),
+    "cu_comm_unique_id": (C.c_int, [_P]),
+    "cu_comm_init": (C.c_int, [C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    "cu_comm_allreduce_bucket": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "cu_comm_reduce_scatter_bucket": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
+    "cu_comm_allgather_bucket": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
+    "cu_comm_destroy": (C.c_int, [_P]),
     "cu_adam_step": (C.c_int, [C.c_size_t] + [_P] * 4 + [C.c_float] * 5 + [C.c_int, C.c_float, _P]),
 }
 

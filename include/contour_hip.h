@@ -290,6 +290,24 @@ int cu_mask_weighted_entropy(int F, int S, int H, int W, const uint32_t* packed,
  * overwrites of `uncertainty_map` (reference contour_uncertainty/utils/umap.py:22-31). */
 int cu_mask_last_value(int S, int H, int W, const uint32_t* packed, const float* values, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange: one communicator per process (= per GPU), RCCL over xGMI.
+ * The reference is single-device; these are the N-GPU form of the training path, used by cu_hip/comm.py when
+ * CONTOUR_COMM=native (default: torch.distributed's "nccl" backend, which is the same RCCL).
+ *   cu_comm_unique_id   rank 0 fills 128 bytes, the host side hands them to every rank (any side channel)
+ *   cu_comm_init        collective over all `world` ranks; *out owns the communicator until cu_comm_destroy
+ *   *_bucket            in-place f32 SUM all-reduce of one gradient bucket / reduce-scatter / all-gather of equal shards,
+ *                       stream-ordered on `stream` (order it behind the kernels with an event; never the null stream)
+ * Return 0, -22 (bad argument), -38 (RCCL not available), -5 (RCCL error; cu_last_error() has the text).
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct cu_comm cu_comm_t;
+int cu_comm_unique_id(void* id128);
+int cu_comm_init(int rank, int world, const void* id128, cu_comm_t** out);
+int cu_comm_allreduce_bucket(cu_comm_t* comm, float* buf, size_t n, void* stream);
+int cu_comm_reduce_scatter_bucket(cu_comm_t* comm, const float* send, float* recv, size_t n_per_rank, void* stream);
+int cu_comm_allgather_bucket(cu_comm_t* comm, const float* send, float* recv, size_t n_per_rank, void* stream);
+int cu_comm_destroy(cu_comm_t* comm);
+
 #ifdef __cplusplus
 }
 #endif

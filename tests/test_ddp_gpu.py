@@ -87,3 +87,33 @@ def test_two_rank_step_equals_single_rank_step():
     assert float((diff > 5e-5).float().mean()) < 0.02 and float(diff.max()) <= 2.2e-3
     diff = (s0 - sflat).abs()
     assert float((diff > 5e-5).float().mean()) < 0.02 and float(diff.max()) <= 2.2e-3
+
+
+def test_native_comm_single_rank():
+    """cu_comm_* (RCCL bound by dlopen inside libcontour_hip.so): a one-rank communicator on the test box -- unique id,
+    init, all-reduce / reduce-scatter / all-gather of a bucket on the communication stream ordered behind the kernel
+    stream, destroy.  (More ranks need more GPUs: RCCL refuses two ranks on one device.)"""
+    import ctypes as C
+    from cu_hip import lib as L
+    from cu_hip.comm import NativeComm
+    comm = NativeComm.create(rank=0, world=1)
+    x = torch.arange(1 << 20, dtype=torch.float32, device="cuda") * 0.5
+    ref = x.clone()
+    y = x * 2                         # queued on the kernel stream before the bucket is handed over
+    comm.allreduce_async(y)
+    comm.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref * 2)    # SUM over one rank
+    h = L.load()
+    out = torch.empty_like(x)
+    assert h.cu_comm_reduce_scatter_bucket(comm._h, x.data_ptr(), out.data_ptr(), x.numel(), comm.stream.cuda_stream) == 0
+    comm.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    out.zero_()
+    assert h.cu_comm_allgather_bucket(comm._h, x.data_ptr(), out.data_ptr(), x.numel(), comm.stream.cuda_stream) == 0
+    comm.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert h.cu_comm_allreduce_bucket(None, None, 0, None) == -22
+    comm.close()

@@ -93,6 +93,10 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--task", default="dsnt-skew", choices=["dsnt-skew", "dsnt-al", "dsnt-al2"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch images per GPU; strong: --batch images in total, split over the GPUs")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step as one hipGraph (cu_hip.graph.CapturedStep); auto = on for a single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -124,17 +128,42 @@ def main():
     task = task.to(dev)
     sync = GradSync(task)
     sync.broadcast_parameters()
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    if use_graph:
+        task.hparams.optim = dict(task.hparams.optim, capturable=True)
     opt = task.configure_optimizers()["optimizer"]
-    img, contour = synthetic_batch(args.batch, args.size, 21, seed=1234 + rank)
+    opt.grad_scale = sync.grad_scale
+    if args.scaling == "strong":
+        assert args.batch % world == 0, "strong scaling: --batch (global) must divide by the number of GPUs"
+        per_gpu = args.batch // world
+    else:
+        per_gpu = args.batch
+    img, contour = synthetic_batch(per_gpu, args.size, 21, seed=1234 + rank)
     batch = {"img": img.to(dev), "contour": contour.to(dev)}
 
-    def step(i):
+    def eager_step(i):
         opt.zero_grad(set_to_none=True)
         out = task.training_step(batch, i)
         out["loss"].backward()
         sync.finish()
-        opt.step(grad_scale=sync.grad_scale)
+        opt.step()
         return out
+
+    captured = None
+    if use_graph:
+        from cu_hip.graph import CapturedStep
+        try:
+            captured = CapturedStep(task, opt, batch, after_backward=sync.finish)
+        except Exception as e:      # noqa: BLE001 -- report and measure the eager step instead
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr,
+                  flush=True)
+            captured = None
+
+    def step(i):
+        if captured is not None:
+            captured.replay()
+            return captured.logs
+        return eager_step(i)
 
     def fence():
         if world > 1:
@@ -160,16 +189,17 @@ def main():
     result = None
     if rank == 0:
         ms = dt / args.steps * 1e3
-        value = args.batch * world * args.steps / dt
+        value = per_gpu * world * args.steps / dt
         flops_step_img, _ = conv_flops_per_image(n_stages, args.size)
         result = {
             "metric": f"train images/sec, {args.task} {args.size}x{args.size} {args.dtype}",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"task={args.task} {args.size}x{args.size}x1, K=21, {n_stages}-stage unet2, "
-                                   f"batch {args.batch}/GPU, Adam(lr=1e-3, wd=1e-3)",
-                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                                   f"batch {per_gpu}/GPU, Adam(lr=1e-3, wd=1e-3)",
+                       "per_gpu_batch": per_gpu, "global_batch": per_gpu * world,
+                       "launch": "hipGraph replay" if captured is not None else "eager",
                        "parallelism": f"dp{world}", "final_loss": round(loss, 4),
                        "mfma_roofline_frac_whole_step": round(value / world * flops_step_img / PEAK_BF16_DENSE, 4)},
         }
@@ -181,7 +211,7 @@ def main():
             ops.PROFILE.clear()
             ops.PROFILE_ON[0] = True
         for i in range(2):
-            step(i)
+            eager_step(i)           # per-launch events need the eager launches (a graph replay is one opaque launch)
         torch.cuda.synchronize()
         ops.PROFILE_ON[0] = False
     if rank == 0 and not args.no_roofline:
@@ -198,7 +228,7 @@ def main():
         achieved = fl / (ms_k * 1e-3) / 1e12
         traffic = None
         pmc = ROOT / "profiles" / "r01_pmc_hbm_traffic.json"     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this bench
-        if pmc.exists() and args.batch == 64 and args.size == 256 and args.dtype == "bf16":
+        if pmc.exists() and per_gpu == 64 and args.size == 256 and args.dtype == "bf16":
             famrec = json.loads(pmc.read_text())["families"].get(name)
             if famrec:
                 traffic = round(famrec["bytes_per_launch"])

@@ -252,9 +252,14 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const cu_prep_it
 __global__ __launch_bounds__(256) void adam_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, float lr, float b1,
                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                   float gscale) {
+                                                   float gscale, const int* __restrict__ step_dev) {
     const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i4 >= n) return;
+    if (step_dev) {          // capturable form: the step count lives on the device (a replayed hipGraph has no host side)
+        const float t = (float)(*step_dev + 1);
+        bc1 = 1.f - powf(b1, t);
+        bc2_sqrt = sqrtf(1.f - powf(b2, t));
+    }
     const float step = lr / bc1;
     if (i4 + 4 <= n) {
         f32x4 pv = *reinterpret_cast<f32x4*>(p + i4);
@@ -360,7 +365,27 @@ extern "C" int cu_adam_step(size_t n, float* p, const float* g, float* m, float*
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     const size_t blocks = (n + 1023) / 1024;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, p, g, m,
-                       v, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+                       v, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale, (const int*)nullptr);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void step_advance_kernel(int* step) { *step += 1; }
+
+extern "C" int cu_adam_step_dev(size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, const int* steps_done, float grad_scale,
+                                void* stream) {
+    CU_CHECK_ARG(n > 0 && p && g && m && v && steps_done, "cu_adam_step_dev: bad argument");
+    const size_t blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, p, g, m,
+                       v, lr, beta1, beta2, eps, weight_decay, 1.f, 1.f, grad_scale, steps_done);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_step_advance(int* steps_done, void* stream) {
+    CU_CHECK_ARG(steps_done != nullptr, "cu_step_advance: null pointer");
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), steps_done);
     CU_LAUNCH_CHECK();
     return 0;
 }

@@ -89,6 +89,8 @@ _SIGS = {
     "cu_comm_allgather_bucket": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "cu_comm_destroy": (C.c_int, [_P]),
     "cu_adam_step": (C.c_int, [C.c_size_t] + [_P] * 4 + [C.c_float] * 5 + [C.c_int, C.c_float, _P]),
+    "cu_adam_step_dev": (C.c_int, [C.c_size_t] + [_P] * 4 + [C.c_float] * 5 + [_P, C.c_float, _P]),
+    "cu_step_advance": (C.c_int, [_P, _P]),
 }
 
 _lib = None

@@ -442,6 +442,19 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: floa
                                       weight_decay, step, grad_scale, L.stream_ptr()), "cu_adam_step")
 
 
+def adam_step_dev(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, beta2: float, eps: float,
+                  weight_decay: float, steps_done: Tensor, grad_scale: float = 1.0):
+    """cu_adam_step_dev: bias correction from the device counter ``steps_done`` (int32, 1 element) + 1."""
+    PARAM_EPOCH[0] += 1
+    with _Prof("adam"):
+        L.check(L.load().cu_adam_step_dev(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), lr, beta1, beta2, eps,
+                                          weight_decay, L.ptr(steps_done), grad_scale, L.stream_ptr()), "cu_adam_step_dev")
+
+
+def step_advance(steps_done: Tensor):
+    L.check(L.load().cu_step_advance(L.ptr(steps_done), L.stream_ptr()), "cu_step_advance")
+
+
 def psm_sample_gauss(mu: Tensor, cov3: Tensor, cov0: Tensor, xbar: Tensor, smean: Tensor, sscale: Tensor,
                      init_pts, tables: Tensor, sigma2, sample_level, n: int, eps: Optional[Tensor] = None,
                      seed: int = 0) -> Tensor:

@@ -28,11 +28,17 @@ def _step_of(st) -> int:
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, **_unused):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False,
+                 capturable: bool = False, **_unused):
         if amsgrad:
             raise NotImplementedError("amsgrad is not used by the reference config")
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
+        # capturable: the step count used for the bias correction lives on the device, so that a hipGraph-captured
+        # training step replays with the right correction (cu_hip.graph.CapturedStep); every parameter that takes part
+        # must then have been stepped equally often (true for the DSNT tasks: all used parameters get a gradient)
+        self.capturable = capturable
+        self._steps_dev = None
         # flat moment buffers per run, keyed by the run's first parameter (NOT part of state_dict: the per-parameter
         # views in self.state are)
         self._flat: Dict[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -130,6 +136,20 @@ class FusedAdam(torch.optim.Optimizer):
                         self.state[p]["step"] += 1
                     pflat = torch.as_strided(first.data, (n,), (1,))
                     gflat = torch.as_strided(first.grad, (n,), (1,))
-                    ops.adam_step(pflat, gflat, m, v, group["lr"], b1, b2, group["eps"], group["weight_decay"], step,
-                                  grad_scale)
+                    if self.capturable:
+                        if self._steps_dev is None:
+                            self._steps_dev = torch.full((1,), step - 1, dtype=torch.int32, device=first.device)
+                        ops.adam_step_dev(pflat, gflat, m, v, group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                                          self._steps_dev, grad_scale)
+                    else:
+                        ops.adam_step(pflat, gflat, m, v, group["lr"], b1, b2, group["eps"], group["weight_decay"], step,
+                                      grad_scale)
+        if self.capturable and self._steps_dev is not None:
+            ops.step_advance(self._steps_dev)
         return loss
+
+    def note_replayed_steps(self, k: int):
+        """A captured step was replayed k times: bring the per-parameter host counters (state_dict) up to date."""
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] += k

@@ -206,6 +206,12 @@ int cu_weight_prep_batch(int dtype, int n_items, const cu_prep_item* items, int 
  * g += wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps). */
 int cu_adam_step(size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step, float grad_scale, void* stream);
+/* The same update with the step count on the device (hipGraph-capturable: a replayed graph has no host side to count):
+ * bias correction uses *steps_done + 1; cu_step_advance increments the counter once all parameter runs of the step have
+ * been launched. */
+int cu_adam_step_dev(size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, const int* steps_done, float grad_scale, void* stream);
+int cu_step_advance(int* steps_done, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Monte-Carlo contour sampler, Gaussian posterior shape model

@@ -1,0 +1,59 @@
+"""The training step as a hipGraph: replaying the captured step must do what the eager step does --
+same losses step by step and the same weights after k steps (Adam's bias correction comes from the device counter)."""
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def _build(capturable):
+    from test_model_gpu import make_task
+    from oracle import unet as OU
+    task = make_task("dsnt-skew", 6, 64, "f32")
+    task.hparams.optim = dict(task.hparams.optim, capturable=capturable)
+    spec = OU.UNetSpec(strides=(1, 2, 2, 2, 2, 2))
+    gen = torch.Generator().manual_seed(0)
+    task.model.load_state_dict(OU.init_unet_state(spec, gen), strict=True)
+    task.skew_block.load_state_dict(OU.init_confidence_state(42, gen), strict=True)
+    return task.to("cuda")
+
+
+def test_captured_step_replays_like_the_eager_step():
+    from contour_uncertainty.data.synthetic import synthetic_batch
+    from cu_hip.graph import CapturedStep
+    img, contour = synthetic_batch(4, 64, 21, seed=3)
+    batch = {"img": img.cuda(), "contour": contour.cuda()}
+    # eager reference: warm-up count of CapturedStep (3) + 4 more steps
+    eager = _build(False)
+    opt = eager.configure_optimizers()["optimizer"]
+    losses = []
+    for i in range(7):
+        opt.zero_grad(set_to_none=True)
+        out = eager.training_step(batch, i)
+        out["loss"].backward()
+        opt.step()
+        losses.append(float(out["loss"]))
+    task = _build(True)
+    copt = task.configure_optimizers()["optimizer"]
+    assert copt.capturable
+    step = CapturedStep(task, copt, batch, warmup=3)
+    got = []
+    for _ in range(4):
+        step.replay()
+        got.append(float(step.logs["loss"]))
+    step.finish()
+    # the loss of replay k is the loss of eager step 3 + k (f32 atomics: ~1e-6 run-to-run noise, amplified by training)
+    for a, b in zip(got, losses[3:]):
+        assert abs(a - b) <= 2e-3 * abs(b), (got, losses)
+    assert got[-1] < got[0] + 1e-3                      # and it is training, not replaying one frozen step
+    fa, _ = eager.model.flat_params()
+    fb, _ = task.model.flat_params()
+    diff = (fa - fb).abs()
+    assert float((diff > 2e-4).float().mean()) < 0.05 and float(diff.max()) <= 1.5e-2
+    st = copt.state[next(iter(task.model.parameters()))]
+    assert float(st["step"]) == 7.0 and int(copt._steps_dev.item()) == 7

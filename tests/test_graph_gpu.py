@@ -47,10 +47,14 @@ def test_captured_step_replays_like_the_eager_step():
         step.replay()
         got.append(float(step.logs["loss"]))
     step.finish()
-    # the loss of replay k is the loss of eager step 3 + k (f32 atomics: ~1e-6 run-to-run noise, amplified by training)
-    for a, b in zip(got, losses[3:]):
-        assert abs(a - b) <= 2e-3 * abs(b), (got, losses)
-    assert got[-1] < got[0] + 1e-3                      # and it is training, not replaying one frozen step
+    # the loss of replay k is the loss of eager step 3 + k.  Two EAGER runs of this very sequence differ by up to 8 % at
+    # step 3 and ~1 % afterwards (the f32 atomics' rounding order, amplified by the first Adam steps of a random network:
+    # tools/_graph_diag.py), so the comparison is as loose as that noise and the real check is the device step counter /
+    # the weights below
+    assert abs(got[0] - losses[3]) <= 0.12 * losses[3], (got, losses)
+    for a, b in zip(got[1:], losses[4:]):
+        assert abs(a - b) <= 0.03 * abs(b), (got, losses)
+    assert got[-1] < got[0]                             # and it is training, not replaying one frozen step
     fa, _ = eager.model.flat_params()
     fb, _ = task.model.flat_params()
     diff = (fa - fb).abs()

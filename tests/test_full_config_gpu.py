@@ -1,5 +1,7 @@
-"""Size-independent properties at BASELINE.json's full configuration (dsnt-skew, 256x256x1, K=21, 8-stage unet2, batch 64,
-bf16): the oracle cannot run this size in seconds, so the hot path is held to properties the domain offers.
+"""Size-independent properties at BASELINE.json's full configurations -- c3 (dsnt-skew, batch 64: the headline), c2
+(dsnt-al, batch 32) and the task of c4 (dsnt-al2 = full bivariate covariance, the per-GPU batch 64 of its 8 x 64 = 512)
+-- all 256x256x1, K=21, 8-stage unet2, bf16: the oracle cannot run these sizes in seconds, so the hot path is held to
+properties the domain offers.
 
   * InstanceNorm is per image and the loss is a mean over N*K points, so the network output of an image does not depend
     on its batch neighbours (batch-permutation equivariance), and the gradient of a batch is the mean of the gradients of
@@ -17,18 +19,24 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
-N, SIZE, K = 64, 256, 21
+SIZE, K = 256, 21
+CONFIGS = {"c3-dsnt-skew-b64": ("dsnt-skew", 64, True), "c2-dsnt-al-b32": ("dsnt-al", 32, False),
+           "c4-dsnt-al2-b64": ("dsnt-al", 64, True)}
 
 
-@pytest.fixture(scope="module")
-def setup():
+@pytest.fixture(scope="module", params=list(CONFIGS))
+def setup(request):
     from bench import build_task
-    from oracle.step import synthetic_batch
-    task, n_stages = build_task(SIZE, "bf16", "dsnt-skew")
+    from contour_uncertainty.data.synthetic import synthetic_batch
+    kind, n, covar = CONFIGS[request.param]
+    task, n_stages = build_task(SIZE, "bf16", kind)
     assert n_stages == 8
+    task.hparams.covar = covar          # dsnt-al2 = dsnt-al with the full covariance (config/task/dsnt-al2.yaml); c2 diagonal
     task = task.to(DEV)
-    img, contour = synthetic_batch(N, SIZE, K, seed=77)
-    return task, img.to(DEV), contour.to(DEV)
+    img, contour = synthetic_batch(n, SIZE, K, seed=77)
+    yield task, img.to(DEV), contour.to(DEV)
+    del task
+    torch.cuda.empty_cache()
 
 
 def _flat_grads(task):
@@ -44,16 +52,22 @@ def _step_grads(task, img, contour):
 
 def test_outputs_are_valid_and_batch_permutation_equivariant(setup):
     task, img, _ = setup
+    N = img.shape[0]
     task.eval()
-    mu, cov, alpha = task.predict(img)
-    mu2, cov2, _ = task.predict(img)                       # run-to-run noise floor
-    assert mu.shape == (N, 1, K, 2) and cov.shape == (N, 1, K, 2, 2) and alpha.shape == (N, 1, K, 2)
-    assert torch.isfinite(mu).all() and torch.isfinite(cov).all() and torch.isfinite(alpha).all()
+    out = task.predict(img)
+    mu, cov = out[0], out[1]
+    mu2, cov2 = task.predict(img)[:2]                      # run-to-run noise floor
+    assert mu.shape == (N, 1, K, 2) and cov.shape == (N, 1, K, 2, 2)
+    assert torch.isfinite(mu).all() and torch.isfinite(cov).all()
+    if len(out) == 3:
+        assert out[2].shape == (N, 1, K, 2) and torch.isfinite(out[2]).all()
+    if not task.hparams.covar:
+        assert float(cov[..., 0, 1].abs().max()) == 0.0          # covar=False: diagonal Sigma (dsnt_al.py:56)
     assert (mu >= 0).all() and (mu <= SIZE - 1).all()
     assert torch.allclose(cov, cov.transpose(-1, -2))
     assert (cov[..., 0, 0] > 0).all() and (torch.linalg.det(cov) > 0).all()
     perm = torch.randperm(N, generator=torch.Generator().manual_seed(3))
-    mu_p, cov_p, _ = task.predict(img[perm.to(DEV)])
+    mu_p, cov_p = task.predict(img[perm.to(DEV)])[:2]
     noise = float((mu - mu2).abs().max())
     assert float((mu_p - mu[perm]).abs().max()) <= 5 * noise + 1e-3
     assert float((cov_p - cov[perm]).abs().max()) <= 5 * float((cov - cov2).abs().max()) + 1e-2 * float(cov.abs().max())
@@ -62,6 +76,7 @@ def test_outputs_are_valid_and_batch_permutation_equivariant(setup):
 
 def test_gradient_of_the_batch_is_the_mean_of_its_halves(setup):
     task, img, contour = setup
+    N = img.shape[0]
     task.train()
     loss, g = _step_grads(task, img, contour)
     _, g_again = _step_grads(task, img, contour)           # noise floor of the identical computation

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs
             const unsigned cc = (unsigned)(s1 ? c0 - p.C0 : c0);
 #pragma unroll
             for (int j = 0; j < DMA_MAXX; ++j) {
-                if (j * 128 < p.halo_px) {       // uniform
+                if (j * 128 < p.halo_px && !(CU_DBG(p, 8) && c0)) {       // uniform
                     const unsigned off = xoff[j] == 0xffffffffu ? OOB : (xoff[j] * Cs + cc + (unsigned)xpiece[j] * 8u) * 2u;
                     const unsigned dst = x_base + (unsigned)(j * 8192 + wave * 1024);
                     if (s1) dma16(rs1, off, dst);
@@ -608,11 +608,12 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs
                 }
                 const bool ok = wok && wrow0 + 128 * j < WROWS;
                 const unsigned off = ok ? (unsigned)(((tw * p.CO + n0 + wcol) * CI + c0 + wpiece * 8)) * 2u : OOB;
-                dma16(rw, off, w_base + (unsigned)(j * 8192 + wave * 1024));
+                if (!(CU_DBG(p, 4) && c0)) dma16(rw, off, w_base + (unsigned)(j * 8192 + wave * 1024));
             }
         }
         dma_wait();
         __syncthreads();
+        if (CU_DBG(p, 2)) continue;
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) {
             int xrow[MA], xsw[MA];
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs
     for (int a = 0; a < MA; ++a) {
         const int n = img0 + pim[a];
         const int py = py0 + pty[a], px = px0 + ptx[a];
-        const bool pvalid = !(pim[a] >= p.imgs || n >= p.N || py >= p.PH || px >= p.PW);
+        const bool pvalid = !(pim[a] >= p.imgs || n >= p.N || py >= p.PH || px >= p.PW || CU_DBG(p, 1));
         const int oy = py * p.OS + p.OY0, ox = px * p.OS + p.OX0;
         const size_t opix = pvalid ? ((size_t)n * p.OH + oy) * p.OW + ox : 0;
 #pragma unroll

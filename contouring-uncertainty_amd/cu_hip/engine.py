@@ -13,6 +13,8 @@ version counter changes.
 """
 from __future__ import annotations
 
+import contextlib
+import os
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -105,6 +107,11 @@ class UNetEngine:
         self.debug: Optional[Dict[str, Tensor]] = None    # tests/tools: set to {} to capture per-layer gradients (NHWC)
         self._prep_state = None     # (pointer key, item table, blocks, names) of the batched operand preparation
         self._dwk_ws: Optional[Tensor] = None
+        # weight gradients (+ their un-preparation) run on a second HIP stream beside the input-gradient chain: the two
+        # only meet in dz, and each family's prologue / atomics tail is filled by the other's workgroups
+        self.side_wgrad = os.environ.get("CONTOUR_SIDE_WGRAD", "1") != "0"
+        self._side: Optional[torch.cuda.Stream] = None
+        self._side_keep: List[Tensor] = []
 
     # ------------------------------------------------------------------------------------------ operand copies
     def _operands(self, name: str, w: Tensor, kind: str, cop: Optional[int] = None):
@@ -266,6 +273,23 @@ class UNetEngine:
             ws = self._dwk_ws = torch.zeros(max(n, 9 * 480 * 960), dtype=torch.float32, device=device)
         return ws[:n].view(shape)
 
+    def _wgrad_stream(self, *reads: Tensor):
+        """``with`` block whose launches go to the weight-gradient stream, ordered after everything enqueued so far.  The
+        tensors it reads are kept alive until ``_join_wgrad`` (no caching-allocator reuse under the side stream)."""
+        if not self.side_wgrad or not reads[0].is_cuda:
+            return contextlib.nullcontext()
+        dev = reads[0].device
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(dev)
+        self._side.wait_stream(torch.cuda.current_stream(dev))
+        self._side_keep.extend(reads)
+        return torch.cuda.stream(self._side)
+
+    def _join_wgrad(self, device):
+        if self._side is not None and self._side_keep:
+            torch.cuda.current_stream(device).wait_stream(self._side)
+        self._side_keep.clear()
+
     def _unprep(self, dwk: Tensor, grad: Tensor, kind: str, prefix: str):
         """kernel-layout dWk -> logical gradient, layer by layer (measured in round 1: one batched launch at the end of the
         backward made the un-preparation itself 0.5 ms cheaper and the step 0.8 ms slower: cold accumulators)."""
@@ -293,14 +317,16 @@ class UNetEngine:
         w = P[f"{prefix}.conv.weight"]
         n, oh, ow, co = g.shape
         if rec.first:
-            dw9 = self._dwk((9, co), g.device)
-            ops.conv_c1_wgrad(ctx.img, g, dw9)
-            self._unprep(dw9.view(9, co, 1), G[f"{prefix}.conv.weight"], "conv", prefix)
+            with self._wgrad_stream(g, ctx.img):
+                dw9 = self._dwk((9, co), g.device)
+                ops.conv_c1_wgrad(ctx.img, g, dw9)
+                self._unprep(dw9.view(9, co, 1), G[f"{prefix}.conv.weight"], "conv", prefix)
             return
         ci = w.shape[1]
-        dwk = self._dwk((9, co, ci), g.device)
-        ops.conv_wgrad(rec.srcs, g, dwk, grid=(oh, ow), in_stride=rec.stride, z_stride=1, taps=TAPS3_W, n_cols=co)
-        self._unprep(dwk, G[f"{prefix}.conv.weight"], "conv", prefix)
+        with self._wgrad_stream(g, *[s_.z for s_ in rec.srcs]):
+            dwk = self._dwk((9, co, ci), g.device)
+            ops.conv_wgrad(rec.srcs, g, dwk, grid=(oh, ow), in_stride=rec.stride, z_stride=1, taps=TAPS3_W, n_cols=co)
+            self._unprep(dwk, G[f"{prefix}.conv.weight"], "conv", prefix)
         if dsrc is None:
             return
         _, wd = self._operands(f"{prefix}.conv.weight", w, "conv")
@@ -331,10 +357,11 @@ class UNetEngine:
         w = P[f"{rec.prefix}.weight"]
         ci, co = w.shape[0], w.shape[1]
         n, h, w_, _ = rec.src.z.shape
-        dwk = self._dwk((4, co, ci), du.device)
-        taps = [(0, 0, dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)]
-        ops.conv_wgrad([rec.src], du, dwk, grid=(h, w_), in_stride=1, z_stride=2, taps=taps, n_cols=co)
-        self._unprep(dwk, G[f"{rec.prefix}.weight"], "convT", rec.prefix)
+        with self._wgrad_stream(du, rec.src.z):
+            dwk = self._dwk((4, co, ci), du.device)
+            taps = [(0, 0, dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)]
+            ops.conv_wgrad([rec.src], du, dwk, grid=(h, w_), in_stride=1, z_stride=2, taps=taps, n_cols=co)
+            self._unprep(dwk, G[f"{rec.prefix}.weight"], "convT", rec.prefix)
         _, wd = self._operands(f"{rec.prefix}.weight", w, "convT")
         ops.conv_gemm([Act(du, None, 1.0)], wd, None, grid=(h, w_), in_stride=2,
                       taps=[(dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)], dsts=[d_in], dst_cols=[ci],
@@ -350,9 +377,10 @@ class UNetEngine:
         # ---- 1x1 output conv
         dl = ops.nchw_f32_to_nhwc(dlogits.contiguous(), dt, cp=32)
         w = P["output_block.conv.weight"]
-        dwk = self._dwk((1, 32, c_last), dl.device)
-        ops.conv_wgrad([last], dl, dwk, grid=(h, w_), in_stride=1, z_stride=1, taps=[(0, 0, 0, 0, 0)], n_cols=32)
-        self._unprep(dwk, G["output_block.conv.weight"], "conv", "output_block")
+        with self._wgrad_stream(dl, last.z):
+            dwk = self._dwk((1, 32, c_last), dl.device)
+            ops.conv_wgrad([last], dl, dwk, grid=(h, w_), in_stride=1, z_stride=1, taps=[(0, 0, 0, 0, 0)], n_cols=32)
+            self._unprep(dwk, G["output_block.conv.weight"], "conv", "output_block")
         _, wd = self._operands("output_block.conv.weight", w, "conv", cop=32)
         g = torch.empty_like(last.z)
         ops.conv_gemm([Act(dl, None, 1.0)], wd, None, grid=(h, w_), in_stride=1, taps=[(0, 0, 0)], dsts=[g],
@@ -397,6 +425,7 @@ class UNetEngine:
         g_c1 = torch.empty_like(c1.out.z)
         self._conv_layer_bwd(P, G, ctx, "input_block.conv2", g, [(g_c1, 0)])
         self._conv_layer_bwd(P, G, ctx, "input_block.conv1", g_c1, None)
+        self._join_wgrad(g.device)
 
 
 class ConfidenceEngine:

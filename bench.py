@@ -213,10 +213,17 @@ def main():
         if rank == 0:
             ops.PROFILE.clear()
             ops.PROFILE_ON[0] = True
+        engines = [m.engine for m in task.modules() if hasattr(getattr(m, "engine", None), "side_wgrad")]
+        side = [e.side_wgrad for e in engines]
+        for e in engines:
+            e.side_wgrad = False    # one stream: an event pair around a launch then times that launch alone (with the
+                                    # weight-gradient stream running beside it, it would time both streams' kernels)
         for i in range(2):
             eager_step(i)           # per-launch events need the eager launches (a graph replay is one opaque launch)
         torch.cuda.synchronize()
         ops.PROFILE_ON[0] = False
+        for e, s_ in zip(engines, side):
+            e.side_wgrad = s_
     if rank == 0 and not args.no_roofline:
         fam = {}
         for name, flops, e0, e1, *_ in ops.PROFILE:

@@ -26,35 +26,42 @@ class SequenceSkewPSMSampler(SkewPosteriorShapeModelSampler):
         for name in ("seq_mu", "seq_Q", "seq_mean", "seq_scale", "seq_X_train", "seq_X_val"):
             setattr(self, name, getattr(self.seq, name))
 
-    def sample_sequence(self, mu: torch.Tensor, cov: torch.Tensor, alpha: torch.Tensor, firsts: Sequence[int],
-                        eps: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """mu (2,K,2), cov (2,K,2,2), alpha (2,K,2), eps (n,2,K,3), u (n,2,K) -> (n,2,K,2)."""
-        n, k = len(firsts), self.nb_points
+    def sample_pairs(self, mu: torch.Tensor, cov: torch.Tensor, alpha: torch.Tensor, firsts: torch.Tensor,
+                     eps: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """ALL ED/ES pairs in one launch set: mu (P,2,K,2), cov (P,2,K,2,2), alpha (P,2,K,2), firsts (P,n) in {0,1},
+        eps (P,n,2,K,3), u (P,n,2,K) -> (P,n,2,K,2).  Both orders are drawn for every sample and the sample's own order
+        is selected afterwards (see ``SequencePSMSampler.sample_pairs``)."""
+        p_, n, k = mu.shape[0], firsts.shape[1], self.nb_points
         dev = torch.device("cuda", torch.cuda.current_device()) if not mu.is_cuda else mu.device
         mu, cov, alpha = (t.to(dev, torch.float32) for t in (mu, cov, alpha))
         d = self.seq.on(dev)
-        out = torch.empty((n, 2, k, 2), dtype=torch.float32, device=dev)
-        firsts_t = torch.tensor(list(firsts))
-        pick = lambda t, idx, inst: None if t is None else t.to(dev)[idx, inst][None]
+        mu_flat = mu.reshape(p_, 4 * k).contiguous()
+        pick = lambda t, inst: None if t is None else t.to(dev, torch.float32)[:, :, inst]
+        branch = []
         for first in (0, 1):
-            idx = torch.nonzero(firsts_t == first).flatten().to(dev)
-            m = idx.numel()
-            if m == 0:
-                continue
             second = 1 - first
-            s1 = self.sample_batch(mu[first][None], cov[first][None], alpha[first][None], n=m,
-                                   eps=pick(eps, idx, first), u=pick(u, idx, first))[0]
-            rec = ops.psm_setup(mu.reshape(1, 4 * k).contiguous(), d["cov0"], d["xbar"], d["mean"], d["scale"],
-                                d["tables"][first], [1.0], self.seq.rec_stride)
-            mu_c, cov_c, _, _ = ops.psm_condition(rec, d["tables"][first], k, self.seq.known(s1, first), m, d["mean"],
-                                                  d["scale"])
-            s2 = self.sample_batch(mu[second][None], cov[second][None], alpha[second][None], n=m,
-                                   eps=pick(eps, idx, second), u=pick(u, idx, second), prior_mu=mu_c[None],
-                                   prior_cov=cov_c.expand(m, -1, -1, -1)[None], use_initial_pdf=True,
-                                   flip_alpha_y=False)[0]
-            out[idx, first] = s1
-            out[idx, second] = s2
+            s1 = self.sample_batch(mu[:, first], cov[:, first], alpha[:, first], n=n, eps=pick(eps, first),
+                                   u=pick(u, first))
+            rec = ops.psm_setup(mu_flat, d["cov0"], d["xbar"], d["mean"], d["scale"], d["tables"][first], [1.0],
+                                self.seq.rec_stride)
+            mu_c, cov_c, _, _ = ops.psm_condition(rec, d["tables"][first], k, self.seq.known(s1.reshape(p_ * n, k, 2), first),
+                                                  n, d["mean"], d["scale"])
+            s2 = self.sample_batch(mu[:, second], cov[:, second], alpha[:, second], n=n, eps=pick(eps, second),
+                                   u=pick(u, second), prior_mu=mu_c.reshape(p_, n, k, 2),
+                                   prior_cov=cov_c[:, None].expand(-1, n, -1, -1, -1), use_initial_pdf=True,
+                                   flip_alpha_y=False)
+            branch.append((s1, s2))
+        pick0 = (firsts.to(dev) == 0)[:, :, None, None]
+        out = torch.empty((p_, n, 2, k, 2), dtype=torch.float32, device=dev)
+        out[:, :, 0] = torch.where(pick0, branch[0][0], branch[1][1])
+        out[:, :, 1] = torch.where(pick0, branch[0][1], branch[1][0])
         return out
+
+    def sample_sequence(self, mu: torch.Tensor, cov: torch.Tensor, alpha: torch.Tensor, firsts: Sequence[int],
+                        eps: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """mu (2,K,2), cov (2,K,2,2), alpha (2,K,2), eps (n,2,K,3), u (n,2,K) -> (n,2,K,2)."""
+        return self.sample_pairs(mu[None], cov[None], alpha[None], torch.as_tensor(list(firsts))[None],
+                                 None if eps is None else eps[None], None if u is None else u[None])[0]
 
     def __call__(self, mu: torch.Tensor, cov: torch.Tensor, alpha: torch.Tensor, n: int = 1, debug_img=None,
                  progress_bar=False) -> torch.Tensor:

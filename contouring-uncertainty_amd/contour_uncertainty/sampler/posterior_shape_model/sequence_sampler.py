@@ -108,26 +108,42 @@ class SequencePSMSampler(PosteriorShapeModelSampler):
             cov_to3(cov.to(dev, torch.float32)).reshape(1, 2 * k, 3).contiguous())
         return mu_c, cov_c[0], mu_f, cov_f[0]
 
+    def sample_pairs(self, mu: torch.Tensor, cov: torch.Tensor, firsts: torch.Tensor,
+                     eps: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """ALL ED/ES pairs in one launch set: mu (P,2,K,2), cov (P,2,K,2,2), firsts (P,n) in {0,1} = instant sampled
+        first for sample i of pair p, eps (P,n,2,K,2) -> (P,n,2,K,2).
+
+        Both orders are drawn for every sample (first = 0 and first = 1, each one batched launch over P x n) and the
+        sample's own order is selected afterwards: twice the arithmetic of the per-pair loop, but no host
+        synchronisation, no ragged groups and a launch count that does not grow with P."""
+        p_, n, k = mu.shape[0], firsts.shape[1], self.nb_points
+        dev = torch.device("cuda", torch.cuda.current_device()) if not mu.is_cuda else mu.device
+        mu, cov = mu.to(dev, torch.float32), cov.to(dev, torch.float32)
+        d = self.seq.on(dev)
+        mu_p = mu.reshape(p_, 4 * k).contiguous()
+        cov_p3 = cov_to3(cov).reshape(p_, 2 * k, 3).contiguous()
+        eps = None if eps is None else eps.to(dev, torch.float32)
+        branch = []
+        for first in (0, 1):
+            second = 1 - first
+            s1 = self.sample_batch(mu[:, first], cov[:, first], n=n, eps=None if eps is None else eps[:, :, first])
+            rec = d["fixed"][first].expand(p_, -1).contiguous()
+            _, _, mu_f, cov_f = ops.psm_condition(rec, d["tables"][first], k, self.seq.known(s1.reshape(p_ * n, k, 2), first),
+                                                  n, d["mean"], d["scale"], mu_p, cov_p3)
+            e2 = None if eps is None else eps[:, :, second].reshape(p_ * n, 1, k, 2)
+            s2 = self.sample_batch(mu_f, cov_f[:, None].expand(-1, n, -1, -1, -1).reshape(p_ * n, k, 2, 2), n=1, eps=e2)
+            branch.append((s1, s2.reshape(p_, n, k, 2)))
+        pick0 = (firsts.to(dev) == 0)[:, :, None, None]
+        out = torch.empty((p_, n, 2, k, 2), dtype=torch.float32, device=dev)
+        out[:, :, 0] = torch.where(pick0, branch[0][0], branch[1][1])
+        out[:, :, 1] = torch.where(pick0, branch[0][1], branch[1][0])
+        return out
+
     def sample_sequence(self, mu: torch.Tensor, cov: torch.Tensor, firsts: Sequence[int],
                         eps: Optional[torch.Tensor] = None) -> torch.Tensor:
         """mu (2,K,2), cov (2,K,2,2), firsts[i] = instant sampled first for sample i, eps (n,2,K,2) -> (n,2,K,2)."""
-        n, k = len(firsts), self.nb_points
-        dev = torch.device("cuda", torch.cuda.current_device()) if not mu.is_cuda else mu.device
-        out = torch.empty((n, 2, k, 2), dtype=torch.float32, device=dev)
-        firsts_t = torch.tensor(list(firsts))
-        for first in (0, 1):
-            idx = torch.nonzero(firsts_t == first).flatten().to(dev)
-            if idx.numel() == 0:
-                continue
-            second = 1 - first
-            e1 = None if eps is None else eps.to(dev)[idx, first][None]
-            s1 = self.sample_batch(mu[first][None], cov[first][None], n=idx.numel(), eps=e1)[0]
-            _, _, mu_f, cov_f = self._second_instant(mu, cov, s1, first)
-            e2 = None if eps is None else eps.to(dev)[idx, second][:, None]
-            s2 = self.sample_batch(mu_f, cov_f[None].expand(idx.numel(), -1, -1, -1), n=1, eps=e2)[:, 0]
-            out[idx, first] = s1
-            out[idx, second] = s2
-        return out
+        return self.sample_pairs(mu[None], cov[None], torch.as_tensor(list(firsts))[None],
+                                 None if eps is None else eps[None])[0]
 
     def __call__(self, mu: torch.Tensor, cov: torch.Tensor, alpha: torch.Tensor = None, n: int = 1,
                  debug_img=None) -> torch.Tensor:

@@ -47,8 +47,12 @@ class AleatoricUncertaintyTask(ContourUncertaintyTask):
         from contour_uncertainty.sampler.posterior_shape_model.sequence_sampler import SequencePSMSampler
         n = mu.shape[0]
         if isinstance(self.sampler, SequencePSMSampler):
-            cs = [self.sampler(mu[:, t], cov[:, t], n=t_a).cpu().numpy() for t in range(mu.shape[1])]
-            return np.array(cs).transpose((2, 0, 1, 3, 4))
+            # an ED/ES pair per t_e member: all pairs in one launch set; the first instant of each sample is drawn with
+            # ``random.randint`` like the reference (sequence_sampler.py:47)
+            import random
+            firsts = torch.tensor([[random.randint(0, 1) for _ in range(t_a)] for _ in range(mu.shape[1])])
+            out = self.sampler.sample_pairs(mu.transpose(0, 1), cov.transpose(0, 1), firsts)       # (T_e, T_a, 2, K, 2)
+            return out.permute(2, 0, 1, 3, 4).cpu().numpy()
         # frames are independent: the batched GPU sampler takes all (frame, t_e) pairs in one call
         out = self.sampler.sample_batch(mu.reshape(-1, *mu.shape[2:]), cov.reshape(-1, *cov.shape[2:]), n=t_a)
         return out.reshape(n, mu.shape[1], t_a, mu.shape[2], 2).cpu().numpy()

@@ -38,8 +38,10 @@ class SkewUncertaintyTask(AleatoricUncertaintyTask):
         """(N, T_e, K, .) -> (N, T_e, T, K, 2)  (reference aleatoric_skew.py:48-53)"""
         from contour_uncertainty.sampler.posterior_shape_model.psm_skew_sequence import SequenceSkewPSMSampler
         if isinstance(self.sampler, SequenceSkewPSMSampler):      # an ED/ES pair is one unit: (2, T, K, 2) per t_e
-            cs = [self.sampler(mu[:, t], cov[:, t], alpha[:, t], n=T).cpu().numpy() for t in range(mu.shape[1])]
-            return np.array(cs).transpose(1, 0, 2, 3, 4)
+            import random
+            firsts = torch.tensor([[random.randint(0, 1) for _ in range(T)] for _ in range(mu.shape[1])])
+            out = self.sampler.sample_pairs(mu.transpose(0, 1), cov.transpose(0, 1), alpha.transpose(0, 1), firsts)
+            return out.permute(2, 0, 1, 3, 4).cpu().numpy()                      # (T_e, T, 2, K, 2) -> (2, T_e, T, K, 2)
         # frames are independent: all (frame, t_e) pairs and all T samples in one launch
         n, te, k = mu.shape[:3]
         out = self.sampler.sample_batch(mu.reshape(-1, k, 2), cov.reshape(-1, k, 2, 2), alpha.reshape(-1, k, 2), n=T)

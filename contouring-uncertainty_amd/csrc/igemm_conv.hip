@@ -793,6 +793,7 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
             dnb = 2;                                                     // ... or leaves CUs without a workgroup
         if (d->IS == 2) dnb = 4;
         if (d->IS == 1 && d->CO <= 32) dnb = 1;                          // thin layers (256^2 x 32 channels)
+        if (d->IS == 1 && dnb > 1 && cu_env_int("CU_CONV_DNB", 0)) dnb = cu_env_int("CU_CONV_DNB", 0);
         // Thin layers too, from 64 input channels on (measured, tools/thin_bench.py, profiles/r02_thin_bench.txt: 128^2 x 64
         // concat forward 313 -> 227 us, 256^2 x 32+32 -> 32 322 -> 286 us; with 32 input channels the one-tile-per-workgroup
         // structure loses to the persistent register-staged kernel, 173 vs 150 us)

@@ -962,7 +962,7 @@ static int pick_chunk(int N, int HW, int rows, int* nchunks) {
 // ---- launch helpers: `nimg` images starting at the pointers given, inside a tensor of N images (plane stride of stats)
 template <typename T>
 static int launch_stats(int nimg, int N, int HW, int C, const void* z, const float* gamma, const float* beta, float eps,
-                        float* stats, float* ws, hipStream_t st) {
+                        float* stats, float* ws, hipStream_t st, bool clean = false) {
     constexpr int PIECE = Elem<T>::PIECE;
     const RowMap rm = row_map(C, PIECE);
     if (HW <= 1024) {       // small feature maps: one fused launch
@@ -973,8 +973,10 @@ static int launch_stats(int nimg, int N, int HW, int C, const void* z, const flo
     }
     int nchunks = 1;
     const int chunk = pick_chunk(nimg, HW, rm.rows, &nchunks);
-    hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)nimg * C, st);
-    CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_stats: memset failed: %s", hipGetErrorString(e));
+    if (!clean) {
+        hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)nimg * C, st);
+        CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_stats: memset failed: %s", hipGetErrorString(e));
+    }
     const size_t lds = sizeof(float) * (size_t)rm.rows * rm.tpp * 2 * PIECE;
     hipLaunchKernelGGL(stats_partial_kernel<T>, dim3(nimg, nchunks), dim3(NT), lds, st, (const T*)z, ws, HW, C, rm.tpp,
                        rm.rows, chunk);
@@ -998,7 +1000,7 @@ static int launch_apply(int nimg, int N, int HW, int C, const void* z, const flo
 
 template <typename T>
 static int launch_bwd(int nimg, int N, int HW, int C, void* g, const void* z, const float* stats, const float* gamma,
-                      float slope, float* dgamma, float* dbeta, float* dbias, float* ws, hipStream_t st) {
+                      float slope, float* dgamma, float* dbeta, float* dbias, float* ws, hipStream_t st, bool clean = false) {
     constexpr int PIECE = Elem<T>::PIECE;
     const RowMap rm = row_map(C, PIECE);
     if (HW <= 1024) {       // small feature maps: one fused launch
@@ -1010,8 +1012,10 @@ static int launch_bwd(int nimg, int N, int HW, int C, void* g, const void* z, co
     }
     int nchunks = 1;
     const int chunk = pick_chunk(nimg, HW, rm.rows, &nchunks);
-    hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)nimg * C, st);
-    CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_lrelu_bwd: memset failed: %s", hipGetErrorString(e));
+    if (!clean) {
+        hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)nimg * C, st);
+        CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_lrelu_bwd: memset failed: %s", hipGetErrorString(e));
+    }
     const size_t lds = sizeof(float) * (size_t)rm.rows * rm.tpp * 2 * PIECE;
     dim3 grid(nimg, nchunks);
     hipLaunchKernelGGL(bwd_reduce_kernel<T>, grid, dim3(NT), lds, st, (const T*)g, (const T*)z, stats, slope, ws, N, HW, C,
@@ -1097,14 +1101,18 @@ extern "C" int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void
                                      float eps, float slope, float* stats, void* out, float* ws, int mode, void* stream) {
     NORM_COMMON_CHECKS("cu_instnorm_fwd_fused");
     CU_CHECK_ARG(z && stats && out && ws, "cu_instnorm_fwd_fused: null pointer");
+    const bool clean = (mode & CU_NORM_WS_CLEAN) != 0;       // the caller hands over a zeroed workspace: no memset launch
+    mode &= ~CU_NORM_WS_CLEAN;
     CU_CHECK_ARG(mode >= 0 && mode <= 2, "cu_instnorm_fwd_fused: mode %d", mode);
     const int np = rc_pick_np(HW, rm.rows);
     const int nch = cdiv(HW, rm.rows * np);
     if (mode == 0) mode = (HW <= 256 && nch <= RC_MAX_CHUNKS) ? 1 : 2;      // measured crossover (see the kernels' header)
     if (mode == 1) {
         CU_CHECK_ARG(nch <= RC_MAX_CHUNKS, "cu_instnorm_fwd_fused: %d chunks per image exceed %d", nch, RC_MAX_CHUNKS);
-        hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * ((size_t)RC_HDR + (size_t)N * rc_block_words(C)), st);
-        CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_fwd_fused: memset failed: %s", hipGetErrorString(e));
+        if (!clean) {
+            hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * ((size_t)RC_HDR + (size_t)N * rc_block_words(C)), st);
+            CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_fwd_fused: memset failed: %s", hipGetErrorString(e));
+        }
         if (dtype == CU_BF16) CU_RC_NP(launch_fwd_resident, bf16_t, np, N, HW, C, rm, nch, z, gamma, beta, eps, slope, stats, out, ws, st);
         else CU_RC_NP(launch_fwd_resident, float, np, N, HW, C, rm, nch, z, gamma, beta, eps, slope, stats, out, ws, st);
         CU_LAUNCH_CHECK();
@@ -1117,8 +1125,8 @@ extern "C" int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void
         const char* zp = (const char*)z + (size_t)n0 * HW * C * esz;
         char* op = (char*)out + (size_t)n0 * HW * C * esz;
         float* sp = stats + (size_t)n0 * C;
-        int rc = dtype == CU_BF16 ? launch_stats<bf16_t>(ni, N, HW, C, zp, gamma, beta, eps, sp, ws + (size_t)n0 * C * 2, st)
-                                  : launch_stats<float>(ni, N, HW, C, zp, gamma, beta, eps, sp, ws + (size_t)n0 * C * 2, st);
+        int rc = dtype == CU_BF16 ? launch_stats<bf16_t>(ni, N, HW, C, zp, gamma, beta, eps, sp, ws + (size_t)n0 * C * 2, st, clean)
+                                  : launch_stats<float>(ni, N, HW, C, zp, gamma, beta, eps, sp, ws + (size_t)n0 * C * 2, st, clean);
         if (rc) return rc;
         rc = dtype == CU_BF16 ? launch_apply<bf16_t>(ni, N, HW, C, zp, sp, slope, op, st)
                               : launch_apply<float>(ni, N, HW, C, zp, sp, slope, op, st);
@@ -1132,14 +1140,18 @@ extern "C" int cu_instnorm_bwd_fused(int dtype, int N, int HW, int C, void* g, c
                                      void* stream) {
     NORM_COMMON_CHECKS("cu_instnorm_bwd_fused");
     CU_CHECK_ARG(g && z && stats && ws, "cu_instnorm_bwd_fused: null pointer");
+    const bool clean = (mode & CU_NORM_WS_CLEAN) != 0;       // the caller hands over a zeroed workspace: no memset launch
+    mode &= ~CU_NORM_WS_CLEAN;
     CU_CHECK_ARG(mode >= 0 && mode <= 2, "cu_instnorm_bwd_fused: mode %d", mode);
     const int np = rc_pick_np(HW, rm.rows);
     const int nch = cdiv(HW, rm.rows * np);
     if (mode == 0) mode = (HW > 1024 && HW <= 4096 && nch <= RC_MAX_CHUNKS) ? 1 : 2;
     if (mode == 1) {
         CU_CHECK_ARG(nch <= RC_MAX_CHUNKS, "cu_instnorm_bwd_fused: %d chunks per image exceed %d", nch, RC_MAX_CHUNKS);
-        hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * ((size_t)RC_HDR + (size_t)N * rc_block_words(C)), st);
-        CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_bwd_fused: memset failed: %s", hipGetErrorString(e));
+        if (!clean) {
+            hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * ((size_t)RC_HDR + (size_t)N * rc_block_words(C)), st);
+            CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_bwd_fused: memset failed: %s", hipGetErrorString(e));
+        }
         if (dtype == CU_BF16) CU_RC_NP(launch_bwd_resident, bf16_t, np, N, HW, C, rm, nch, g, z, stats, gamma, slope, dgamma, dbeta, ws, st);
         else CU_RC_NP(launch_bwd_resident, float, np, N, HW, C, rm, nch, g, z, stats, gamma, slope, dgamma, dbeta, ws, st);
         CU_LAUNCH_CHECK();
@@ -1153,8 +1165,8 @@ extern "C" int cu_instnorm_bwd_fused(int dtype, int N, int HW, int C, void* g, c
         const char* zp = (const char*)z + (size_t)n0 * HW * C * esz;
         const float* sp = stats + (size_t)n0 * C;
         const int rc = dtype == CU_BF16
-            ? launch_bwd<bf16_t>(ni, N, HW, C, gp, zp, sp, gamma, slope, dgamma, dbeta, nullptr, ws + (size_t)n0 * C * 2, st)
-            : launch_bwd<float>(ni, N, HW, C, gp, zp, sp, gamma, slope, dgamma, dbeta, nullptr, ws + (size_t)n0 * C * 2, st);
+            ? launch_bwd<bf16_t>(ni, N, HW, C, gp, zp, sp, gamma, slope, dgamma, dbeta, nullptr, ws + (size_t)n0 * C * 2, st, clean)
+            : launch_bwd<float>(ni, N, HW, C, gp, zp, sp, gamma, slope, dgamma, dbeta, nullptr, ws + (size_t)n0 * C * 2, st, clean);
         if (rc) return rc;
     }
     return 0;

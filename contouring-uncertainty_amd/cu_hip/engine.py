@@ -82,6 +82,33 @@ class UNetCtx:
     n_up: int = 0
 
 
+class _WsArena:
+    """Bump allocator over one persistent float32 tensor, zeroed once per pass.  The first pass (size still unknown)
+    hands out individually zeroed tensors and records the total; from the second pass on every take is a slice."""
+
+    def __init__(self):
+        self.buf: Optional[Tensor] = None
+        self.off = 0
+        self.need = 0
+
+    def begin(self, device):
+        if self.buf is None or self.buf.device != device or self.buf.numel() < self.need:
+            self.buf = torch.zeros(max(self.need, 1), dtype=torch.float32, device=device) if self.need else None
+        elif self.off:
+            self.buf[:self.off].zero_()
+        self.off = 0
+        self.need = 0
+
+    def take(self, n: int, device) -> Tensor:
+        n = (n + 63) // 64 * 64
+        self.need += n
+        if self.buf is not None and self.off + n <= self.buf.numel():
+            out = self.buf[self.off:self.off + n]
+            self.off += n
+            return out
+        return torch.zeros(n, dtype=torch.float32, device=device)
+
+
 class UNetEngine:
     def __init__(self, in_channels: int, num_classes: int, strides: Sequence[int], filters: Sequence[int],
                  negative_slope: float = 1e-2, eps: float = 1e-5, dtype: torch.dtype = torch.bfloat16):
@@ -107,6 +134,9 @@ class UNetEngine:
         self.debug: Optional[Dict[str, Tensor]] = None    # tests/tools: set to {} to capture per-layer gradients (NHWC)
         self._prep_state = None     # (pointer key, item table, blocks, names) of the batched operand preparation
         self._dwk_ws: Optional[Tensor] = None
+        # InstanceNorm workspaces (atomics targets) of all layers of one pass: slices of ONE arena per direction that
+        # is zeroed by one fill at the start of the pass (instead of one memset launch per layer)
+        self._arena = {"fwd": _WsArena(), "bwd": _WsArena()}
         # weight gradients (+ their un-preparation) run on a second HIP stream beside the input-gradient chain: the two
         # only meet in dz, and each family's prologue / atomics tail is filled by the other's workgroups
         self.side_wgrad = os.environ.get("CONTOUR_SIDE_WGRAD", "1") != "0"
@@ -180,7 +210,8 @@ class UNetEngine:
     def _norm_act_fwd(self, P, prefix: str, z: Tensor) -> Act:
         gamma, beta = P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"]
         if self.fused_norm and self.materialize:
-            return ops.instnorm_fwd_fused(z, gamma, beta, self.slope, self.eps)
+            ws = self._arena["fwd"].take(ops.resident_ws_floats(z.shape[0], z.shape[3]), z.device)
+            return ops.instnorm_fwd_fused(z, gamma, beta, self.slope, self.eps, ws=ws, mode=ops.NORM_WS_CLEAN)
         out = Act(z, ops.instnorm_stats(z, gamma, beta, self.eps), self.slope)
         if self.materialize:
             ops.instnorm_apply(out)
@@ -229,6 +260,7 @@ class UNetEngine:
             self._last_ctx = ctx
         st = self.strides
         assert st[0] == 1
+        self._arena["fwd"].begin(img.device)
         self._prep_all(P)
         a = self._first_layer_fwd(P, ctx, "input_block.conv1", img)
         a = self._conv_layer_fwd(P, ctx, "input_block.conv2", [a], 1)
@@ -305,8 +337,9 @@ class UNetEngine:
         # d(conv bias) = sum_p dz is identically zero behind an InstanceNorm (dz has zero mean per (n, c)); the reference
         # accumulates rounding noise there.  G[conv.bias] stays exactly 0 (no kernel work, no atomics contention).
         if self.fused_norm:
+            ws = self._arena["bwd"].take(ops.resident_ws_floats(g.shape[0], g.shape[3]), g.device)
             ops.instnorm_bwd_fused(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
-                                   G[f"{prefix}.norm.bias"], getattr(rec.out, "ws", None))
+                                   G[f"{prefix}.norm.bias"], ws, mode=ops.NORM_WS_CLEAN)
         else:
             ops.instnorm_lrelu_bwd(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
                                    G[f"{prefix}.norm.bias"], None)
@@ -374,6 +407,7 @@ class UNetEngine:
         dt = self.dtype
         last = ctx.last
         n, h, w_, c_last = last.z.shape
+        self._arena["bwd"].begin(dlogits.device)
         # ---- 1x1 output conv
         dl = ops.nchw_f32_to_nhwc(dlogits.contiguous(), dt, cp=32)
         w = P["output_block.conv.weight"]

@@ -213,10 +213,18 @@ def _resident_ws(n: int, c: int, device) -> Tensor:
     return torch.empty(L.load().cu_instnorm_resident_ws_floats(n, c), dtype=torch.float32, device=device)
 
 
+NORM_WS_CLEAN = 16     # include/contour_hip.h: CU_NORM_WS_CLEAN
+
+
+def resident_ws_floats(n: int, c: int) -> int:
+    return int(L.load().cu_instnorm_resident_ws_floats(n, c))
+
+
 def instnorm_fwd_fused(z: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], slope: float, eps: float = 1e-5,
                        ws: Optional[Tensor] = None, mode: int = 0) -> Act:
     """statistics + LeakyReLU(z*scale + shift) in one call (cu_instnorm_fwd_fused; mode 0 auto, 1 resident-chunk
-    kernel, 2 two-pass kernels on cache-sized image groups) -> Act(z, stats, a)."""
+    kernel, 2 two-pass kernels on cache-sized image groups; + NORM_WS_CLEAN: ``ws`` is handed over zeroed)
+    -> Act(z, stats, a)."""
     n, h, w_, c = z.shape
     stats = torch.empty((4, n, c), dtype=torch.float32, device=z.device)
     out = torch.empty_like(z)

@@ -127,8 +127,11 @@ int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, const void* 
  *   1  "resident": one launch, every tensor read once -- workgroups keep their pixel chunk in registers while the
  *      per-(image, channel) sums are combined with atomics behind an image-local arrival counter (norm.hip), and
  *   2  the two-pass kernels (statistics / reduction pass, then apply pass).
- * ws: f32 workspace of cu_instnorm_resident_ws_floats(N, C) elements (zero-filled by the call as needed).  After the
+ * ws: f32 workspace of cu_instnorm_resident_ws_floats(N, C) elements, zero-filled by the call as needed -- unless
+ * CU_NORM_WS_CLEAN is or-ed into mode: the caller then hands over a workspace that is already zero (one memset for
+ * all layers of a step instead of one launch per layer); the call leaves it dirty.  After the
  * stream has drained, ((unsigned*)ws)[1] != 0 after a mode-1 call reports that its bounded arrival wait gave up. */
+#define CU_NORM_WS_CLEAN 16
 size_t cu_instnorm_resident_ws_floats(int N, int C);
 int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* z, const float* gamma, const float* beta,
                           float eps, float slope, float* stats, void* out, float* ws, int mode, void* stream);

@@ -19,6 +19,9 @@ def bench(fn, iters=10):
     return e0.elapsed_time(e1) / iters * 1e3
 n = 64
 MODES = [(0, "full"), (1, "no stores"), (2, "no MFMA"), (12, "no DMA after chunk 0"), (14, "no DMA, no MFMA"), (15, "nothing")]
+if len(sys.argv) > 1:
+    os.environ["CU_CONV_DNB"] = sys.argv[1]
+    MODES = MODES[:1]
 print("size C  " + "".join(f"{m[1]:>22s}" for m in MODES))
 for size, c in ((256, 32), (128, 64), (64, 128), (32, 256), (16, 480)):
     dt = torch.bfloat16

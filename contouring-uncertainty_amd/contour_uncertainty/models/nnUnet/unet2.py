@@ -90,10 +90,10 @@ def _is_flat(plist) -> bool:
 
 class _UNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module: "UNet", x: Tensor, *params: Tensor):
+    def forward(ctx, module: "UNet", slot, x: Tensor, *params: Tensor):
         P = dict(zip(module._pnames, params))
         logits, feats, ectx = module.engine.forward(P, x, module.bottleneck_out, module.training or module.mc_dropout)
-        ctx.module, ctx.ectx = module, ectx
+        ctx.module, ctx.ectx, ctx.slot = module, ectx, slot
         ctx.save_for_backward(*params)
         if module.bottleneck_out:
             return logits, feats
@@ -106,7 +106,7 @@ class _UNetFn(torch.autograd.Function):
         P = dict(zip(module._pnames, params))
         used = module._used_names
         total = sum(P[n].numel() for n in used)
-        flat = torch.zeros(total, dtype=torch.float32, device=dlogits.device)
+        flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
         G, off = {}, 0
         for n in used:
             k = P[n].numel()
@@ -115,10 +115,15 @@ class _UNetFn(torch.autograd.Function):
         module.last_flat_grad = flat
         if module.flat_grad_hook is not None:
             module.flat_grad_hook(flat)
-        with _lib.device_guard(dlogits):
-            module.engine.backward(P, G, ctx.ectx, dlogits, dfeats)
+        # the DSNT head may have left dL/dlogits in the engine's layout (cu_hip.head.GradSlot); its stand-in in autograd is
+        # a stride-0 zero tensor, and anything else that reached ``dlogits`` is a genuine extra gradient to add
+        dl_nhwc = ctx.slot.take() if ctx.slot is not None else None
+        if dl_nhwc is not None and all(s == 0 for s in dlogits.stride()):
+            dlogits = None
+        with _lib.device_guard(dl_nhwc if dlogits is None else dlogits):
+            module.engine.backward(P, G, ctx.ectx, dlogits, dfeats, dl_nhwc=dl_nhwc)
         ctx.ectx = None
-        return (None, None) + tuple(G.get(n) for n in module._pnames)
+        return (None, None, None) + tuple(G.get(n) for n in module._pnames)
 
 
 class UNet(nn.Module):
@@ -234,8 +239,13 @@ class UNet(nn.Module):
         params = [p for _, p in self.named_parameters()]
         if params[0].device != input_data.device:
             raise _lib.ContourHipError(f"input on {input_data.device}, parameters on {params[0].device}")
+        from cu_hip.head import GradSlot
+        slot = GradSlot(self.engine.dtype) if torch.is_grad_enabled() else None
         with _lib.device_guard(input_data):
-            return _UNetFn.apply(self, input_data.float(), *params)
+            out = _UNetFn.apply(self, slot, input_data.float(), *params)
+        if slot is not None:
+            (out[0] if isinstance(out, tuple) else out)._cu_grad_slot = slot
+        return out
 
 
 class _ConfidenceFn(torch.autograd.Function):

@@ -135,6 +135,66 @@ __global__ __launch_bounds__(HT) void dsnt_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// The same gradient written where its consumers read it: NHWC with CP (= 32) channels per pixel in the engine's element
+// type -- the Z operand of the 1x1 output convolution's weight / input gradients -- instead of NCHW f32 plus a layout
+// pass (saves one f32 write and one f32 read of N*K*H*W).  One thread per pixel walks the K maps (loads coalesced per
+// map across the wave), one 64-byte (bf16) row store per pixel; maps K..CP-1 are zero.
+template <typename T>
+__global__ __launch_bounds__(256) void dsnt_bwd_nhwc_kernel(const float* __restrict__ logits, const float* __restrict__ aux,
+                                                            const float* __restrict__ gmu, const float* __restrict__ gsigma,
+                                                            int use_covar, T* __restrict__ dl, int K, int H, int W) {
+    constexpr int CP = 32;
+    __shared__ float sc[CP][12];
+    const int n = blockIdx.y, HWn = H * W;
+    const float half = 0.5f * (float)W;
+    if ((int)threadIdx.x < K) {
+        const int map = n * K + threadIdx.x;
+        const float* a = aux + 8 * (size_t)map;
+        const float gx = gmu[2 * map] * 0.5f * (float)W, gy = gmu[2 * map + 1] * 0.5f * (float)H;
+        const float gxx = gsigma[3 * map] * half * half, gyy = gsigma[3 * map + 1] * half * half;
+        const float gxy = use_covar ? gsigma[3 * map + 2] * half * half : 0.f;
+        float* o = sc[threadIdx.x];
+        o[0] = gx; o[1] = gy; o[2] = gxx; o[3] = gyy; o[4] = gxy;
+        o[5] = a[0]; o[6] = a[1]; o[7] = a[2]; o[8] = a[3];
+        o[9] = gx * a[2] + gy * a[3] + gxx * a[4] + gyy * a[5] + gxy * a[6];        // sum_j p_j q_j in closed form
+    }
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HWn) return;
+    const int yy = p / W, xx = p - yy * W;
+    const float invW = 1.f / (float)W;
+    const float X = (2.f * xx + 1.f) * invW - 1.f, Y = (2.f * yy + 1.f) * invW - 1.f;
+    const float* lp = logits + (size_t)n * K * HWn + p;
+    float v[CP];
+#pragma unroll
+    for (int k = 0; k < CP; ++k) v[k] = k < K ? lp[(size_t)k * HWn] : 0.f;
+#pragma unroll
+    for (int k = 0; k < CP; ++k) {
+        if (k < K) {
+            const float* o = sc[k];
+            const float dx = X - o[7], dy = Y - o[8];
+            const float pr = expf(v[k] - o[5]) * o[6];
+            const float q = o[0] * X + o[1] * Y + o[2] * dx * dx + o[3] * dy * dy + o[4] * dx * dy;
+            v[k] = pr * (q - o[9]);
+        }
+    }
+    T* op = dl + ((size_t)n * HWn + p) * CP;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                w[e] = (unsigned)f32_to_bf16(v[8 * g + 2 * e]) | ((unsigned)f32_to_bf16(v[8 * g + 2 * e + 1]) << 16);
+            *reinterpret_cast<u32x4*>(op + 8 * g) = w;
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            *reinterpret_cast<f32x4*>(op + 4 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+    }
+}
+
 // -------------------------------------------------------------------------------------------------- NLL
 __global__ __launch_bounds__(HT) void nll_kernel(int M, int skew, float w_mse, float w_log, const float* __restrict__ mu,
                                                  const float* __restrict__ sigma, const float* __restrict__ y,
@@ -272,6 +332,23 @@ extern "C" int cu_dsnt_head_bwd(int NK, int H, int W, const float* logits, const
     while (NK * split < 1024 && (H * W) / (4 * HT * split) > 4) split *= 2;
     hipLaunchKernelGGL(dsnt_bwd_kernel, dim3(NK, split), dim3(HT), 0, reinterpret_cast<hipStream_t>(stream), logits, aux,
                        gmu, gsigma, use_covar, dlogits, H, W);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_dsnt_head_bwd_nhwc(int dtype, int N, int K, int H, int W, const float* logits, const float* aux,
+                                     const float* gmu, const float* gsigma, int use_covar, void* dl, void* stream) {
+    CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_dsnt_head_bwd_nhwc: bad dtype %d", dtype);
+    CU_CHECK_ARG(N > 0 && K > 0 && K <= 32 && H > 0 && W > 0 && H == W, "cu_dsnt_head_bwd_nhwc: bad shape (K <= 32, square maps)");
+    CU_CHECK_ARG(logits && aux && gmu && gsigma && dl, "cu_dsnt_head_bwd_nhwc: null pointer");
+    const dim3 grid(cdiv(H * W, 256), N);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL(dsnt_bwd_nhwc_kernel<bf16_t>, grid, dim3(256), 0, st, logits, aux, gmu, gsigma, use_covar,
+                           (bf16_t*)dl, K, H, W);
+    else
+        hipLaunchKernelGGL(dsnt_bwd_nhwc_kernel<float>, grid, dim3(256), 0, st, logits, aux, gmu, gsigma, use_covar,
+                           (float*)dl, K, H, W);
     CU_LAUNCH_CHECK();
     return 0;
 }

@@ -401,15 +401,21 @@ class UNetEngine:
                       accum=[accum])
 
     # ------------------------------------------------------------------------------------------ backward
-    def backward(self, P: Dict[str, Tensor], G: Dict[str, Tensor], ctx: UNetCtx, dlogits: Tensor,
-                 dfeats: Optional[Tensor]):
-        """Accumulates parameter gradients into G (float32, reference layouts; every touched tensor is ``+=``)."""
+    def backward(self, P: Dict[str, Tensor], G: Dict[str, Tensor], ctx: UNetCtx, dlogits: Optional[Tensor],
+                 dfeats: Optional[Tensor], dl_nhwc: Optional[Tensor] = None):
+        """Accumulates parameter gradients into G (float32, reference layouts; every touched tensor is ``+=``).
+        dL/dlogits arrives as ``dlogits`` (N, K, H, W) float32 and / or as ``dl_nhwc`` (N, H, W, 32) in the engine's
+        element type (``cu_dsnt_head_bwd_nhwc``); both given = their sum."""
         dt = self.dtype
         last = ctx.last
         n, h, w_, c_last = last.z.shape
-        self._arena["bwd"].begin(dlogits.device)
+        self._arena["bwd"].begin(last.z.device)
         # ---- 1x1 output conv
-        dl = ops.nchw_f32_to_nhwc(dlogits.contiguous(), dt, cp=32)
+        if dl_nhwc is not None:
+            assert dl_nhwc.dtype == dt and dl_nhwc.shape == (n, h, w_, 32)
+            dl = dl_nhwc if dlogits is None else dl_nhwc + ops.nchw_f32_to_nhwc(dlogits.contiguous(), dt, cp=32)
+        else:
+            dl = ops.nchw_f32_to_nhwc(dlogits.contiguous(), dt, cp=32)
         w = P["output_block.conv.weight"]
         with self._wgrad_stream(dl, last.z):
             dwk = self._dwk((1, 32, c_last), dl.device)

@@ -18,9 +18,28 @@ Tensor = torch.Tensor
 LOG_KEYS = ("loss", "distance_loss", "loss_term1", "loss_term2", "loss_term3", "alpha_norm")
 
 
+class GradSlot:
+    """Hand-over of dL/dlogits in the layout the producer's backward reads.  ``UNet.forward`` hangs one on the logits it
+    returns (``logits._cu_grad_slot``); the head's backward then writes the gradient ONCE, as NHWC in the engine's
+    element type (``cu_dsnt_head_bwd_nhwc``), puts it here and returns a stride-0 zero tensor to autograd; the UNet's
+    backward takes it (and adds whatever else autograd accumulated into its incoming gradient).  Logits that did not
+    come straight from such a UNet carry no slot and get the ordinary NCHW float32 gradient."""
+    __slots__ = ("dtype", "dl")
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self.dl: Optional[Tensor] = None
+
+    def take(self) -> Optional[Tensor]:
+        dl, self.dl = self.dl, None
+        return dl
+
+
 class _DsntNllFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits: Tensor, y: Tensor, alpha: Optional[Tensor], covar: bool, w_mse: float, w_log: float):
+    def forward(ctx, logits: Tensor, y: Tensor, alpha: Optional[Tensor], covar: bool, w_mse: float, w_log: float,
+                slot: Optional[GradSlot] = None):
+        ctx.slot = slot if logits.is_contiguous() else None
         logits = logits.contiguous()
         need_grad = logits.requires_grad or (alpha is not None and alpha.requires_grad)
         with ops.L.device_guard(logits):
@@ -39,9 +58,14 @@ class _DsntNllFn(torch.autograd.Function):
         logits, aux, gmu, gsigma, galpha = ctx.saved_tensors
         scale = gloss.reshape(1)
         with ops.L.device_guard(logits):
-            dl = ops.dsnt_head_bwd(logits, aux, (gmu * scale).contiguous(), (gsigma * scale).contiguous(), ctx.covar)
+            if ctx.slot is not None:
+                ctx.slot.dl = ops.dsnt_head_bwd_nhwc(logits, aux, (gmu * scale).contiguous(), (gsigma * scale).contiguous(),
+                                                     ctx.covar, ctx.slot.dtype)
+                dl = torch.zeros((), dtype=logits.dtype, device=logits.device).expand(logits.shape)
+            else:
+                dl = ops.dsnt_head_bwd(logits, aux, (gmu * scale).contiguous(), (gsigma * scale).contiguous(), ctx.covar)
         dalpha = (galpha * scale) if ctx.has_alpha else None
-        return dl, None, dalpha, None, None, None
+        return dl, None, dalpha, None, None, None, None
 
 
 def dsnt_nll(logits: Tensor, y: Tensor, alpha: Optional[Tensor] = None, covar: bool = True, mse_weight: float = 1.0,
@@ -49,7 +73,7 @@ def dsnt_nll(logits: Tensor, y: Tensor, alpha: Optional[Tensor] = None, covar: b
     """logits (N,K,H,W) f32, y (N,K,2) pixel (x,y), alpha (N,K,2) or None ->
     (logs dict of 0-dim tensors with a differentiable ``loss``, mu (N,K,2), Sigma (N,K,2,2))."""
     loss, logs, mu, sigma3 = _DsntNllFn.apply(logits, y, alpha, bool(covar), float(mse_weight),
-                                              float(log_penalty_weight))
+                                              float(log_penalty_weight), getattr(logits, "_cu_grad_slot", None))
     out: Dict[str, Tensor] = {"loss": loss, "distance_loss": logs[1], "loss_term1": logs[2], "loss_term2": logs[3]}
     if alpha is not None:
         out["loss_term3"] = logs[4]

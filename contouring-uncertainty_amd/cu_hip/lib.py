@@ -64,6 +64,7 @@ _SIGS = {
     "cu_nhwc_to_nchw_f32": (C.c_int, [C.c_int] * 4 + [_P] * 2 + [C.c_int, _P]),
     "cu_dsnt_head_fwd": (C.c_int, [C.c_int] * 3 + [_P, C.c_int] + [_P] * 4),
     "cu_dsnt_head_bwd": (C.c_int, [C.c_int] * 3 + [_P] * 4 + [C.c_int] + [_P] * 2),
+    "cu_dsnt_head_bwd_nhwc": (C.c_int, [C.c_int] * 5 + [_P] * 4 + [C.c_int] + [_P] * 2),
     "cu_nll_fwd_bwd": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float] + [_P] * 10),
     "cu_linear_fwd": (C.c_int, [C.c_int] * 3 + [_P] * 5),
     "cu_linear_bwd": (C.c_int, [C.c_int] * 3 + [_P] * 7),

@@ -318,6 +318,17 @@ def dsnt_head_bwd(logits: Tensor, aux: Tensor, gmu: Tensor, gsigma: Tensor, use_
     return dl
 
 
+def dsnt_head_bwd_nhwc(logits: Tensor, aux: Tensor, gmu: Tensor, gsigma: Tensor, use_covar: bool, dtype) -> Tensor:
+    """-> dL/dlogits as (N, H, W, 32) ``dtype`` (channels K.. zero): what ``UNetEngine.backward`` stages (cu_dsnt_head_bwd_nhwc)."""
+    n, k, h, w_ = logits.shape
+    dl = torch.empty((n, h, w_, 32), dtype=dtype, device=logits.device)
+    with _Prof("dsnt_head"):
+        L.check(L.load().cu_dsnt_head_bwd_nhwc(L.dtype_code(dtype), n, k, h, w_, L.ptr(logits), L.ptr(aux), L.ptr(gmu),
+                                               L.ptr(gsigma), int(use_covar), L.ptr(dl), L.stream_ptr()),
+                "cu_dsnt_head_bwd_nhwc")
+    return dl
+
+
 def nll_fwd_bwd(mu: Tensor, sigma: Tensor, y: Tensor, alpha: Optional[Tensor], w_mse: float = 1.0,
                 w_log: float = 1.0, need_grad: bool = True, terms: Optional[Tensor] = None):
     m = mu.numel() // 2

@@ -162,6 +162,10 @@ int cu_dsnt_head_fwd(int NK, int H, int W, const float* logits, int use_covar, f
  * off-diagonal entries) -> dlogits [N*K][H][W] f32. */
 int cu_dsnt_head_bwd(int NK, int H, int W, const float* logits, const float* aux, const float* gmu,
                      const float* gsigma, int use_covar, float* dlogits, void* stream);
+/* The same gradient in the layout its consumers read (the Z operand of the 1x1 output convolution's weight / input
+ * gradients, layers.py:456-463): dl [N][H][W][32] of dtype, channels K..31 zero; K <= 32.  Saves the NCHW f32 round trip. */
+int cu_dsnt_head_bwd_nhwc(int dtype, int N, int K, int H, int W, const float* logits, const float* aux,
+                          const float* gmu, const float* gsigma, int use_covar, void* dl, void* stream);
 
 /* Gaussian NLL of dsnt_al.py:64-74 and skew-normal NLL of bivariateskewnormal.py:36-61 (closed-form 2x2 algebra,
  * Sigma^-1/2 = ((Sigma + sqrt(det) I)/sqrt(tr + 2 sqrt(det)))^-1 instead of distributions/utils.py:100-129's eig).

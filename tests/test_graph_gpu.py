@@ -11,19 +11,20 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "tests"))
 
 
-LR = 5e-5      # small enough that two runs of the same sequence stay together (at the config's 1e-3 the first Adam steps of a
-               # random network amplify the f32-atomics rounding noise to 8 % of the loss: tools/_graph_diag.py)
+LR = 1e-6      # small enough that the seven steps see (nearly) the same gradient: at 1e-4 this random network goes through a
+               # loss spike at step 2 (|g| x 300) whose size differs by several % from run to run, eager or not
 
 
 def _build(capturable):
+    """4 stages on 64 x 64 (8 x 8 at the bottom): a well-conditioned step.  The 6-stage test network normalises 2 x 2 maps,
+    which amplifies the f32-atomics rounding noise until two EAGER runs of the same seven steps disagree by ~100 % in
+    the Adam moments of the deep layers (tools/_graph_diag.py) -- nothing could be told apart there."""
     from test_model_gpu import make_task
     from oracle import unet as OU
-    task = make_task("dsnt-skew", 6, 64, "f32")
+    task = make_task("dsnt-al", 4, 64, "f32")
     task.hparams.optim = dict(task.hparams.optim, capturable=capturable, lr=LR)
-    spec = OU.UNetSpec(strides=(1, 2, 2, 2, 2, 2))
-    gen = torch.Generator().manual_seed(0)
-    task.model.load_state_dict(OU.init_unet_state(spec, gen), strict=True)
-    task.skew_block.load_state_dict(OU.init_confidence_state(42, gen), strict=True)
+    spec = OU.UNetSpec(strides=(1, 2, 2, 2))
+    task.model.load_state_dict(OU.init_unet_state(spec, torch.Generator().manual_seed(0)), strict=True)
     return task.to("cuda")
 
 
@@ -74,20 +75,18 @@ def test_captured_step_replays_like_the_eager_step():
     step.finish()
     # the loss of replay k is the loss of eager step 3 + k
     for a, b in zip(got, losses[3:]):
-        assert abs(a - b) <= 5e-3 * abs(b), (got, losses)
-    assert got[-1] < got[0] < losses[0]                 # and it is training, not replaying one frozen step
-    # Both runs moved the weights (about 7 * lr each) and accumulated the same Adam moments.  The moments are compared, not
-    # the weights: Adam normalises every element to a step of about lr whatever its gradient, so elements whose gradient is
-    # f32-atomics rounding noise take either sign from run to run (a third of the L2 norm of the weight change), while
-    # the moments are dominated by the elements that carry signal
+        assert abs(a - b) <= 1e-4 * abs(b), (got, losses)
+    # seven Adam steps on a (nearly) constant gradient move every weight by about 7 * lr, in both runs, the same way
     da = eager.model.flat_params()[0] - w0
     db = task.model.flat_params()[0] - w0
-    assert float(da.abs().mean()) > 2 * LR and float(db.abs().mean()) > 2 * LR
+    for d in (da, db):
+        assert 5 * LR < float(d.abs().mean()) < 7.5 * LR, float(d.abs().mean())
+    assert float((torch.sign(da) == torch.sign(db)).float().mean()) > 0.97
 
     def moments(o, t, key):
         return torch.cat([o.state[q][key].reshape(-1) for q in t.model.parameters() if q in o.state])
 
-    for key, tol in (("exp_avg", 0.05), ("exp_avg_sq", 0.05)):
+    for key, tol in (("exp_avg", 5e-3), ("exp_avg_sq", 5e-3)):
         ma, mb = moments(opt, eager, key), moments(copt, task, key)
         assert ma.shape == mb.shape and float((ma - mb).norm() / ma.norm()) < tol, (key, float((ma - mb).norm() / ma.norm()))
     st = copt.state[next(iter(task.model.parameters()))]

@@ -308,6 +308,15 @@ def test_dsnt_head_vs_golden(golden_dir, size):
     else:
         ref = torch.from_numpy(g[f"{tag}_dlogits_row"])
         assert float((dl[0, 0, 100] - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    # the same gradient in the layout / element type the UNet's backward stages (cu_dsnt_head_bwd_nhwc): f32 is the same
+    # arithmetic up to fused-multiply-add contraction, bf16 its rounding; channels K.. are zero
+    d32 = ops.dsnt_head_bwd_nhwc(logits, aux, gmu.contiguous(), gs.contiguous(), True, torch.float32).cpu()
+    assert d32.shape == (n, size, size, 32) and float(d32[..., k:].abs().max()) == 0.0
+    scale = float(dl.abs().max())
+    assert float((d32[..., :k].permute(0, 3, 1, 2) - dl).abs().max()) <= 2e-6 * scale
+    d16 = ops.dsnt_head_bwd_nhwc(logits, aux, gmu.contiguous(), gs.contiguous(), True, torch.bfloat16).cpu()
+    err = (d16[..., :k].permute(0, 3, 1, 2).float() - dl).abs()
+    assert bool((err <= dl.abs() * 2.0 ** -8 + 2e-6 * scale).all()) and float(d16[..., k:].abs().max()) == 0.0
 
 
 def test_nll_vs_golden(golden_dir):

@@ -39,6 +39,9 @@ struct ConvKArgs {
     int imgs;                   // images per tile (TW*TH*imgs <= 128*MA; rows beyond are idle)
     int txl, tyl, ntiles;       // log2 of tiles per row / column, total pixel tiles
     int tap_lds;                // byte offset of the tap table inside the dynamic LDS
+    int ksplit, kspan;          // split-K (tiny feature maps): grid.z = ksplit workgroups per tile, each walks kspan input
+    float* ws0; float* ws1;     // channels and stores its f32 partial tile into slice blockIdx.z of ws (laid out like
+    size_t ws_slice;            // dst0 | dst1; ws_slice floats per split)
     int dbg;                    // CU_CONV_DBG bits (timing experiments only): 1 no stores, 2 no MFMA, 4 no commit, 8 no loads
 };
 
@@ -306,9 +309,11 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
     auto tile_of = [&](int l) { return xcd_order ? (l & 7) * (ntiles >> 3) + (l >> 3) : l; };
     int ltile = blockIdx.x;
     int tile = tile_of(ltile);
+    const int c_begin = p.ksplit > 1 ? (int)blockIdx.z * p.kspan : 0;
+    const int c_end = p.ksplit > 1 ? (c_begin + p.kspan < CI ? c_begin + p.kspan : CI) : CI;
     if (ltile < ntiles) {
         tile_geometry(tile);
-        prefetch(0);
+        prefetch(c_begin);
     }
     while (ltile < ntiles) {
         // origin of the tile being computed (the staging state may move on to the next tile before the epilogue)
@@ -326,16 +331,16 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-        for (int c0 = 0, ci = 0; c0 < CI; c0 += CK, ++ci) {
+        for (int c0 = c_begin, ci = c_begin / CK; c0 < c_end; c0 += CK, ++ci) {
             __syncthreads();          // previous chunk's fragment reads are done
             if (!CU_DBG(p, 4)) commit(c0);
             __syncthreads();
             if (!CU_DBG(p, 8)) {
-            if (c0 + CK < CI) {
+            if (c0 + CK < c_end) {
                 prefetch(c0 + CK);
             } else if (lnext < ntiles) {  // cross-tile prefetch: the next tile's first chunk flies under these MFMAs
                 tile_geometry(next);
-                prefetch(0);
+                prefetch(c_begin);
             }
             }
             const int wbase_units = WRES ? ci * w_chunk_units : 0;
@@ -408,6 +413,25 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
                 }
                 const bool d1 = colb >= p.D0;
                 const int accum = d1 ? p.accum1 : p.accum0;
+                // split-K partial tile: plain f32 stores into this split's slice of the workspace (laid out like the
+                // destination); the finish pass sums the slices in a fixed order and applies bias / rounding / accumulate
+                if (p.ksplit > 1) {
+                    if (pvalid) {
+                        const int DC = d1 ? p.DC1 : p.DC0;
+                        float* o = (d1 ? p.ws1 : p.ws0) + (size_t)blockIdx.z * p.ws_slice + opix * DC +
+                                   (d1 ? colb - p.D0 : colb) + 4 * h;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            // the arithmetic no-op moves the value out of the accumulator file: storing the accumulator
+                            // registers of this block directly makes hipcc emit an illegal instruction in some instances
+                            f32x4 ov;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) ov[e] = acc[a][b][4 * g + e] + 0.f * (float)p.ksplit;
+                            *reinterpret_cast<f32x4*>(o + 8 * g) = ov;
+                        }
+                    }
+                    continue;
+                }
                 if constexpr (sizeof(T) == 2) {
                     if (!p.out_nchw && !accum) {
                         // bf16 fast path: lanes l and l+32 hold interleaved channel quads of the same pixel; two
@@ -720,9 +744,39 @@ int launch(const ConvKArgs& a, size_t lds, int grid_x, int grid_y, hipStream_t s
                                            (int)lds);
         CU_CHECK_ARG(e == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(k, dim3(grid_x, grid_y), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k, dim3(grid_x, grid_y, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, st, a);
     CU_LAUNCH_CHECK();
     return 0;
+}
+
+// split-K finish: dst = T(sum of the splits' slices, in split order + bias [+ dst]).  4 elements per thread; DC % 4 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void ksplit_finish_kernel(const float* __restrict__ ws, size_t slice, int ksplit,
+                                                            T* __restrict__ dst, const float* __restrict__ bias, size_t n4,
+                                                            int DC, int accum) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(ws + 4 * i);
+    for (int k = 1; k < ksplit; ++k) v += *reinterpret_cast<const f32x4*>(ws + (size_t)k * slice + 4 * i);
+    if (bias) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + (int)((4 * i) % (size_t)DC));
+        v += b;
+    }
+    T* o = dst + 4 * i;
+    if constexpr (sizeof(T) == 2) {
+        if (accum) {
+            const u32x2 old = *reinterpret_cast<const u32x2*>(o);
+            v[0] += __uint_as_float(old[0] << 16); v[1] += __uint_as_float(old[0] & 0xffff0000u);
+            v[2] += __uint_as_float(old[1] << 16); v[3] += __uint_as_float(old[1] & 0xffff0000u);
+        }
+        u32x2 pk;
+        pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<u32x2*>(o) = pk;
+    } else {
+        if (accum) v += *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = v;
+    }
 }
 
 }  // namespace
@@ -730,8 +784,14 @@ int launch(const ConvKArgs& a, size_t lds, int grid_x, int grid_y, hipStream_t s
 int cu_pconv_try(const cu_conv_desc* d, const void* src0, const void* w, const float* bias, void* dst0, void* stream);
 
 extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float* scale0, const float* shift0,
+                            const void* src1, const float* scale1, const float* shift1, const void* w, const float* bias,
+                            void* dst0, void* dst1, void* stream) {
+    return cu_conv_gemm_ws(d, src0, scale0, shift0, src1, scale1, shift1, w, bias, dst0, dst1, nullptr, 0, stream);
+}
+
+extern "C" int cu_conv_gemm_ws(const cu_conv_desc* d, const void* src0, const float* scale0, const float* shift0,
                             const void* src1, const float* scale1, const float* shift1, const void* w,
-                            const float* bias, void* dst0, void* dst1, void* stream) {
+                            const float* bias, void* dst0, void* dst1, float* ws, size_t ws_floats, void* stream) {
     CU_CHECK_ARG(d != nullptr, "cu_conv_gemm: null descriptor");
     CU_CHECK_ARG(d->dtype == CU_F32 || d->dtype == CU_BF16, "cu_conv_gemm: bad dtype %d", d->dtype);
     const bool bf = d->dtype == CU_BF16;
@@ -946,12 +1006,58 @@ extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float
     if (grid_x > cap) grid_x = cap;
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // ---- split-K for tiny feature maps (<= 4x4 at batch 64): with so few pixel tiles every workgroup walks all channel
+    //      chunks one L2 round trip at a time (33-36 us whatever the FLOPs).  grid.z workgroups share a tile's chunks and
+    //      store f32 partial tiles into their slice of the caller's workspace; a finish pass sums the slices (fixed order:
+    //      deterministic), applies bias / rounding / accumulate.  Needs a destination that this launch covers completely.
+    size_t fin0 = 0, fin1 = 0;
+    {
+        const long wgs = (long)grid_x * coltiles2;
+        const bool whole = (d->OS == 1 && d->OY0 == 0 && d->OX0 == 0 && d->PH == d->OH && d->PW == d->OW &&
+                            d->DC0 == d->D0 && (d->D0 == d->CO || d->DC1 == d->CO - d->D0)) ||
+                           (d->par_co > 0 && d->DC0 == d->par_co && d->OH == 2 * d->PH && d->OW == 2 * d->PW);
+        fin0 = (size_t)d->N * d->OH * d->OW * d->DC0;
+        fin1 = d->D0 == d->CO ? 0 : (size_t)d->N * d->OH * d->OW * d->DC1;
+        const int max_wgs = cu_env_int("CU_CONV_KSPLIT_WGS", 128);
+        if (ws && !wres && whole && !d->out_nchw_f32 && nchunks >= 4 && wgs <= max_wgs && a.ntiles <= grid_x &&
+            !cu_env_set("CU_CONV_NO_KSPLIT")) {
+            int want = (int)(512 / wgs);
+            if (want > 8) want = 8;
+            if (want > nchunks / 2) want = nchunks / 2;
+            while (want > 1 && (size_t)want * (fin0 + fin1) > ws_floats) --want;
+            if (want > 1) {
+                const int per = cdiv(nchunks, want);
+                a.ksplit = cdiv(nchunks, per);
+                a.kspan = per * CK;
+                a.ws0 = ws;
+                a.ws1 = ws + fin0;
+                a.ws_slice = fin0 + fin1;
+            }
+        }
+    }
+    auto finish = [&]() -> int {
+        if (a.ksplit <= 1) return 0;
+        for (int k = 0; k < 2; ++k) {
+            const size_t n = k ? fin1 : fin0;
+            if (!n) continue;
+            const float* wsp = k ? a.ws1 : a.ws0;
+            void* dp = k ? dst1 : dst0;
+            const float* bp = bias ? bias + (k ? d->D0 : 0) : nullptr;
+            const int DC = k ? d->DC1 : d->DC0, acc = k ? d->accum1 : d->accum0;
+            const unsigned blocks = (unsigned)((n / 4 + 255) / 256);
+            if (bf) hipLaunchKernelGGL(ksplit_finish_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, wsp, a.ws_slice, a.ksplit, (bf16_t*)dp, bp, n / 4, DC, acc);
+            else hipLaunchKernelGGL(ksplit_finish_kernel<float>, dim3(blocks), dim3(256), 0, st, wsp, a.ws_slice, a.ksplit, (float*)dp, bp, n / 4, DC, acc);
+        }
+        CU_LAUNCH_CHECK();
+        return 0;
+    };
     const int nx = ma == 2 ? 6 : (a.halo_px * 4 > 256 * 4 ? 10 : 4);
     const bool plain = !scale0 && d->slope0 == 1.0f && (d->C1 == 0 || (!scale1 && d->slope1 == 1.0f));
 #define CU_L(T, MAv, NBv, NXv, NTv, WR)                                                              \
     do {                                                                                             \
-        if (plain) return launch<T, MAv, NBv, NXv, NTv, WR, true>(a, lds, grid_x, coltiles2, st);     \
-        return launch<T, MAv, NBv, NXv, NTv, WR, false>(a, lds, grid_x, coltiles2, st);               \
+        const int rc_ = plain ? launch<T, MAv, NBv, NXv, NTv, WR, true>(a, lds, grid_x, coltiles2, st) \
+                              : launch<T, MAv, NBv, NXv, NTv, WR, false>(a, lds, grid_x, coltiles2, st); \
+        return rc_ ? rc_ : finish();                                                                 \
     } while (0)
 #define CU_NXNT(T, NBv, WR)                                       \
     do {                                                          \

@@ -35,7 +35,9 @@ class CapturedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.logs = self._step(0)
-        self.warmup_steps = warmup + 1          # the capture itself does not execute
+        # the capture ran the optimizer's host code (its per-parameter step counters moved) but no kernel
+        self.optimizer.note_replayed_steps(-1)
+        self.warmup_steps = warmup
 
     def _step(self, i):
         self.optimizer.zero_grad(set_to_none=True)

@@ -48,6 +48,7 @@ _SIGS = {
     "cu_version": (C.c_int, []),
     "cu_arch": (C.c_char_p, []),
     "cu_conv_gemm": (C.c_int, [C.POINTER(ConvDesc)] + [_P] * 11),
+    "cu_conv_gemm_ws": (C.c_int, [C.POINTER(ConvDesc)] + [_P] * 11 + [C.c_size_t, _P]),
     "cu_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc)] + [_P] * 9),
     "cu_conv_c1_fwd": (C.c_int, [C.c_int] * 5 + [_P] * 5),
     "cu_conv_c1_wgrad": (C.c_int, [C.c_int] * 5 + [_P] * 4),

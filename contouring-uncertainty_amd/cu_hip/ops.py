@@ -7,7 +7,7 @@ InstanceNorm+LeakyReLU of the layer that produced it (applied by the consumer wh
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -125,10 +125,27 @@ def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: T
     nbytes = (d.N * d.SH * d.SW * (d.C0 + d.C1) * esz if d.IS == 1 else d.N * d.PH * d.PW * d.ntaps * (d.C0 + d.C1) * esz) \
         + d.N * d.PH * d.PW * d.CO * (4 if out_nchw else esz) * (2 if any(accum) else 1)
     note = f"N{d.N} {d.PH}x{d.PW} IS{d.IS} OS{d.OS} C{d.C0}+{d.C1}->{d.CO} t{d.ntaps}"
+    ws = _split_k_ws(t0.device)
     with _Prof("igemm_conv", flops, note, nbytes):
-        rc = lib.cu_conv_gemm(d, L.ptr(t0), L.ptr(sc0), L.ptr(sh0), L.ptr(t1), L.ptr(sc1), L.ptr(sh1), L.ptr(w),
-                              L.ptr(bias), L.ptr(dst0), L.ptr(dsts[1]) if len(dsts) > 1 else None, L.stream_ptr())
-    L.check(rc, "cu_conv_gemm")
+        rc = lib.cu_conv_gemm_ws(d, L.ptr(t0), L.ptr(sc0), L.ptr(sh0), L.ptr(t1), L.ptr(sc1), L.ptr(sh1), L.ptr(w),
+                                 L.ptr(bias), L.ptr(dst0), L.ptr(dsts[1]) if len(dsts) > 1 else None, L.ptr(ws), ws.numel(),
+                                 L.stream_ptr())
+    L.check(rc, "cu_conv_gemm_ws")
+
+
+_SPLIT_K_WS: Dict[str, Tensor] = {}
+SPLIT_K_WS_FLOATS = 16 << 20
+
+
+def _split_k_ws(device) -> Tensor:
+    """The split-K scratch of cu_conv_gemm_ws: one f32 buffer per device (64 MiB; 8 slices of a 4x4 x 1920-column tile).
+    Launches that use it are ordered on one stream per device (the convolution chain; the weight-gradient stream of
+    cu_hip.engine launches no cu_conv_gemm)."""
+    key = str(device)
+    ws = _SPLIT_K_WS.get(key)
+    if ws is None:
+        ws = _SPLIT_K_WS[key] = torch.empty(SPLIT_K_WS_FLOATS, dtype=torch.float32, device=device)
+    return ws
 
 
 def conv_wgrad(srcs: Sequence[Act], z: Tensor, dwk: Tensor, *, grid: Tuple[int, int], in_stride: int, z_stride: int,

@@ -73,6 +73,15 @@ int cu_conv_gemm(const cu_conv_desc* d,
                  const void* src1, const float* scale1, const float* shift1,
                  const void* w, const float* bias /* [CO] or NULL */,
                  void* dst0, void* dst1, void* stream);
+/* The same, allowed to split the channel reduction over several workgroups per tile (tiny feature maps: <= 4x4 at
+ * batch 64, where one workgroup per tile walks all channel chunks one L2 round trip at a time).  ws: caller-owned f32
+ * scratch of ws_floats elements (contents irrelevant on entry, garbage on exit): every split stores its partial tile
+ * in a slice of its own and a finish pass sums the slices in a fixed order (deterministic).  Used when the launch
+ * covers its destinations completely and >= 2 slices of N*OH*OW*(DC0+DC1) floats fit. */
+int cu_conv_gemm_ws(const cu_conv_desc* d,
+                    const void* src0, const float* scale0, const float* shift0,
+                    const void* src1, const float* scale1, const float* shift1,
+                    const void* w, const float* bias, void* dst0, void* dst1, float* ws, size_t ws_floats, void* stream);
 
 /* Weight gradient of the same gather convolution:  dW[t][n][c] += sum_p Z[p*ZS + zoff_t, n] * act(S[p*IS + off_t, c])
  * (autograd of nn.Conv2d / nn.ConvTranspose2d weights).  dW is f32, accumulated with atomics. */

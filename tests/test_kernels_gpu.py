@@ -73,6 +73,8 @@ def make_act(x_nchw, dtype, with_norm, slope, gen):
     (4, 256, 0, 480, 4, 2),      # stride 2 on a tiny map (image count per tile is reduced)
     (2, 480, 480, 480, 8, 1),
     (64, 480, 0, 128, 2, 1),     # ConfidenceNet-like 2x2
+    (64, 480, 480, 480, 4, 1),   # bottom of the U at batch 64: split-K over the channel chunks (cu_conv_gemm_ws)
+    (64, 480, 0, 480, 2, 2),
 ])
 def test_conv_fwd(dtype, case):
     ops = _ops()
@@ -99,7 +101,8 @@ def test_conv_fwd(dtype, case):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(2, 64, 32, 64, 1), (2, 64, 128, 32, 2), (3, 960, 480, 4, 2), (2, 128, 256, 16, 1)])
+@pytest.mark.parametrize("case", [(2, 64, 32, 64, 1), (2, 64, 128, 32, 2), (3, 960, 480, 4, 2), (2, 128, 256, 16, 1),
+                                  (64, 960, 480, 4, 1), (64, 512, 480, 2, 1)])      # tiny maps at batch 64: split-K
 def test_conv_dgrad_wgrad(dtype, case):
     """input gradient (incl. concat split + accumulate) and weight gradient vs autograd of F.conv2d."""
     ops = _ops()
@@ -471,7 +474,9 @@ def test_conv_transpose_single_pass_matches_four_parity_launches(dtype):
         for dx in range(2):
             ops.conv_gemm([a], wf, None, grid=(size, size), in_stride=1, taps=[(0, 0, dy * 2 + dx)], dsts=[four],
                           dst_cols=[co], out_stride=2, out_off=(dy, dx))
-    assert torch.equal(one, four)
+    # same products, but the single pass may split its channel chunks over workgroups (cu_conv_gemm_ws): the f32 sums
+    # then differ in their last bits (and a bf16 result by one rounding step)
+    assert rel_err(one.float(), four.float()) < (1e-6 if dtype == torch.float32 else 2e-3)
     ref = F.conv_transpose2d(r, rq(w, dtype), stride=2)
     assert rel_err(nchw(one), ref) < tol(dtype)
 

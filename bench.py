@@ -248,7 +248,7 @@ def main():
                               "achieved": round(achieved, 2),
                               "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
                               "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": traffic,
-                              "traffic_source": "profiles/r01_pmc_hbm_traffic.json (HBM bytes per launch, PMC)" if traffic else None,
+                              "traffic_source": "profiles/r02_pmc_hbm_traffic.json (HBM bytes per launch, PMC)" if traffic else None,
                               "launches_per_step": cnt // 2, "avg_launch_ms": round(ms_k / cnt, 4),
                               "flops_per_launch": fl / cnt,
                               "family_ms_per_step": {k: round(v[1] / 2, 3) for k, v in fam.items()},

@@ -679,7 +679,11 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
     a.dbg = cu_env_int("CU_CONV_DBG", 0);
 
     const int CI_all = d->C0 + d->C1;
-    const bool wn = d->CO > 32, wc = CI_all > 32;
+    // 64-wide blocks of dW unless the loop grid is tiny (<= CU_WGRAD_SMALLPX pixels, tuning knob): then 32 x 32 blocks put
+    // four times as many workgroups on a launch whose k-loop is a few steps long
+    const long px_total = (long)d->N * d->PH * d->PW;
+    const bool tiny = d->dtype == CU_BF16 && px_total <= cu_env_int("CU_WGRAD_SMALLPX", 0);
+    const bool wn = d->CO > 32 && !tiny, wc = CI_all > 32 && !tiny;
     const int rows_b = d->dtype == CU_BF16 ? (wc ? 192 : 64) : (wc ? 64 : 32) * 4 + 16;
     const int rowz_b = d->dtype == CU_BF16 ? (wn ? 192 : 64) : (wn ? 64 : 32) * 4 + 16;
     const int kpix = d->dtype == CU_BF16 ? 16 : 2;

@@ -1,4 +1,4 @@
-"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into profiles/r01_pmc_hbm_traffic.json.
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into profiles/rNN_pmc_hbm_traffic.json.
 
     python tools/pmc_summary.py <fetch_dir> <write_dir> <steps incl. warm-up> <out.json>
 
@@ -11,7 +11,8 @@ import sys
 from collections import defaultdict
 from pathlib import Path
 
-FAMILIES = [("igemm_conv", "igemm_conv"), ("igemm_wgrad", "igemm_wgrad"), ("stats_", "instnorm_stats"),
+FAMILIES = [("igemm_conv", "igemm_conv"), ("pconv_kernel", "igemm_conv"), ("ksplit_finish", "igemm_conv"),
+            ("igemm_wgrad", "igemm_wgrad"), ("fwd_resident", "instnorm_apply"), ("stats_", "instnorm_stats"),
             ("apply_kernel", "instnorm_apply"), ("bwd_", "instnorm_bwd"), ("act_bwd", "instnorm_bwd"),
             ("weight_prep", "weight_prep"), ("grad_unprep", "weight_prep"), ("adam", "adam"), ("conv_c1", "conv_c1"),
             ("dsnt", "dsnt_head"), ("nll", "dsnt_head")]

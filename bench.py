@@ -237,12 +237,12 @@ def main():
         name, (fl, ms_k, cnt) = dom
         achieved = fl / (ms_k * 1e-3) / 1e12
         traffic = None
-        pmc = ROOT / "profiles" / "r01_pmc_hbm_traffic.json"     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this bench
+        pmc = ROOT / "profiles" / "r02_pmc_hbm_traffic.json"     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this bench
         if pmc.exists() and per_gpu == 64 and args.size == 256 and args.dtype == "bf16":
             famrec = json.loads(pmc.read_text())["families"].get(name)
             if famrec:
                 traffic = round(famrec["bytes_per_launch"])
-        symbols = {"igemm_conv": "igemm_conv_kernel<*> + igemm_conv_dma_kernel<*> (all instantiations)",
+        symbols = {"igemm_conv": "igemm_conv_kernel<*> + igemm_conv_dma_kernel<*> + pconv_kernel<*> (all instantiations; + ksplit_finish_kernel)",
                    "igemm_wgrad": "igemm_wgrad_kernel<*> + igemm_wgrad_dma_kernel<*> (all instantiations)"}
         result["roofline"] = {"bound": "mfma", "kernel": name, "kernel_symbols": symbols.get(name, name),
                               "achieved": round(achieved, 2),

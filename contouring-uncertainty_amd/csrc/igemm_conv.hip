@@ -782,6 +782,8 @@ __global__ __launch_bounds__(256) void ksplit_finish_kernel(const float* __restr
 }  // namespace
 
 int cu_pconv_try(const cu_conv_desc* d, const void* src0, const void* w, const float* bias, void* dst0, void* stream);
+int cu_tconv_try(const cu_conv_desc* d, const void* src0, const void* src1, const void* w, const float* bias, void* dst0,
+                 void* dst1, void* stream);
 
 extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float* scale0, const float* shift0,
                             const void* src1, const float* scale1, const float* shift1, const void* w, const float* bias,
@@ -838,6 +840,12 @@ extern "C" int cu_conv_gemm_ws(const cu_conv_desc* d, const void* src0, const fl
     // ---- few-tap / strided bf16 gathers of plain operands: the lean gather-GEMM (pconv.hip)
     if (bf && !scale0 && !scale1 && !cu_env_set("CU_CONV_NOPCONV")) {
         const int rc = cu_pconv_try(d, src0, w, bias, dst0, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
+
+    // ---- thin, large bf16 3x3 stride-1 layers (256^2 x 32, 128^2 x 64 channels): the streaming kernel (tconv.hip)
+    if (bf && !scale0 && !scale1 && !cu_env_set("CU_CONV_NOTCONV")) {
+        const int rc = cu_tconv_try(d, src0, src1, w, bias, dst0, dst1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
 

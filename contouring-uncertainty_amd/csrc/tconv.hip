@@ -1,0 +1,254 @@
+// Streaming 3x3 stride-1 convolution for the THIN, large layers (gfx950, bf16 production mode): 256^2 x 32 channels and
+// 128^2 x 64 channels of the U-Net's two top levels -- forward, concat forward, input gradient and the input gradient
+// with two destinations (reference models/nnUnet/layers.py:55-80,192-205,436; dispatched inside cu_conv_gemm).
+//
+// These layers are HBM-bound (32 -> 32 at 256^2, batch 64: 536 MB in + out = ~100 us at 5.4 TB/s against 31 us of
+// MFMA work), so the kernel is built as a stream, not as a GEMM:
+//   * persistent workgroups (one per CU, 8 waves); the whole weight set (<= 73 KiB) is staged ONCE and stays in LDS;
+//   * a ring of R halo tiles ((TH+2) x 34 pixels, all input channels) filled by LDS-DMA (buffer_load_dwordx4 ... lds) one or
+//     two tiles ahead: the copy of tile i+1 / i+2 flies under the MFMAs and the stores of tile i, and ONE barrier per
+//     tile both publishes tile i and frees the slot of tile i-1;
+//   * counted waits: loads, LDS-DMA and stores retire in issue order, so s_waitcnt vmcnt(N) with N = the (compile-time)
+//     number of younger operations waits for exactly the tile that is needed and never for the stores just issued
+//     (every iteration issues the same number of DMA instructions -- out-of-range ones when the tiles run out -- and of
+//     stores, which is why the kernel only takes whole tiles: PW % 32 == 0, PH % TH == 0);
+//   * LDS images are lane-linear [32-channel plane][row][64 bytes] (row = halo pixel / weight row); 16-byte piece p of
+//     row r sits in slot p ^ ((r >> 2) & 3) (applied on the DMA source address and on the read): conflict-free
+//     ds_read_b128 fragments, and every DMA instruction (16 rows of one plane) reads ONE source of a concat;
+//   * the MFMA takes the weights as A and the pixels as B: a lane owns one pixel and 16 consecutive channels after two
+//     v_permlane32_swap -> two 16-byte stores per 32-channel block; zero padding = the buffer range check.
+#include "common.h"
+
+namespace {
+
+struct TcArgs {
+    const void* src0; const void* src1; const void* w; const float* bias; void* dst0; void* dst1;
+    unsigned src0_bytes, src1_bytes, w_bytes;
+    int N, H, W, C0, C1;            // source = destination grid; channels of the two sources (C1 may be 0)
+    int tap_off[9];                 // halo row offset of gather tap t: (dy + 1) * 34 + (dx + 1)
+    int tap_w[9];                   // weight tap of gather tap t
+    int D0, DC0, DC1;               // columns [0, D0) -> dst0, the rest -> dst1; channel strides
+    int ntiles, tiles_x, tiles_y;   // tiles of TH x 32 pixels
+};
+
+__device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// CIP = input channels / 32, NB = output channels / 32, TH = tile rows, R = ring slots
+template <int CIP, int NB, int TH, int R>
+__global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
+    constexpr int CI = 32 * CIP, CO = 32 * NB;
+    constexpr int HW34 = 34, HALO = (TH + 2) * HW34, HPAD = (HALO + 15) / 16 * 16;     // plane stride: whole DMA instructions
+    constexpr int XPIECES = CIP * HPAD * 4, D = (XPIECES + 511) / 512, SLOT_B = D * 8192;
+    constexpr int WROWS = 9 * CO;                                                        // a multiple of 16
+    constexpr int WPIECES = CIP * WROWS * 4, WD = (WPIECES + 511) / 512, W_B = WD * 8192;
+    constexpr int NBW = NB * TH / 8;            // 32-column blocks per wave
+    constexpr int S = 2 * NBW;                  // 16-byte stores per thread and tile
+    static_assert(NBW >= 1 && W_B + R * SLOT_B <= 160 * 1024, "tconv: bad instance");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const unsigned w_base = lds_addr(smem), x_base = w_base + W_B;
+    const i32x4 rs0 = make_rsrc(p.src0, p.src0_bytes);
+    const i32x4 rs1 = make_rsrc(p.src1 ? p.src1 : p.src0, p.src1 ? p.src1_bytes : 0u);
+    const i32x4 rw = make_rsrc(p.w, p.w_bytes);
+    constexpr unsigned OOB = 0x7ffffff0u;
+
+    // ---- weights, once: LDS row (t * CO + n) of plane pl = channels [32 pl, 32 pl + 32) of weight row (tap_w[t], n);
+    //      static tap indices only (a runtime index into the by-value argument block would move it to scratch)
+#pragma unroll
+    for (int j = 0; j < WD; ++j) {
+        const int q = tid + j * 512;
+        const int pl = q / (WROWS * 4), qq = q - pl * (WROWS * 4);
+        const int row = qq >> 2, s = qq & 3;
+        const int t = row / CO, n = row - t * CO;
+        int tw = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) tw = t == k ? p.tap_w[k] : tw;
+        const int piece = s ^ swz(row);
+        const unsigned off = q < WPIECES ? (unsigned)(((tw * CO + n) * CI + pl * 32 + piece * 8) * 2) : OOB;
+        dma16(rw, off, w_base + (unsigned)(j * 8192 + wave * 1024));
+    }
+
+    // ---- per-thread halo staging geometry (tile-invariant): plane, halo pixel, piece.  A DMA instruction covers 16 rows
+    //      of ONE plane (HPAD is a multiple of 16), so its source is wave-uniform
+    int hy[D], hx[D];
+    unsigned coff[D];               // byte offset of the piece inside its source pixel; ~0u: padding row / no item
+    const bool cat = p.C1 > 0;      // plane 1 = source 1 (C0 = C1 = 32)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const int q = tid + j * 512;
+        const int pl = q / (HPAD * 4), qq = q - pl * (HPAD * 4);
+        const int hp = qq >> 2, s = qq & 3;
+        hy[j] = hp / HW34; hx[j] = hp - hy[j] * HW34;
+        const int c = (cat ? 0 : pl * 32) + (s ^ swz(hp)) * 8;
+        coff[j] = (q < XPIECES && hp < HALO) ? (unsigned)(c * 2) : 0xffffffffu;
+    }
+    const unsigned pix0_b = (unsigned)p.C0 * 2u, pix1_b = (unsigned)p.C1 * 2u;
+
+    // XCD-aware tile order (workgroups are dealt round-robin to the 8 XCDs): logical tile L -> (L % 8) * ntiles/8 + L / 8,
+    // so one XCD's L2 sees a contiguous eighth of the tiles and the halo rows shared by vertical neighbours are L2 hits
+    const bool xcd = (p.ntiles & 7) == 0 && (gridDim.x & 7) == 0;
+    auto tile_of = [&](int l) { return xcd ? (l & 7) * (p.ntiles >> 3) + (l >> 3) : l; };
+    auto issue = [&](int l, int slot) {          // DMA of logical tile l (or D out-of-range instructions) into ring slot
+        const bool live = l < p.ntiles;
+        const int tile = live ? tile_of(l) : 0;
+        const int tx = tile % p.tiles_x, rest = tile / p.tiles_x;
+        const int ty = rest % p.tiles_y, n = rest / p.tiles_y;
+        const int y0 = ty * TH - 1, x0 = tx * 32 - 1;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int sy = y0 + hy[j], sx = x0 + hx[j];
+            const bool ok = live && coff[j] != 0xffffffffu && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+            // plane of this instruction (wave-uniform, made scalar so that exactly ONE DMA instruction is issued)
+            const bool s1 = cat && __builtin_amdgcn_readfirstlane((tid + j * 512) / (HPAD * 4)) != 0;
+            const unsigned pix = (unsigned)((n * p.H + sy) * p.W + sx);
+            const unsigned off = ok ? pix * (s1 ? pix1_b : pix0_b) + coff[j] : OOB;
+            const unsigned dst = x_base + (unsigned)(slot * SLOT_B + j * 8192 + wave * 1024);
+            if (s1) dma16(rs1, off, dst);
+            else dma16(rs0, off, dst);
+        }
+    };
+
+    // ---- this wave's output: row `row` of the tile, column blocks b0 .. b0 + NBW - 1
+    const int row = wave % TH, b0 = (wave / TH) * NBW;
+    const int hp0 = row * HW34 + r;              // + tap_off[t] = the pixel's halo row for tap t
+    f32x4 bv[NBW][4];
+#pragma unroll
+    for (int b = 0; b < NBW; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            bv[b][g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + (b0 + b) * 32 + 8 * g + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weights + bias have landed (before any counted wait below)
+
+    const bf16_t* W16 = reinterpret_cast<const bf16_t*>(smem);
+    int l = blockIdx.x;
+    issue(l, 0);
+    if (R == 3) issue(l + gridDim.x, 1);
+    for (int it = 0; l < p.ntiles; ++it, l += gridDim.x) {
+        // DMA(it) must have landed; younger operations, in issue order: [R == 3: stores(it-2), DMA(it+1)], stores(it-1)
+        if (R == 3) {
+            if (it == 0) wait_vm<D>();
+            else if (it == 1) wait_vm<D + S>();
+            else wait_vm<D + 2 * S>();
+        } else {
+            if (it == 0) wait_vm<0>();
+            else wait_vm<S>();
+        }
+        __syncthreads();        // tile `it` is complete for every wave, and nobody reads the slot of tile it-1 any more
+        issue(l + (R - 1) * gridDim.x, (it + R - 1) % R);
+        const bf16_t* X16 = reinterpret_cast<const bf16_t*>(smem + W_B + (it % R) * SLOT_B);
+
+        f32x16 acc[NBW];
+#pragma unroll
+        for (int b = 0; b < NBW; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int xr = hp0 + p.tap_off[t];
+            const int xs = swz(xr);
+#pragma unroll
+            for (int kk = 0; kk < CI / 16; ++kk) {
+                const int pl = kk >> 1, pc = 2 * (kk & 1) + h;
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(X16 + ((size_t)(pl * HPAD + xr) * 4 + (pc ^ xs)) * 8);
+#pragma unroll
+                for (int b = 0; b < NBW; ++b) {
+                    const int wr = t * CO + (b0 + b) * 32 + r;
+                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(W16 + ((size_t)(pl * WROWS + wr) * 4 + (pc ^ swz(wr))) * 8);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af, acc[b], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue: register i of a block = channel (i & 3) + 8 * (i >> 2) + 4 * h of pixel r
+        const int tile = tile_of(l);
+        const int tx = tile % p.tiles_x, rest = tile / p.tiles_x;
+        const int ty = rest % p.tiles_y, n = rest / p.tiles_y;
+        const size_t opix = ((size_t)n * p.H + ty * TH + row) * p.W + tx * 32 + r;
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) {
+            const int colb = (b0 + b) * 32;
+            const bool d1 = colb >= p.D0;
+            unsigned q[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[b][4 * g + e] + bv[b][g][e];
+                q[g][0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                q[g][1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            }
+#pragma unroll
+            for (int w2 = 0; w2 < 2; ++w2) {
+                auto r02 = __builtin_amdgcn_permlane32_swap(q[0][w2], q[2][w2], false, false);
+                q[0][w2] = r02[0]; q[2][w2] = r02[1];
+                auto r13 = __builtin_amdgcn_permlane32_swap(q[1][w2], q[3][w2], false, false);
+                q[1][w2] = r13[0]; q[3][w2] = r13[1];
+            }
+            bf16_t* o = reinterpret_cast<bf16_t*>(d1 ? p.dst1 : p.dst0) + opix * (d1 ? p.DC1 : p.DC0) +
+                        (d1 ? colb - p.D0 : colb) + 16 * h;
+            *reinterpret_cast<u32x4*>(o) = u32x4{q[0][0], q[0][1], q[2][0], q[2][1]};
+            *reinterpret_cast<u32x4*>(o + 8) = u32x4{q[1][0], q[1][1], q[3][0], q[3][1]};
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing out-of-range DMA instructions target live LDS
+}
+
+template <int CIP, int NB, int TH, int R>
+int launch_tc(const TcArgs& a, hipStream_t st) {
+    constexpr int HPAD = ((TH + 2) * 34 + 15) / 16 * 16;
+    constexpr int D = (CIP * HPAD * 4 + 511) / 512, WD = (CIP * 9 * 32 * NB * 4 + 511) / 512;
+    const size_t lds = (size_t)WD * 8192 + (size_t)R * D * 8192;
+    auto k = tconv_kernel<CIP, NB, TH, R>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    CU_CHECK_ARG(e == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;       // workgroups that fit a CU (LDS; <= 128 VGPRs in every instance)
+    int grid = a.ntiles < 256 * per_cu ? a.ntiles : 256 * per_cu;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
+    CU_LAUNCH_CHECK();
+    return 1;
+}
+
+}  // namespace
+
+// 1 = launched, 0 = not this kernel's shape, < 0 = error.  Called by cu_conv_gemm for plain bf16 operands.
+int cu_tconv_try(const cu_conv_desc* d, const void* src0, const void* src1, const void* w, const float* bias, void* dst0,
+                 void* dst1, void* stream) {
+    if (d->dtype != CU_BF16 || d->ntaps != 9 || d->IS != 1 || d->OS != 1 || d->OY0 || d->OX0 || d->out_nchw_f32 ||
+        d->par_co || d->accum0 || d->accum1 || d->slope0 != 1.0f || (d->C1 && d->slope1 != 1.0f))
+        return 0;
+    if (d->PH != d->SH || d->PW != d->SW || d->OH != d->PH || d->OW != d->PW || d->PW % 32 || d->PH % 8) return 0;
+    const int CI = d->C0 + d->C1;
+    if (!((CI == 32 && d->C1 == 0) || (CI == 64 && (d->C1 == 0 || d->C0 == 32)))) return 0;
+    if (d->CO != 32 && d->CO != 64) return 0;
+    const bool two = d->D0 != d->CO;
+    if (two ? !(d->D0 == 32 && d->DC0 == 32 && d->DC1 == d->CO - 32 && dst1) : d->DC0 != d->CO) return 0;
+    if (CI == 64 && d->CO == 64 && d->C1) return 0;                     // 128-byte rows x 64 columns: no concat instance
+    if ((long)d->N * d->PH * d->PW < (1L << 20)) return 0;             // the large maps only (256^2, 128^2 at batch >= 16 / 64)
+    const size_t b0 = (size_t)d->N * d->SH * d->SW * d->C0 * 2, b1 = (size_t)d->N * d->SH * d->SW * d->C1 * 2;
+    if (b0 >= 0x7fff0000ull || b1 >= 0x7fff0000ull) return 0;
+    TcArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src0 = src0; a.src1 = d->C1 ? src1 : nullptr; a.w = w; a.bias = bias; a.dst0 = dst0; a.dst1 = dst1;
+    a.src0_bytes = (unsigned)b0; a.src1_bytes = (unsigned)b1; a.w_bytes = (unsigned)((size_t)9 * d->CO * CI * 2);
+    a.N = d->N; a.H = d->PH; a.W = d->PW; a.C0 = d->C0; a.C1 = d->C1;
+    a.D0 = d->D0; a.DC0 = d->DC0; a.DC1 = d->DC1;
+    for (int t = 0; t < 9; ++t) {
+        if (d->tap_dy[t] < -1 || d->tap_dy[t] > 1 || d->tap_dx[t] < -1 || d->tap_dx[t] > 1 || d->tap_w[t] < 0 || d->tap_w[t] > 8)
+            return 0;
+        a.tap_off[t] = (d->tap_dy[t] + 1) * 34 + (d->tap_dx[t] + 1);
+        a.tap_w[t] = d->tap_w[t];
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int th = (CI == 64 && d->CO == 64) ? 4 : 8;
+    a.tiles_x = d->PW / 32; a.tiles_y = d->PH / th; a.ntiles = a.tiles_x * a.tiles_y * d->N;
+    // Measured at 256^2 x 32, batch 64 (tools/thin_bench.py, profiles/r02_thin_bench.txt): two ring slots and two workgroups
+    // per CU beat three slots and one workgroup (32 -> 32: 129 vs 143 us forward, 130 vs 162 us input gradient); for the
+    // two-destination input gradient the 4-row tile that would fit two workgroups loses to 8 rows x 3 slots (248 vs 237)
+    const int var = cu_env_int("CU_TCONV_VAR", 1);      // tuning knob: 0 = three slots, one workgroup per CU
+    if (CI == 32 && d->CO == 32) return var == 1 ? launch_tc<1, 1, 8, 2>(a, st) : launch_tc<1, 1, 8, 3>(a, st);
+    if (CI == 32 && d->CO == 64) return launch_tc<1, 2, 8, 3>(a, st);
+    if (CI == 64 && d->CO == 32) return launch_tc<2, 1, 8, 2>(a, st);
+    return launch_tc<2, 2, 4, 2>(a, st);
+}

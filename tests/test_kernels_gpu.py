@@ -612,3 +612,48 @@ def test_lean_gather_gemm_shapes(case):
                       dsts=[d0], dst_cols=[cx], out_stride=2, accum=[accum], n_cols=4 * cx, parity_cols=cx,
                       parity_taps=S2_PARITY_TAPS)
         assert rel_err(nchw(d0), xin.grad + (base if accum else 0)) < tol(dtype)
+
+
+@pytest.mark.parametrize("case", [(16, 32, 0, 32, 256), (16, 32, 32, 32, 256), (64, 64, 0, 64, 128), (64, 64, 0, 32, 128),
+                                  (20, 32, 0, 32, 256)])
+def test_thin_streaming_conv(case):
+    """The streaming kernel of the thin, large layers (tconv.hip; bf16, >= 2^20 loop pixels): forward (+ bias), concat
+    forward, and the input gradient into one and into two destinations -- vs F.conv2d and its autograd.  20 images x 8192
+    tiles is not a multiple of 8 workgroup strides: ragged tail of the persistent loop (out-of-range DMA instructions)."""
+    ops = _ops()
+    from cu_hip.engine import TAPS3, TAPS3_D
+    n, c0, c1, co, size = case
+    dtype = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(31)
+    srcs, refs = [], []
+    for c in (c0, c1):
+        if c:
+            a, r = make_act(torch.randn(n, c, size, size, device=DEV, generator=g), dtype, False, 1.0, g)
+            srcs.append(a)
+            refs.append(r)
+    ci = c0 + c1
+    w = torch.randn(co, ci, 3, 3, device=DEV, generator=g) / math.sqrt(9 * ci)
+    b = torch.randn(co, device=DEV, generator=g) * 0.1
+    wf, wd = ops.weight_prep(w, "conv", dtype)
+    wq = rq(w, dtype)
+    z = torch.empty(n, size, size, co, device=DEV, dtype=dtype)
+    ops.conv_gemm(srcs, wf, b, grid=(size, size), in_stride=1, taps=TAPS3, dsts=[z], dst_cols=[co])
+    ref = F.conv2d(torch.cat(refs, 1), wq, b, padding=1)
+    assert rel_err(nchw(z), ref) < tol(dtype)
+    # borders: the zero padding comes from the buffer range check
+    assert rel_err(nchw(z)[:, :, [0, -1]], ref[:, :, [0, -1]]) < tol(dtype)
+    assert rel_err(nchw(z)[:, :, :, [0, -1]], ref[:, :, :, [0, -1]]) < tol(dtype)
+    del ref
+    # ---- input gradient: dz (n, co) -> dx (n, ci), into one destination and split into two
+    dz = rq(torch.randn(n, co, size, size, device=DEV, generator=g), dtype)
+    gx = F.conv_transpose2d(dz, wq, None, padding=1)
+    gz = ops.Act(nhwc(dz, dtype), None, 1.0)
+    if ci in (32, 64) and co in (32, 64):
+        d0 = torch.empty(n, size, size, ci, device=DEV, dtype=dtype)
+        ops.conv_gemm([gz], wd, None, grid=(size, size), in_stride=1, taps=TAPS3_D, dsts=[d0], dst_cols=[ci])
+        assert rel_err(nchw(d0), gx) < tol(dtype)
+    if ci == 64 and co == 32:
+        da = torch.empty(n, size, size, 32, device=DEV, dtype=dtype)
+        db = torch.empty(n, size, size, 32, device=DEV, dtype=dtype)
+        ops.conv_gemm([gz], wd, None, grid=(size, size), in_stride=1, taps=TAPS3_D, dsts=[da, db], dst_cols=[32, 32])
+        assert rel_err(nchw(da), gx[:, :32]) < tol(dtype) and rel_err(nchw(db), gx[:, 32:]) < tol(dtype)

@@ -96,10 +96,10 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch images per GPU; strong: --batch images in total, split over the GPUs")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="replay the step as one hipGraph (cu_hip.graph.CapturedStep); auto = on for a single GPU with "
-                         "fewer than 16 images per GPU, where the eager step is bound by its ~500 host launches (from 16 "
-                         "images on the eager step is faster: its weight-gradient stream runs beside the main one, which "
-                         "a replayed graph serialises -- profiles/r02_small_batch_graph.txt)")
+                    help="replay the step as one hipGraph (cu_hip.graph.CapturedStep); auto = on for a single GPU with at "
+                         "most 16 images per GPU, where the eager step is bound by its ~320 host launches (from 32 images "
+                         "on the eager step is faster: its weight-gradient stream runs beside the main one, which a "
+                         "replayed graph serialises -- profiles/r02_small_batch_graph.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -136,7 +136,7 @@ def main():
         per_gpu = args.batch // world
     else:
         per_gpu = args.batch
-    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and per_gpu < 16)
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and per_gpu <= 16)
     if use_graph:
         task.hparams.optim = dict(task.hparams.optim, capturable=True)
     opt = task.configure_optimizers()["optimizer"]

@@ -312,7 +312,7 @@ class UNetEngine:
             return contextlib.nullcontext()
         dev = reads[0].device
         if self._side is None or self._side.device != dev:
-            self._side = torch.cuda.Stream(dev)
+            self._side = torch.cuda.Stream(dev)     # (a higher / lower stream priority changed nothing: 15.4-15.6 ms)
         self._side.wait_stream(torch.cuda.current_stream(dev))
         self._side_keep.extend(reads)
         return torch.cuda.stream(self._side)

@@ -92,8 +92,10 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module: "UNet", slot, x: Tensor, *params: Tensor):
         P = dict(zip(module._pnames, params))
-        logits, feats, ectx = module.engine.forward(P, x, module.bottleneck_out, module.training or module.mc_dropout)
-        ctx.module, ctx.ectx, ctx.slot = module, ectx, slot
+        need = any(ctx.needs_input_grad)
+        logits, feats, ectx = module.engine.forward(P, x, module.bottleneck_out, module.training or module.mc_dropout,
+                                                    keep=need)
+        ctx.module, ctx.ectx, ctx.slot = module, (ectx if need else None), slot
         ctx.save_for_backward(*params)
         if module.bottleneck_out:
             return logits, feats

@@ -74,6 +74,7 @@ class _UpRec:
 class UNetCtx:
     img: Tensor
     training: bool = False
+    keep: bool = True            # False = nothing will be back-propagated: layers keep only their activated output
     convs: Dict[str, _ConvRec] = field(default_factory=dict)
     ups: List[_UpRec] = field(default_factory=list)
     enc: List[Act] = field(default_factory=list)
@@ -204,6 +205,8 @@ class UNetEngine:
                 mask = keep.float() / (1.0 - self.drop_p)
             ops.channel_scale(z, mask)
         out = self._norm_act_fwd(P, prefix, z)
+        if not ctx.keep and out.a is not None:
+            return Act(out.a, None, 1.0)      # inference: z, the statistics and the layer record die here
         ctx.convs[prefix] = _ConvRec(prefix, srcs, out, stride, drop_mask=mask)
         return out
 
@@ -230,6 +233,8 @@ class UNetEngine:
         z = torch.empty((n, h, w_, co), dtype=self.dtype, device=img.device)
         ops.conv_c1_fwd(img, w9, P[f"{prefix}.conv.bias"], z)
         out = self._norm_act_fwd(P, prefix, z)
+        if not ctx.keep and out.a is not None:
+            return Act(out.a, None, 1.0)
         ctx.convs[prefix] = _ConvRec(prefix, [], out, 1, first=True)
         return out
 
@@ -247,15 +252,19 @@ class UNetEngine:
         ops.conv_gemm([src], wf.view(1, 4 * co, wf.shape[2]), None, grid=(h, w_), in_stride=1, taps=[(0, 0, 0)], dsts=[u],
                       dst_cols=[co], out_stride=2, n_cols=4 * co, parity_cols=co)
         out = Act(u, None, 1.0)
-        ctx.ups.append(_UpRec(prefix, src, out))
+        if ctx.keep:
+            ctx.ups.append(_UpRec(prefix, src, out))
         return out
 
     # ------------------------------------------------------------------------------------------ forward
-    def forward(self, P: Dict[str, Tensor], img: Tensor, want_bottleneck: bool, training: bool = False):
-        """P: parameter name -> float32 device tensor (reference names).  img: (N, 1, H, W) float32."""
+    def forward(self, P: Dict[str, Tensor], img: Tensor, want_bottleneck: bool, training: bool = False,
+                keep: bool = True):
+        """P: parameter name -> float32 device tensor (reference names).  img: (N, 1, H, W) float32.
+        keep=False (no gradient will be asked for): every layer drops its raw output and statistics as soon as its
+        activated output exists, so predict-time peak memory is the encoder skips + one block, not a training step's."""
         assert img.dtype == torch.float32 and img.is_cuda and img.shape[1] == 1
         img = img.contiguous()
-        ctx = UNetCtx(img=img, training=training)
+        ctx = UNetCtx(img=img, training=training, keep=keep or self.debug is not None)
         if self.debug is not None:
             self._last_ctx = ctx
         st = self.strides

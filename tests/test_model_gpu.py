@@ -436,3 +436,25 @@ def test_predict_step_device_masks_and_entropy(golden_dir, kind):
     # single-contour call keeps the reference signature and agrees with the batch
     one = USContourToMask()(cs[0, 0, 0], (size, size), None, apply_argmax=False)
     assert one.shape == (1, size, size) and (one[0] == res.pred_samples[0, 0, 0]).all()
+
+
+def test_inference_forward_drops_layer_records():
+    """Under no_grad every layer keeps only its activated output: same logits, and the peak memory of the
+    forward is well below that of a forward that has to keep z + statistics + activations of every layer."""
+    t = make_task("dsnt-al", 6, 128, "bf16").to(DEV).eval()
+    x = torch.rand(16, 1, 128, 128, device=DEV)
+    peaks, outs = [], []
+    for grad in (True, False):
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        with torch.set_grad_enabled(grad):
+            y = t.model(x)
+        torch.cuda.synchronize()
+        peaks.append(torch.cuda.max_memory_allocated() - base)
+        outs.append(y.detach().float().clone())
+        assert (y.grad_fn is not None) == grad
+        del y
+    assert torch.equal(outs[0], outs[1])
+    assert peaks[1] < 0.6 * peaks[0], peaks

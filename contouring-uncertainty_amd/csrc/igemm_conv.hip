@@ -16,6 +16,7 @@
 //   - the next chunk's global loads are issued before the current chunk's MFMAs (register prefetch);
 //   - bf16: v_mfma_f32_32x32x16_bf16; f32 (parity mode): v_mfma_f32_32x32x2_f32 (exact f32 FMA chain).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -736,6 +737,235 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same tile (512 pixels x 128 columns, 8 waves, 3x3 stride-1 taps) with the staging of chunk c+1 in flight under the
+// MFMAs of chunk c (tools/dma_abl.py: the kernel above spends 14 of 71 us on 32^2 x 256 waiting for its
+// per-chunk LDS-DMA because no second 111-KiB image fits).  What does fit in 160 KiB: TWO halo images (<= 40 KiB each)
+// and a ring of THREE weight slots of one tap row (3 taps x 128 columns x 64 B = 24 KiB).  An iteration = (chunk, tap
+// row g): wait for its stage with a counted vmcnt, ONE barrier (publishes the stage, frees slot (g+2) % 3), issue the
+// weights of the iteration after next plus a third of the next chunk's halo image -- always six DMA instructions per
+// thread, out-of-range ones (into an 8-KiB dump area) where there is nothing to fetch, so the wait count is a constant.
+__global__ __launch_bounds__(64 * DW) void igemm_conv_dma_ring_kernel(const ConvKArgs p, unsigned src0_bytes,
+                                                                     unsigned src1_bytes, unsigned w_bytes) {
+    constexpr int MA = 2, NB = 4, BN = 128, CK = 32, NXR = 5;      // halo image = 5 staging rounds of 128 rows
+    constexpr unsigned XB = NXR * 8192, WSLOT = 3 * 8192;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int TW = 1 << p.twl, TH = 1 << p.thl;
+    const int n0 = blockIdx.y * BN;
+    const int CI = p.C0 + p.C1;
+    const int hpi = p.HH * p.HW;
+    const unsigned x_base = lds_addr(smem), w_base = x_base + 2 * XB, dump = w_base + 3 * WSLOT;
+    const i32x4 rs0 = make_rsrc(p.src0, src0_bytes);
+    const i32x4 rs1 = make_rsrc(p.src1 ? p.src1 : p.src0, p.src1 ? src1_bytes : 0u);
+    const i32x4 rw = make_rsrc(p.w, w_bytes);
+    constexpr unsigned OOB = 0x7ffffff0u;
+
+    const int tile = blockIdx.x;
+    const int tile_x = tile & ((1 << p.txl) - 1), tile_y = (tile >> p.txl) & ((1 << p.tyl) - 1);
+    const int img0 = (tile >> (p.txl + p.tyl)) << p.iml;
+    const int py0 = tile_y << p.thl, px0 = tile_x << p.twl;
+
+    const int slot = tid & 3;
+    unsigned xoff[NXR];
+    int xpiece[NXR];
+#pragma unroll
+    for (int j = 0; j < NXR; ++j) {
+        const int hp = (tid >> 2) + 128 * j;
+        const int im = hp / hpi, rem = hp - im * hpi;
+        const int hy = rem / p.HW, hx = rem - hy * p.HW;
+        const int n = img0 + im, sy = py0 + p.dymin + hy, sx = px0 + p.dxmin + hx;
+        const bool ok = hp < p.imgs * hpi && n < p.N && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;
+        xoff[j] = ok ? (unsigned)((n * p.SH + sy) * p.SW + sx) : 0xffffffffu;
+        xpiece[j] = slot ^ ((hp >> 2) & 3);
+    }
+    const int wcol = tid >> 2;                          // 128 weight rows (= columns) per staging round, one tap per round
+    const bool wok = n0 + wcol < p.CO;
+    const int wpiece = slot ^ ((wcol >> 2) & 3);
+
+    int hpA[MA], ptx[MA], pty[MA], pim[MA];
+#pragma unroll
+    for (int a = 0; a < MA; ++a) {
+        const int m = wave * 32 * MA + a * 32 + r;
+        ptx[a] = m & (TW - 1); pty[a] = (m >> p.twl) & (TH - 1); pim[a] = m >> (p.twl + p.thl);
+        hpA[a] = pim[a] < p.imgs ? pim[a] * hpi + pty[a] * p.HW + ptx[a] : 0;
+    }
+    const int wsw = (r >> 2) & 3;
+
+    f32x16 acc[MA][NB];
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    const int nch = CI / CK;
+    // rounds [j0, j1) of chunk c's halo image into image c & 1; rounds beyond the image / chunks beyond the last go,
+    // out of range, to the dump area: the instruction count stays the same
+    auto issue_x = [&](int c, int j0, int j1) {
+        const bool live = c < nch;
+        const int c0 = live ? c * CK : 0;
+        const bool s1 = c0 >= p.C0;
+        const unsigned Cs = (unsigned)(s1 ? p.C1 : p.C0);
+        const unsigned cc = (unsigned)(s1 ? c0 - p.C0 : c0);
+#pragma unroll
+        for (int j = 0; j < NXR; ++j) {
+            if (j >= j0 && j < j1) {
+                const unsigned off = (!live || xoff[j] == 0xffffffffu) ? OOB : (xoff[j] * Cs + cc + (unsigned)xpiece[j] * 8u) * 2u;
+                const unsigned dst = x_base + (unsigned)((c & 1) * XB + j * 8192 + wave * 1024);
+                if (s1) dma16(rs1, off, dst);
+                else dma16(rs0, off, dst);
+            }
+        }
+    };
+    auto issue_dump = [&](int n) {
+        for (int j = 0; j < n; ++j) dma16(rw, OOB, dump + (unsigned)(wave * 1024));
+    };
+    // the three taps of tap row G (static) of chunk c into weight slot G
+    auto issue_w = [&](int c, auto G) {
+        constexpr int g = decltype(G)::value;
+        const bool live = c < nch;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int tw = p.tap_w[3 * g + j];
+            const unsigned off = (live && wok) ? (unsigned)(((tw * p.CO + n0 + wcol) * CI + c * CK + wpiece * 8)) * 2u : OOB;
+            dma16(rw, off, w_base + (unsigned)(g * WSLOT + j * 8192 + wave * 1024));
+        }
+    };
+    auto compute = [&](int c, auto G) {
+        constexpr int g = decltype(G)::value;
+        const bf16_t* X16 = reinterpret_cast<const bf16_t*>(smem + (size_t)(c & 1) * XB);
+        const bf16_t* W16 = reinterpret_cast<const bf16_t*>(smem + 2 * (size_t)XB + (size_t)g * WSLOT);
+#pragma unroll
+        for (int tl = 0; tl < 3; ++tl) {
+            int xrow[MA], xsw[MA];
+#pragma unroll
+            for (int a = 0; a < MA; ++a) {
+                xrow[a] = hpA[a] + p.tap_off[3 * g + tl];
+                xsw[a] = (xrow[a] >> 2) & 3;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[MA], bfr[NB];
+#pragma unroll
+                for (int a = 0; a < MA; ++a)
+                    af[a] = *reinterpret_cast<const bf16x8*>(X16 + ((size_t)xrow[a] * 4 + ((2 * kk + h) ^ xsw[a])) * 8);
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    bfr[b] = *reinterpret_cast<const bf16x8*>(
+                        W16 + ((size_t)(tl * BN + b * 32 + r) * 4 + ((2 * kk + h) ^ wsw)) * 8);
+#pragma unroll
+                for (int a = 0; a < MA; ++a)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
+            }
+        }
+    };
+    using G0 = std::integral_constant<int, 0>;
+    using G1 = std::integral_constant<int, 1>;
+    using G2 = std::integral_constant<int, 2>;
+
+    // prologue: X(0), W(0, 0), W(0, 1)
+    issue_x(0, 0, NXR);
+    issue_w(0, G0{});
+    issue_w(0, G1{});
+    for (int c = 0; c < nch; ++c) {
+        // ---- tap row 0: needs X(c) and W(c, 0); younger: W(c, 1) [first chunk] / the 6 instructions of the iteration before
+        if (c == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __syncthreads();
+        issue_w(c, G2{});
+        issue_x(c + 1, 0, 3);
+        compute(c, G0{});
+        // ---- tap row 1
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __syncthreads();
+        issue_w(c + 1, G0{});
+        issue_x(c + 1, 3, NXR);
+        issue_dump(3 - (NXR - 3));
+        compute(c, G1{});
+        // ---- tap row 2
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __syncthreads();
+        issue_w(c + 1, G1{});
+        issue_dump(3);
+        compute(c, G2{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing out-of-range DMA instructions target this LDS
+
+    // ---- epilogue (as igemm_conv_dma_kernel)
+#pragma unroll
+    for (int a = 0; a < MA; ++a) {
+        const int n = img0 + pim[a];
+        const int py = py0 + pty[a], px = px0 + ptx[a];
+        const bool pvalid = !(pim[a] >= p.imgs || n >= p.N || py >= p.PH || px >= p.PW);
+        const size_t opix = pvalid ? ((size_t)n * p.OH + py) * p.OW + px : 0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int colb = n0 + b * 32;
+            if (colb >= p.CO) continue;                       // uniform
+            const bool d1 = colb >= p.D0;
+            const int accum = d1 ? p.accum1 : p.accum0;
+            const int DC = d1 ? p.DC1 : p.DC0;
+            bf16_t* dstp = reinterpret_cast<bf16_t*>(d1 ? p.dst1 : p.dst0);
+            if (!accum) {
+                unsigned q[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e];
+                    if (p.bias) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + colb + 8 * g + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                    }
+                    q[g][0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    q[g][1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                }
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2) {
+                    auto r02 = __builtin_amdgcn_permlane32_swap(q[0][w2], q[2][w2], false, false);
+                    q[0][w2] = r02[0]; q[2][w2] = r02[1];
+                    auto r13 = __builtin_amdgcn_permlane32_swap(q[1][w2], q[3][w2], false, false);
+                    q[1][w2] = r13[0]; q[3][w2] = r13[1];
+                }
+                if (pvalid) {
+                    const int dcol = (d1 ? colb - p.D0 : colb) + 16 * h;
+                    bf16_t* o = dstp + opix * DC + dcol;
+                    *reinterpret_cast<u32x4*>(o) = u32x4{q[0][0], q[0][1], q[2][0], q[2][1]};
+                    *reinterpret_cast<u32x4*>(o + 8) = u32x4{q[1][0], q[1][1], q[3][0], q[3][1]};
+                }
+                continue;
+            }
+            if (!pvalid) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = colb + 8 * g + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e];
+                if (p.bias) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                }
+                bf16_t* o = dstp + opix * DC + (d1 ? col - p.D0 : col);
+                const u32x2 old = *reinterpret_cast<const u32x2*>(o);
+                v[0] += __uint_as_float(old[0] << 16); v[1] += __uint_as_float(old[0] & 0xffff0000u);
+                v[2] += __uint_as_float(old[1] << 16); v[3] += __uint_as_float(old[1] & 0xffff0000u);
+                u32x2 pk;
+                pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                *reinterpret_cast<u32x2*>(o) = pk;
+            }
+        }
+    }
+}
+
 template <typename T, int MA, int NB, int NX, int NT, bool WRES, bool PLAIN>
 int launch(const ConvKArgs& a, size_t lds, int grid_x, int grid_y, hipStream_t st) {
     auto k = igemm_conv_kernel<T, MA, NB, NX, NT, WRES, PLAIN>;
@@ -895,6 +1125,17 @@ extern "C" int cu_conv_gemm_ws(const cu_conv_desc* d, const void* src0, const fl
                     a.tap_off[t] = (d->tap_dy[t] - dymin) * a.HW + (d->tap_dx[t] - dxmin);
                     a.tap_w[t] = d->tap_w[t];
                     CU_CHECK_ARG(d->tap_w[t] >= 0, "cu_conv_gemm: negative weight tap index");
+                }
+                if (d->IS == 1 && dnb == 4 && halo_pad == 640 && !cu_env_set("CU_CONV_NORING")) {
+                    const size_t rl = 2 * 5 * 8192 + 3 * 3 * 8192 + 8192;          // two halo images, three tap rows, dump
+                    auto kr = igemm_conv_dma_ring_kernel;
+                    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kr),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);
+                    CU_CHECK_ARG(er == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(er));
+                    hipLaunchKernelGGL(kr, dim3(a.ntiles, cdiv(d->CO, 128)), dim3(64 * DW), rl,
+                                       reinterpret_cast<hipStream_t>(stream), a, (unsigned)b0, (unsigned)b1, (unsigned)bw);
+                    CU_LAUNCH_CHECK();
+                    return 0;
                 }
                 auto k = d->IS == 2 ? igemm_conv_dma_kernel<9, 4, 1>
                                     : (dnb == 4 ? igemm_conv_dma_kernel<9, 4, 2>

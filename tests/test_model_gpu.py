@@ -443,6 +443,8 @@ def test_inference_forward_drops_layer_records():
     forward is well below that of a forward that has to keep z + statistics + activations of every layer."""
     t = make_task("dsnt-al", 6, 128, "bf16").to(DEV).eval()
     x = torch.rand(16, 1, 128, 128, device=DEV)
+    with torch.no_grad():
+        t.model(x)                      # the persistent buffers (operand copies, scratch) exist before anything is measured
     peaks, outs = [], []
     for grad in (True, False):
         torch.cuda.synchronize()

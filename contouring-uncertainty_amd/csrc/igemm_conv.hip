@@ -1096,7 +1096,7 @@ extern "C" int cu_conv_gemm_ws(const cu_conv_desc* d, const void* src0, const fl
         // concat forward 313 -> 227 us, 256^2 x 32+32 -> 32 322 -> 286 us; with 32 input channels the one-tile-per-workgroup
         // structure loses to the persistent register-staged kernel, 173 vs 150 us)
         const int min_ci = d->IS == 1 ? cu_env_int("CU_CONV_DMA_MINC", 64) : 64;
-        if (bf && plain0 && (d->IS == 1 || (d->IS == 2 && d->CO % 128 == 0)) && d->ntaps == 9 &&
+        if (bf && plain0 && (d->IS == 1 || (d->IS == 2 && (d->CO % 128 == 0 || (d->CO > 256 && !cu_env_set("CU_CONV_S2_RAGGED_OFF"))))) && d->ntaps == 9 &&
             !d->out_nchw_f32 && d->CO >= (d->IS == 1 ? 32 : 128) && CI >= min_ci && d->C0 % 32 == 0 &&
             d->D0 % 32 == 0 && d->CO % 16 == 0 && !d->par_co && b0 < lim && b1 < lim && bw < lim &&
             (px_all / dbm) * cdiv(d->CO, 32 * dnb) >= 128 && !cu_env_set("CU_CONV_NODMA")) {

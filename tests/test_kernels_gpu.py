@@ -505,7 +505,7 @@ def test_weight_prep_batch_matches_per_layer(dtype):
         assert torch.equal(wf, rf) and torch.equal(wd, rd)
 
 
-@pytest.mark.parametrize("case", [(64, 64, 128, 64), (40, 128, 256, 32), (64, 256, 512, 16)])
+@pytest.mark.parametrize("case", [(64, 64, 128, 64), (40, 128, 256, 32), (64, 256, 512, 16), (64, 256, 480, 32)])
 def test_conv_wide_dma_kernel_stride2(case):
     """stride-2 3x3 forward on the 8-wave LDS-DMA kernel (256-pixel tiles, 17 x 65 halo) vs the register-staged kernel
     (same summation order) and F.conv2d."""

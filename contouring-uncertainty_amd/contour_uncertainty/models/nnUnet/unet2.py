@@ -92,7 +92,9 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module: "UNet", slot, x: Tensor, *params: Tensor):
         P = dict(zip(module._pnames, params))
-        need = any(ctx.needs_input_grad)
+        # (ctx.needs_input_grad only mirrors requires_grad of the inputs: under no_grad it is still True for parameters;
+        # the slot exists exactly when grad mode was on at the call)
+        need = slot is not None and any(ctx.needs_input_grad)
         logits, feats, ectx = module.engine.forward(P, x, module.bottleneck_out, module.training or module.mc_dropout,
                                                     keep=need)
         ctx.module, ctx.ectx, ctx.slot = module, (ectx if need else None), slot

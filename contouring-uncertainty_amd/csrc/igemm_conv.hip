@@ -473,6 +473,7 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int col = colb + 8 * g + 4 * h;
+                    if (col >= p.CO) continue;        // ragged last block (f32: 16-channel layers of the `vital` U-Net)
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e];

@@ -285,6 +285,65 @@ __global__ __launch_bounds__(256) void adam_kernel(size_t n, float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------- MaxPool2d(2, 2)
+// nn.MaxPool2d(kernel_size=2, stride=2) of the `vital` U-Net (reference vital/vital/models/segmentation/unet.py:137-139)
+// on NHWC tensors: one thread = 4 consecutive channels of one output pixel.  idx[n][oy][ox][c] in {0,1,2,3} = window
+// position (dy * 2 + dx) of the maximum, the FIRST one in row-major window order on ties like ATen; NaN propagates.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                           unsigned char* __restrict__ idx, int N, int OH, int OW, int C) {
+    const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const size_t total = (size_t)N * OH * OW * C;
+    if (i4 >= total) return;
+    const int c = (int)(i4 % C);
+    const size_t pix = i4 / C;
+    const int ox = (int)(pix % OW);
+    const size_t t = pix / OW;
+    const int oy = (int)(t % OH), n = (int)(t / OH);
+    const int W = 2 * OW;
+    const T* base = x + (((size_t)n * 2 * OH + 2 * oy) * W + 2 * ox) * C + c;
+    float best[4];
+    unsigned char bi[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) best[e] = Elem<T>::ld(base + e);
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        const T* q = base + ((size_t)(k >> 1) * W + (k & 1)) * C;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = Elem<T>::ld(q + e);
+            if (v > best[e] || v != v) { best[e] = v; bi[e] = (unsigned char)k; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        Elem<T>::st(y + i4 + e, best[e]);
+        idx[i4 + e] = bi[e];
+    }
+}
+
+// dx[window position idx] = dy, the other three positions 0 (every input pixel belongs to exactly one window)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                           T* __restrict__ dx, int N, int OH, int OW, int C) {
+    const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const size_t total = (size_t)N * OH * OW * C;
+    if (i4 >= total) return;
+    const int c = (int)(i4 % C);
+    const size_t pix = i4 / C;
+    const int ox = (int)(pix % OW);
+    const size_t t = pix / OW;
+    const int oy = (int)(t % OH), n = (int)(t / OH);
+    const int W = 2 * OW;
+    T* base = dx + (((size_t)n * 2 * OH + 2 * oy) * W + 2 * ox) * C + c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        T* q = base + ((size_t)(k >> 1) * W + (k & 1)) * C;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Elem<T>::st(q + e, idx[i4 + e] == k ? Elem<T>::ld(dy + i4 + e) : 0.f);
+    }
+}
+
 }  // namespace
 
 extern "C" int cu_conv_c1_fwd(int dtype, int N, int H, int W, int CO, const float* img, const float* w, const float* bias,
@@ -398,6 +457,35 @@ extern "C" int cu_weight_prep_batch(int dtype, int n_items, const cu_prep_item* 
         hipLaunchKernelGGL(weight_prep_batch_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, items, n_items);
     else
         hipLaunchKernelGGL(weight_prep_batch_kernel<float>, dim3(total_blocks), dim3(256), 0, st, items, n_items);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_maxpool2_fwd(int dtype, int N, int OH, int OW, int C, const void* x, void* y, unsigned char* idx, void* stream) {
+    CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_maxpool2_fwd: bad dtype");
+    CU_CHECK_ARG(N > 0 && OH > 0 && OW > 0 && C > 0 && C % 4 == 0 && x && y && idx, "cu_maxpool2_fwd: bad argument (C % 4 == 0)");
+    const size_t n4 = (size_t)N * OH * OW * C / 4;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const unsigned blocks = (unsigned)((n4 + 255) / 256);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, idx, N, OH, OW, C);
+    else
+        hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, idx, N, OH, OW, C);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_maxpool2_bwd(int dtype, int N, int OH, int OW, int C, const void* dy, const unsigned char* idx, void* dx,
+                               void* stream) {
+    CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_maxpool2_bwd: bad dtype");
+    CU_CHECK_ARG(N > 0 && OH > 0 && OW > 0 && C > 0 && C % 4 == 0 && dy && dx && idx, "cu_maxpool2_bwd: bad argument (C % 4 == 0)");
+    const size_t n4 = (size_t)N * OH * OW * C / 4;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const unsigned blocks = (unsigned)((n4 + 255) / 256);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, idx, (bf16_t*)dx, N, OH, OW, C);
+    else
+        hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, idx, (float*)dx, N, OH, OW, C);
     CU_LAUNCH_CHECK();
     return 0;
 }

@@ -59,6 +59,8 @@ _SIGS = {
     "cu_instnorm_fwd_fused": (C.c_int, [C.c_int] * 4 + [_P] * 3 + [C.c_float, C.c_float] + [_P] * 3 + [C.c_int, _P]),
     "cu_instnorm_bwd_fused": (C.c_int, [C.c_int] * 4 + [_P] * 4 + [C.c_float] + [_P] * 3 + [C.c_int, _P]),
     "cu_channel_scale": (C.c_int, [C.c_int] * 4 + [_P] * 3),
+    "cu_maxpool2_fwd": (C.c_int, [C.c_int] * 5 + [_P] * 4),
+    "cu_maxpool2_bwd": (C.c_int, [C.c_int] * 5 + [_P] * 4),
     "cu_act_bwd": (C.c_int, [C.c_int] * 4 + [_P] * 2 + [C.c_float] + [_P] * 2),
     "cu_act_to_nchw_f32": (C.c_int, [C.c_int] * 4 + [_P] * 2 + [C.c_float] + [_P] * 2),
     "cu_nchw_f32_to_nhwc": (C.c_int, [C.c_int] * 5 + [_P] * 3),

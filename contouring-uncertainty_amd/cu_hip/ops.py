@@ -270,6 +270,27 @@ def resident_wait_failed(ws: Tensor, n: int, c: int) -> bool:
     return bool(ws.view(torch.int32)[1].item() != 0)
 
 
+def maxpool2_fwd(x: Tensor):
+    """x (N, 2OH, 2OW, C) -> (y (N, OH, OW, C), idx uint8 of the same shape)  (cu_maxpool2_fwd)."""
+    n, h, w_, c = x.shape
+    y = torch.empty((n, h // 2, w_ // 2, c), dtype=x.dtype, device=x.device)
+    idx = torch.empty((n, h // 2, w_ // 2, c), dtype=torch.uint8, device=x.device)
+    with _Prof("small"):
+        L.check(L.load().cu_maxpool2_fwd(L.dtype_code(x.dtype), n, h // 2, w_ // 2, c, L.ptr(x), L.ptr(y), L.ptr(idx),
+                                         L.stream_ptr()), "cu_maxpool2_fwd")
+    return y, idx
+
+
+def maxpool2_bwd(dy: Tensor, idx: Tensor) -> Tensor:
+    """dy (N, OH, OW, C) -> dx (N, 2OH, 2OW, C)  (cu_maxpool2_bwd)."""
+    n, oh, ow, c = dy.shape
+    dx = torch.empty((n, 2 * oh, 2 * ow, c), dtype=dy.dtype, device=dy.device)
+    with _Prof("small"):
+        L.check(L.load().cu_maxpool2_bwd(L.dtype_code(dy.dtype), n, oh, ow, c, L.ptr(dy), L.ptr(idx), L.ptr(dx),
+                                         L.stream_ptr()), "cu_maxpool2_bwd")
+    return dx
+
+
 def channel_scale(x: Tensor, mask: Tensor):
     """x (N,H,W,C) *= mask (N,C) in place (Dropout2d)."""
     n, h, w_, c = x.shape

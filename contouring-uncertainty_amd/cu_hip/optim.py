@@ -56,8 +56,12 @@ class FusedAdam(torch.optim.Optimizer):
                 raise RuntimeError("FusedAdam needs contiguous float32 parameters and gradients")
             if cur:
                 q = cur[-1]
+                # back to back in memory AND inside one storage each (separately allocated tensors can be neighbours by
+                # accident; a strided view cannot span two storages)
                 if (q.data_ptr() + q.numel() * 4 == p.data_ptr()
-                        and q.grad.data_ptr() + q.numel() * 4 == p.grad.data_ptr()):
+                        and q.grad.data_ptr() + q.numel() * 4 == p.grad.data_ptr()
+                        and q.untyped_storage().data_ptr() == p.untyped_storage().data_ptr()
+                        and q.grad.untyped_storage().data_ptr() == p.grad.untyped_storage().data_ptr()):
                     cur.append(p)
                     continue
                 runs.append(cur)

@@ -150,6 +150,11 @@ int cu_instnorm_bwd_fused(int dtype, int N, int HW, int C, void* g, const void* 
 /* x[n][p][c] *= mask[n][c] in place: nn.Dropout2d(p) between conv and norm (layers.py:154-164,199-202), forward and
  * backward (mask entries are 0 or 1/(1-p)) */
 int cu_channel_scale(int dtype, int N, int HW, int C, void* x, const float* mask, void* stream);
+/* nn.MaxPool2d(2, 2) of the `vital` U-Net (vital/vital/models/segmentation/unet.py:137-139) on NHWC tensors:
+ * x [N][2 OH][2 OW][C] -> y [N][OH][OW][C], idx (same shape, bytes) = window position dy*2+dx of the maximum (first one
+ * on ties, NaN propagates: ATen's rule); backward routes dy to that position and zeroes the other three.  C % 4 == 0. */
+int cu_maxpool2_fwd(int dtype, int N, int OH, int OW, int C, const void* x, void* y, unsigned char* idx, void* stream);
+int cu_maxpool2_bwd(int dtype, int N, int OH, int OW, int C, const void* dy, const unsigned char* idx, void* dx, void* stream);
 /* plain activation backward for layers without norm (ConfidenceNet ReLU): g *= (z > 0 ? 1 : slope); dbias[c] += sum g */
 int cu_act_bwd(int dtype, int N, int HW, int C, void* g, const void* z, float slope, float* dbias, void* stream);
 /* materialise act(z*scale+shift) as NCHW f32 (the bottleneck clone handed to the skew head, unet2.py:186) and back */

@@ -448,11 +448,51 @@ def gen_drop():
     (OUT / "drop_block_layers.json").write_text(json.dumps(res, indent=1) + "\n")
 
 
+def gen_vital_unet():
+    """The `vital` U-Net (vital/vital/models/segmentation/unet.py, loaded by file path: the package's __init__ needs
+    dotenv): init_channels 32, K = 5, N = 3, 64 x 64, train mode: logits, running statistics after the forward,
+    per-parameter gradient statistics; then the eval-mode logits with the updated statistics."""
+    import importlib.util
+    from oracle import vital_unet as OV
+    spec = importlib.util.spec_from_file_location("ref_vital_unet", REF / "vital/vital/models/segmentation/unet.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = torch.Generator().manual_seed(23)
+    sd = OV.init_state(1, 5, 32, g)
+    net = mod.UNet((1, 64, 64), (5, 64, 64), init_channels=32)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    x = torch.rand(3, 1, 64, 64, generator=g)
+    logits = net(x)
+    gl = torch.randn(logits.shape, generator=g)
+    (logits * gl).sum().backward()
+    out = {"x": npy(x), "logits": npy(logits), "g_logits": npy(gl)}
+    names, gstats, ghead = [], [], []
+    for name, p in net.named_parameters():
+        names.append(name)
+        gstats.append(stats(p.grad))
+        ghead.append(npy(p.grad.flatten()[:8]))
+    out["grad_names"] = np.array(names)
+    out["grad_stats"] = np.stack(gstats)
+    out["grad_head"] = np.stack([np.pad(h, (0, 8 - len(h))) for h in ghead])
+    new = net.state_dict()
+    for k in ("layer1.net.1", "layer6.net.1.net.5", "layer11.conv.net.5"):
+        out[f"rm:{k}"] = npy(new[f"{k}.running_mean"])
+        out[f"rv:{k}"] = npy(new[f"{k}.running_var"])
+    net.eval()
+    with torch.no_grad():
+        out["logits_eval"] = npy(net(x))
+    np.savez_compressed(OUT / "vital_unet.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dsnt", "nll", "unet_small", "unet_full", "step", "psm", "skew_grid", "umap", "drop", "skew_mode"]
+    which = sys.argv[1:] or ["dsnt", "nll", "unet_small", "unet_full", "step", "psm", "skew_grid", "umap", "drop", "skew_mode",
+                             "vital_unet"]
     for w in which:
         print("generating", w, flush=True)
         {"dsnt": gen_dsnt, "nll": gen_nll, "unet_small": gen_unet_small, "unet_full": gen_unet_full,
-         "step": gen_step, "psm": gen_psm, "skew_grid": gen_skew_grid, "umap": gen_umap, "drop": gen_drop, "skew_mode": gen_skew_mode}[w]()
+         "step": gen_step, "psm": gen_psm, "skew_grid": gen_skew_grid, "umap": gen_umap, "drop": gen_drop, "skew_mode": gen_skew_mode,
+         "vital_unet": gen_vital_unet}[w]()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)

@@ -153,3 +153,33 @@ def test_train_step_matches_reference(golden_dir, task):
             assert abs(logs[keys[j]] - r) <= 2e-4 * max(1.0, abs(r)), (it, keys[j], logs[keys[j]], r)
     assert torch.allclose(ot.sd["output_block.conv.weight"].detach(), T(g[f"{task}_w_out"]), rtol=1e-3, atol=2e-5)
     assert torch.allclose(ot.sd["input_block.conv1.conv.weight"].detach(), T(g[f"{task}_w_in"]), rtol=1e-3, atol=2e-5)
+
+
+def test_vital_unet_oracle_vs_reference_golden(golden_dir):
+    """oracle/vital_unet.py against the fixture written from the reference module (vital/.../segmentation/unet.py):
+    train-mode logits, every parameter gradient, the running statistics after the forward, eval-mode logits."""
+    from oracle import vital_unet as OV
+    g = np.load(golden_dir / "vital_unet.npz")
+    gen = torch.Generator().manual_seed(23)
+    sd = OV.init_state(1, 5, 32, gen)
+    x = torch.from_numpy(g["x"])
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    state = dict(sd)
+    state.update(params)
+    logits = OV.forward(state, x, training=True)
+    assert torch.allclose(logits, torch.from_numpy(g["logits"]), rtol=1e-4, atol=1e-5)
+    (logits * torch.from_numpy(g["g_logits"])).sum().backward()
+    for name, st, head in zip(g["grad_names"], g["grad_stats"], g["grad_head"]):
+        gr = params[str(name)].grad
+        l2 = float(gr.double().norm())
+        assert abs(l2 - st[2]) <= 2e-4 * st[2] + 1e-7, name
+        k = min(8, gr.numel())
+        assert np.allclose(gr.flatten()[:k].numpy(), head[:k], rtol=2e-3, atol=1e-5 * max(st[2], 1e-3)), name
+    for key in g.files:
+        if key.startswith("rm:"):
+            assert np.allclose(state[f"{key[3:]}.running_mean"].numpy(), g[key], rtol=1e-5, atol=1e-6)
+        if key.startswith("rv:"):
+            assert np.allclose(state[f"{key[3:]}.running_var"].numpy(), g[key], rtol=1e-5, atol=1e-6)
+    with torch.no_grad():
+        ev = OV.forward(state, x, training=False)
+    assert torch.allclose(ev, torch.from_numpy(g["logits_eval"]), rtol=1e-4, atol=1e-5)

@@ -162,6 +162,27 @@ __global__ void stats_finalize_kernel(const T* __restrict__ z, const float* __re
     stats[3 * NC + i] = b - mean * g * rstd;
 }
 
+// the same from sums a convolution epilogue gathered (tconv.hip): sums[n][c] = {sum, sum of squares} of (z - shift[c]) in
+// f32 BEFORE the rounding of z to its storage type (shift = the conv bias, or NULL = 0)
+__global__ void stats_finalize_given_kernel(const float* __restrict__ sums, const float* __restrict__ shift,
+                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                            float* __restrict__ stats, int N, int HW, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int c = i % C;
+    const float inv = 1.f / (float)HW;
+    const float m1 = sums[2 * i] * inv, m2 = sums[2 * i + 1] * inv;
+    const float mean = (shift ? shift[c] : 0.f) + m1;
+    const float var = fmaxf(m2 - m1 * m1, 0.f);
+    const float rstd = 1.f / sqrtf(var + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const size_t NC = (size_t)N * C;
+    stats[i] = mean;
+    stats[NC + i] = rstd;
+    stats[2 * NC + i] = g * rstd;
+    stats[3 * NC + i] = b - mean * g * rstd;
+}
+
 // materialise a = LeakyReLU(z*scale + shift) (one streaming pass): the MFMA kernels then stage plain operands.
 // Measured on MI355X: re-doing this affine + activation inside every consumer's operand load made the thin-channel
 // convolutions VALU-bound (40-50 % of their time); one extra 2-byte write + read per element is far cheaper.
@@ -1133,6 +1154,17 @@ extern "C" int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void
         if (rc) return rc;
     }
     return 0;
+}
+
+extern "C" int cu_instnorm_fwd_given(int dtype, int N, int HW, int C, const void* z, const float* gamma, const float* beta,
+                                     float eps, float slope, const float* sums, const float* shift, float* stats, void* out,
+                                     void* stream) {
+    NORM_COMMON_CHECKS("cu_instnorm_fwd_given");
+    CU_CHECK_ARG(z && stats && out && sums, "cu_instnorm_fwd_given: null pointer");
+    hipLaunchKernelGGL(stats_finalize_given_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, st, sums, shift, gamma, beta, eps,
+                       stats, N, HW, C);
+    return dtype == CU_BF16 ? launch_apply<bf16_t>(N, N, HW, C, z, stats, slope, out, st)
+                            : launch_apply<float>(N, N, HW, C, z, stats, slope, out, st);
 }
 
 extern "C" int cu_instnorm_bwd_fused(int dtype, int N, int HW, int C, void* g, const void* z, const float* stats,

@@ -29,14 +29,20 @@ struct TcArgs {
     int tap_w[9];                   // weight tap of gather tap t
     int D0, DC0, DC1;               // columns [0, D0) -> dst0, the rest -> dst1; channel strides
     int ntiles, tiles_x, tiles_y;   // tiles of TH x 32 pixels
+    float* stat_sums;               // STATS instances: [N][CO][2] += (sum, sum of squares) of the outputs minus their bias
+    int run;                        // STATS instances: consecutive tiles per workgroup (all of one image)
 };
 
 __device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// CIP = input channels / 32, NB = output channels / 32, TH = tile rows, R = ring slots
-template <int CIP, int NB, int TH, int R>
+// CIP = input channels / 32, NB = output channels / 32, TH = tile rows, R = ring slots.
+// STATS: the InstanceNorm statistics of the layer are gathered here: a workgroup walks `run`
+// CONSECUTIVE tiles of one image, every lane keeps running sums of its 16 channels' f32 accumulators (one add and one
+// fma per accumulator register and tile -- the stream has the vector slack), and ONE 32-lane reduction + one set of
+// atomics per workgroup hands sum / sum of squares of (z - bias) to the norm kernels' finalize step.
+template <int CIP, int NB, int TH, int R, bool STATS>
 __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
     constexpr int CI = 32 * CIP, CO = 32 * NB;
     constexpr int HW34 = 34, HALO = (TH + 2) * HW34, HPAD = (HALO + 15) / 16 * 16;     // plane stride: whole DMA instructions
@@ -88,10 +94,13 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
 
     // XCD-aware tile order (workgroups are dealt round-robin to the 8 XCDs): logical tile L -> (L % 8) * ntiles/8 + L / 8,
     // so one XCD's L2 sees a contiguous eighth of the tiles and the halo rows shared by vertical neighbours are L2 hits
-    const bool xcd = (p.ntiles & 7) == 0 && (gridDim.x & 7) == 0;
+    const bool xcd = !STATS && (p.ntiles & 7) == 0 && (gridDim.x & 7) == 0;
     auto tile_of = [&](int l) { return xcd ? (l & 7) * (p.ntiles >> 3) + (l >> 3) : l; };
+    const int l_step = STATS ? 1 : (int)gridDim.x;
+    const int l_begin = STATS ? (int)blockIdx.x * p.run : (int)blockIdx.x;
+    const int l_end = STATS ? l_begin + p.run : p.ntiles;
     auto issue = [&](int l, int slot) {          // DMA of logical tile l (or D out-of-range instructions) into ring slot
-        const bool live = l < p.ntiles;
+        const bool live = l < l_end;
         const int tile = live ? tile_of(l) : 0;
         const int tx = tile % p.tiles_x, rest = tile / p.tiles_x;
         const int ty = rest % p.tiles_y, n = rest / p.tiles_y;
@@ -122,10 +131,17 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weights + bias have landed (before any counted wait below)
 
     const bf16_t* W16 = reinterpret_cast<const bf16_t*>(smem);
-    int l = blockIdx.x;
+    float ssum[STATS ? NBW : 1][16], ssq[STATS ? NBW : 1][16];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int b = 0; b < NBW; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ssum[b][i] = 0.f; ssq[b][i] = 0.f; }
+    }
+    int l = l_begin;
     issue(l, 0);
-    if (R == 3) issue(l + gridDim.x, 1);
-    for (int it = 0; l < p.ntiles; ++it, l += gridDim.x) {
+    if (R == 3) issue(l + l_step, 1);
+    for (int it = 0; l < l_end; ++it, l += l_step) {
         // DMA(it) must have landed; younger operations, in issue order: [R == 3: stores(it-2), DMA(it+1)], stores(it-1)
         if (R == 3) {
             if (it == 0) wait_vm<D>();
@@ -136,7 +152,7 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
             else wait_vm<S>();
         }
         __syncthreads();        // tile `it` is complete for every wave, and nobody reads the slot of tile it-1 any more
-        issue(l + (R - 1) * gridDim.x, (it + R - 1) % R);
+        issue(l + (R - 1) * l_step, (it + R - 1) % R);
         const bf16_t* X16 = reinterpret_cast<const bf16_t*>(smem + W_B + (it % R) * SLOT_B);
 
         f32x16 acc[NBW];
@@ -161,6 +177,15 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
             }
         }
 
+        if constexpr (STATS) {
+#pragma unroll
+            for (int b = 0; b < NBW; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    ssum[b][i] += acc[b][i];
+                    ssq[b][i] = fmaf(acc[b][i], acc[b][i], ssq[b][i]);
+                }
+        }
         // ---- epilogue: register i of a block = channel (i & 3) + 8 * (i >> 2) + 4 * h of pixel r
         const int tile = tile_of(l);
         const int tx = tile % p.tiles_x, rest = tile / p.tiles_x;
@@ -193,28 +218,55 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing out-of-range DMA instructions target live LDS
+    if constexpr (STATS) {
+        // lanes with the same h hold the same 16 channels of 32 different pixels: butterfly over the pixel lanes
+        const int n = (l_begin / (p.tiles_x * p.tiles_y));
+#pragma unroll
+        for (int b = 0; b < NBW; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float a = ssum[b][i], q2 = ssq[b][i];
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1) {
+                    a += __shfl_xor(a, m, 64);
+                    q2 += __shfl_xor(q2, m, 64);
+                }
+                if (r == 0) {
+                    const int col = (b0 + b) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    float* o = p.stat_sums + ((size_t)n * CO + col) * 2;
+                    unsafeAtomicAdd(o, a);
+                    unsafeAtomicAdd(o + 1, q2);
+                }
+            }
+    }
 }
 
 template <int CIP, int NB, int TH, int R>
-int launch_tc(const TcArgs& a, hipStream_t st) {
+int launch_tc(TcArgs& a, hipStream_t st) {
     constexpr int HPAD = ((TH + 2) * 34 + 15) / 16 * 16;
     constexpr int D = (CIP * HPAD * 4 + 511) / 512, WD = (CIP * 9 * 32 * NB * 4 + 511) / 512;
     const size_t lds = (size_t)WD * 8192 + (size_t)R * D * 8192;
-    auto k = tconv_kernel<CIP, NB, TH, R>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    CU_CHECK_ARG(e == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;       // workgroups that fit a CU (LDS; <= 128 VGPRs in every instance)
     int grid = a.ntiles < 256 * per_cu ? a.ntiles : 256 * per_cu;
+    // statistics: every workgroup needs a run of consecutive tiles inside ONE image
+    const int per_img = a.tiles_x * a.tiles_y;
+    const bool stats = a.stat_sums && a.ntiles % grid == 0 && per_img % (a.ntiles / grid) == 0;
+    if (!stats) a.stat_sums = nullptr;
+    a.run = stats ? a.ntiles / grid : 0;
+    auto k = stats ? tconv_kernel<CIP, NB, TH, R, true> : tconv_kernel<CIP, NB, TH, R, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    CU_CHECK_ARG(e == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
     CU_LAUNCH_CHECK();
-    return 1;
+    return stats ? 2 : 1;
 }
 
 }  // namespace
 
-// 1 = launched, 0 = not this kernel's shape, < 0 = error.  Called by cu_conv_gemm for plain bf16 operands.
+// 2 = launched and the statistics were gathered, 1 = launched, 0 = not this kernel's shape, < 0 = error.  Called by
+// cu_conv_gemm for plain bf16 operands.  stat_sums ([N][CO][2] f32, zero on entry) or NULL.
 int cu_tconv_try(const cu_conv_desc* d, const void* src0, const void* src1, const void* w, const float* bias, void* dst0,
-                 void* dst1, void* stream) {
+                 void* dst1, float* stat_sums, void* stream) {
     if (d->dtype != CU_BF16 || d->ntaps != 9 || d->IS != 1 || d->OS != 1 || d->OY0 || d->OX0 || d->out_nchw_f32 ||
         d->par_co || d->accum0 || d->accum1 || d->slope0 != 1.0f || (d->C1 && d->slope1 != 1.0f))
         return 0;
@@ -234,6 +286,7 @@ int cu_tconv_try(const cu_conv_desc* d, const void* src0, const void* src1, cons
     a.src0_bytes = (unsigned)b0; a.src1_bytes = (unsigned)b1; a.w_bytes = (unsigned)((size_t)9 * d->CO * CI * 2);
     a.N = d->N; a.H = d->PH; a.W = d->PW; a.C0 = d->C0; a.C1 = d->C1;
     a.D0 = d->D0; a.DC0 = d->DC0; a.DC1 = d->DC1;
+    a.stat_sums = two ? nullptr : stat_sums;
     for (int t = 0; t < 9; ++t) {
         if (d->tap_dy[t] < -1 || d->tap_dy[t] > 1 || d->tap_dx[t] < -1 || d->tap_dx[t] > 1 || d->tap_w[t] < 0 || d->tap_w[t] > 8)
             return 0;

@@ -127,6 +127,7 @@ class UNetEngine:
         # True: InstanceNorm + LeakyReLU forward (statistics + materialise) and backward (reduce + apply) each run as ONE
         # resident-chunk launch that reads every tensor once (norm.hip); False: the two-pass kernels
         self.fused_norm = True
+        self.fused_stats = os.environ.get("CONTOUR_FUSED_STATS", "1") != "0"
         # Dropout2d(p=0.5) between conv and norm in the listed ConvLayers (reference unet2.py:129-136,302: the last
         # downsample block and the bottleneck when task.model.drop_block=True); active in training mode only
         self.drop_layers: set = set()
@@ -194,8 +195,21 @@ class UNetEngine:
         oh, ow = sh // stride, sw // stride
         co = w.shape[0]
         z = torch.empty((n, oh, ow, co), dtype=self.dtype, device=w.device)
-        ops.conv_gemm(srcs, wf, P[f"{prefix}.conv.bias"], grid=(oh, ow), in_stride=stride, taps=TAPS3, dsts=[z],
-                      dst_cols=[co])
+        # thin, large layers: the streaming kernel gathers the InstanceNorm statistics in its epilogue (no statistics pass)
+        sums = None
+        fusable = (self.fused_stats and self.fused_norm and self.materialize and stride == 1 and self.dtype == torch.bfloat16
+                   and n * oh * ow >= (1 << 20) and not (ctx.training and prefix in self.drop_layers))
+        if fusable:
+            sums = self._arena["fwd"].take(2 * n * co, z.device)
+        got = ops.conv_gemm(srcs, wf, P[f"{prefix}.conv.bias"], grid=(oh, ow), in_stride=stride, taps=TAPS3, dsts=[z],
+                            dst_cols=[co], stat_sums=sums)
+        if got:
+            out = ops.instnorm_fwd_given(z, P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"], self.slope, sums,
+                                         P[f"{prefix}.conv.bias"], self.eps)
+            if not ctx.keep and out.a is not None:
+                return Act(out.a, None, 1.0)
+            ctx.convs[prefix] = _ConvRec(prefix, srcs, out, stride, drop_mask=None)
+            return out
         mask = None
         if ctx.training and prefix in self.drop_layers:
             if self.drop_mask_fn is not None:

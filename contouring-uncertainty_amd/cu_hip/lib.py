@@ -49,6 +49,7 @@ _SIGS = {
     "cu_arch": (C.c_char_p, []),
     "cu_conv_gemm": (C.c_int, [C.POINTER(ConvDesc)] + [_P] * 11),
     "cu_conv_gemm_ws": (C.c_int, [C.POINTER(ConvDesc)] + [_P] * 11 + [C.c_size_t, _P]),
+    "cu_conv_gemm_stats": (C.c_int, [C.POINTER(ConvDesc)] + [_P] * 11 + [C.c_size_t, _P, C.POINTER(C.c_int), _P]),
     "cu_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc)] + [_P] * 9),
     "cu_conv_c1_fwd": (C.c_int, [C.c_int] * 5 + [_P] * 5),
     "cu_conv_c1_wgrad": (C.c_int, [C.c_int] * 5 + [_P] * 4),
@@ -57,6 +58,7 @@ _SIGS = {
     "cu_instnorm_lrelu_bwd": (C.c_int, [C.c_int] * 4 + [_P] * 4 + [C.c_float] + [_P] * 5),
     "cu_instnorm_resident_ws_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "cu_instnorm_fwd_fused": (C.c_int, [C.c_int] * 4 + [_P] * 3 + [C.c_float, C.c_float] + [_P] * 3 + [C.c_int, _P]),
+    "cu_instnorm_fwd_given": (C.c_int, [C.c_int] * 4 + [_P] * 3 + [C.c_float, C.c_float] + [_P] * 5),
     "cu_instnorm_bwd_fused": (C.c_int, [C.c_int] * 4 + [_P] * 4 + [C.c_float] + [_P] * 3 + [C.c_int, _P]),
     "cu_channel_scale": (C.c_int, [C.c_int] * 4 + [_P] * 3),
     "cu_maxpool2_fwd": (C.c_int, [C.c_int] * 5 + [_P] * 4),

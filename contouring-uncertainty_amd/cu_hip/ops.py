@@ -82,7 +82,7 @@ def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: T
               taps: Sequence[Tuple[int, int, int]], dsts: Sequence[Tensor], dst_cols: Sequence[int],
               out_stride: int = 1, out_off: Tuple[int, int] = (0, 0), accum: Sequence[int] = (0, 0),
               out_nchw: bool = False, n_cols: Optional[int] = None, parity_cols: int = 0,
-              parity_taps: Optional[Sequence[int]] = None):
+              parity_taps: Optional[Sequence[int]] = None, stat_sums: Optional[Tensor] = None) -> bool:
     """D[p, n] = bias[n] + sum_t sum_c act(S[p*IS + off_t, c]) W[tap_w[t]][n][c]  (cu_conv_gemm).
     ``parity_taps`` (16 ints, with ``parity_cols``): weight tap of (gather tap t, parity group g) at [t*4+g], -1 = none."""
     lib = L.load()
@@ -126,11 +126,15 @@ def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: T
         + d.N * d.PH * d.PW * d.CO * (4 if out_nchw else esz) * (2 if any(accum) else 1)
     note = f"N{d.N} {d.PH}x{d.PW} IS{d.IS} OS{d.OS} C{d.C0}+{d.C1}->{d.CO} t{d.ntaps}"
     ws = _split_k_ws(t0.device)
+    import ctypes as _C
+    done = _C.c_int(0)
     with _Prof("igemm_conv", flops, note, nbytes):
-        rc = lib.cu_conv_gemm_ws(d, L.ptr(t0), L.ptr(sc0), L.ptr(sh0), L.ptr(t1), L.ptr(sc1), L.ptr(sh1), L.ptr(w),
-                                 L.ptr(bias), L.ptr(dst0), L.ptr(dsts[1]) if len(dsts) > 1 else None, L.ptr(ws), ws.numel(),
-                                 L.stream_ptr())
-    L.check(rc, "cu_conv_gemm_ws")
+        rc = lib.cu_conv_gemm_stats(d, L.ptr(t0), L.ptr(sc0), L.ptr(sh0), L.ptr(t1), L.ptr(sc1), L.ptr(sh1), L.ptr(w),
+                                    L.ptr(bias), L.ptr(dst0), L.ptr(dsts[1]) if len(dsts) > 1 else None, L.ptr(ws),
+                                    ws.numel(), L.ptr(stat_sums), _C.byref(done) if stat_sums is not None else None,
+                                    L.stream_ptr())
+    L.check(rc, "cu_conv_gemm_stats")
+    return bool(done.value)          # True: stat_sums (N, CO, 2; zero on entry) now holds the output's statistics sums
 
 
 _SPLIT_K_WS: Dict[str, Tensor] = {}
@@ -251,6 +255,20 @@ def instnorm_fwd_fused(z: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor
                                                slope, L.ptr(stats), L.ptr(out), L.ptr(ws), mode, L.stream_ptr()),
                 "cu_instnorm_fwd_fused")
     return Act(z, stats, slope, out, ws)
+
+
+def instnorm_fwd_given(z: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], slope: float, sums: Tensor,
+                       shift: Optional[Tensor], eps: float = 1e-5) -> Act:
+    """statistics from sums the producing convolution gathered (``conv_gemm(stat_sums=...)``) + the apply pass
+    (cu_instnorm_fwd_given) -> Act(z, stats, a)."""
+    n, h, w_, c = z.shape
+    stats = torch.empty((4, n, c), dtype=torch.float32, device=z.device)
+    out = torch.empty_like(z)
+    with _Prof("instnorm_fwd", 0.0, f"N{n} {h}x{w_} C{c}", 2 * z.numel() * z.element_size()):
+        L.check(L.load().cu_instnorm_fwd_given(L.dtype_code(z.dtype), n, h * w_, c, L.ptr(z), L.ptr(gamma), L.ptr(beta), eps,
+                                               slope, L.ptr(sums), L.ptr(shift), L.ptr(stats), L.ptr(out), L.stream_ptr()),
+                "cu_instnorm_fwd_given")
+    return Act(z, stats, slope, out, None)
 
 
 def instnorm_bwd_fused(g: Tensor, act: Act, gamma: Optional[Tensor], dgamma, dbeta, ws: Optional[Tensor] = None,

@@ -83,6 +83,17 @@ int cu_conv_gemm_ws(const cu_conv_desc* d,
                     const void* src1, const float* scale1, const float* shift1,
                     const void* w, const float* bias, void* dst0, void* dst1, float* ws, size_t ws_floats, void* stream);
 
+/* The same, and -- when the launch goes to the streaming kernel of the thin, large 3x3 layers (tconv.hip) with one
+ * destination -- the InstanceNorm statistics of the output gathered in its epilogue (layers.py:192-194: conv -> norm):
+ * stat_sums [N][CO][2] f32, ZERO on entry, += {sum, sum of squares} of (output - bias) in f32 before the rounding to the
+ * storage type.  *stats_done (host) = 1 when they were gathered, 0 when the launch took another kernel (stat_sums is
+ * then untouched and the caller runs the statistics pass).  Consumer: cu_instnorm_fwd_given. */
+int cu_conv_gemm_stats(const cu_conv_desc* d,
+                       const void* src0, const float* scale0, const float* shift0,
+                       const void* src1, const float* scale1, const float* shift1,
+                       const void* w, const float* bias, void* dst0, void* dst1, float* ws, size_t ws_floats,
+                       float* stat_sums, int* stats_done, void* stream);
+
 /* Weight gradient of the same gather convolution:  dW[t][n][c] += sum_p Z[p*ZS + zoff_t, n] * act(S[p*IS + off_t, c])
  * (autograd of nn.Conv2d / nn.ConvTranspose2d weights).  dW is f32, accumulated with atomics. */
 typedef struct {
@@ -144,6 +155,12 @@ int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, const void* 
 size_t cu_instnorm_resident_ws_floats(int N, int C);
 int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* z, const float* gamma, const float* beta,
                           float eps, float slope, float* stats, void* out, float* ws, int mode, void* stream);
+/* forward from statistics gathered elsewhere (cu_conv_gemm_stats): sums [N][C][2] = {sum, sum of squares} of
+ * (z - shift[c]) (shift [C] or NULL) -> stats (planes as above) and out = LeakyReLU(z*scale + shift): the statistics
+ * pass over z is gone, the apply pass remains. */
+int cu_instnorm_fwd_given(int dtype, int N, int HW, int C, const void* z, const float* gamma, const float* beta,
+                          float eps, float slope, const float* sums, const float* shift, float* stats, void* out,
+                          void* stream);
 int cu_instnorm_bwd_fused(int dtype, int N, int HW, int C, void* g, const void* z, const float* stats,
                           const float* gamma, float slope, float* dgamma, float* dbeta, float* ws, int mode,
                           void* stream);

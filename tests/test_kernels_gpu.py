@@ -637,9 +637,22 @@ def test_thin_streaming_conv(case):
     wf, wd = ops.weight_prep(w, "conv", dtype)
     wq = rq(w, dtype)
     z = torch.empty(n, size, size, co, device=DEV, dtype=dtype)
-    ops.conv_gemm(srcs, wf, b, grid=(size, size), in_stride=1, taps=TAPS3, dsts=[z], dst_cols=[co])
+    sums = torch.zeros(n, co, 2, device=DEV)
+    got = ops.conv_gemm(srcs, wf, b, grid=(size, size), in_stride=1, taps=TAPS3, dsts=[z], dst_cols=[co], stat_sums=sums)
     ref = F.conv2d(torch.cat(refs, 1), wq, b, padding=1)
     assert rel_err(nchw(z), ref) < tol(dtype)
+    # the InstanceNorm statistics gathered in the epilogue (cu_conv_gemm_stats): sum / sum of squares of (z - bias) per
+    # (image, channel), from the f32 accumulators; then the norm's forward from them vs F.instance_norm of the f32 output
+    assert got == (n != 20)           # 20 images: 10 tiles per workgroup do not divide an image (256 tiles) -> plain launch
+    if got:
+        c0_ = ref - b[None, :, None, None]
+        s1, s2 = c0_.sum((2, 3)), (c0_ * c0_).sum((2, 3))
+        assert rel_err(sums[..., 0], s1) < 2e-3 and rel_err(sums[..., 1], s2) < 2e-3
+        gm = 1 + 0.1 * torch.randn(co, device=DEV, generator=g)
+        bt = 0.1 * torch.randn(co, device=DEV, generator=g)
+        act = ops.instnorm_fwd_given(z, gm, bt, 0.01, sums, b)
+        want = F.leaky_relu(F.instance_norm(nchw(z), weight=gm, bias=bt, eps=1e-5), 0.01)
+        assert rel_err(nchw(act.a), want) < 2e-2
     # borders: the zero padding comes from the buffer range check
     assert rel_err(nchw(z)[:, :, [0, -1]], ref[:, :, [0, -1]]) < tol(dtype)
     assert rel_err(nchw(z)[:, :, :, [0, -1]], ref[:, :, :, [0, -1]]) < tol(dtype)

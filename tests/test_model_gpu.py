@@ -284,7 +284,8 @@ def test_drop_block_matches_oracle_with_shared_masks():
     masks = {}
 
     def mask_fn(prefix, n, c, device):
-        g = torch.Generator().manual_seed(hash(prefix) % 1000)
+        import zlib
+        g = torch.Generator().manual_seed(zlib.crc32(prefix.encode()) % 1000)      # (str hashes change from run to run)
         masks[prefix] = (torch.rand(n, c, generator=g) >= 0.5).float() * 2.0
         return masks[prefix].to(device)
 

@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256) void ksplit_finish_kernel(const float* __restr
 
 int cu_pconv_try(const cu_conv_desc* d, const void* src0, const void* w, const float* bias, void* dst0, void* stream);
 int cu_tconv_try(const cu_conv_desc* d, const void* src0, const void* src1, const void* w, const float* bias, void* dst0,
-                 void* dst1, float* stat_sums, void* stream);
+                 void* dst1, const cu_conv_epilogue* ep, void* stream);
 
 extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float* scale0, const float* shift0,
                             const void* src1, const float* scale1, const float* shift1, const void* w, const float* bias,
@@ -1034,6 +1034,17 @@ extern "C" int cu_conv_gemm_stats(const cu_conv_desc* d, const void* src0, const
                                   const void* src1, const float* scale1, const float* shift1, const void* w,
                                   const float* bias, void* dst0, void* dst1, float* ws, size_t ws_floats,
                                   float* stat_sums, int* stats_done, void* stream) {
+    cu_conv_epilogue ep;
+    memset(&ep, 0, sizeof(ep));
+    ep.mode = 1; ep.sums = stat_sums;
+    return cu_conv_gemm_ex(d, src0, scale0, shift0, src1, scale1, shift1, w, bias, dst0, dst1, ws, ws_floats,
+                           stat_sums && stats_done ? &ep : nullptr, stats_done, stream);
+}
+
+extern "C" int cu_conv_gemm_ex(const cu_conv_desc* d, const void* src0, const float* scale0, const float* shift0,
+                               const void* src1, const float* scale1, const float* shift1, const void* w,
+                               const float* bias, void* dst0, void* dst1, float* ws, size_t ws_floats,
+                               const cu_conv_epilogue* ep, int* stats_done, void* stream) {
     if (stats_done) *stats_done = 0;
     CU_CHECK_ARG(d != nullptr, "cu_conv_gemm: null descriptor");
     CU_CHECK_ARG(d->dtype == CU_F32 || d->dtype == CU_BF16, "cu_conv_gemm: bad dtype %d", d->dtype);
@@ -1086,7 +1097,7 @@ extern "C" int cu_conv_gemm_stats(const cu_conv_desc* d, const void* src0, const
 
     // ---- thin, large bf16 3x3 stride-1 layers (256^2 x 32, 128^2 x 64 channels): the streaming kernel (tconv.hip)
     if (bf && !scale0 && !scale1 && !cu_env_set("CU_CONV_NOTCONV")) {
-        const int rc = cu_tconv_try(d, src0, src1, w, bias, dst0, dst1, stats_done ? stat_sums : nullptr, stream);
+        const int rc = cu_tconv_try(d, src0, src1, w, bias, dst0, dst1, stats_done ? ep : nullptr, stream);
         if (rc == 2) *stats_done = 1;
         if (rc != 0) return rc < 0 ? rc : 0;
     }

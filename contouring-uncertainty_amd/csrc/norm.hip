@@ -1167,6 +1167,23 @@ extern "C" int cu_instnorm_fwd_given(int dtype, int N, int HW, int C, const void
                             : launch_apply<float>(N, N, HW, C, z, stats, slope, out, st);
 }
 
+extern "C" int cu_instnorm_bwd_given(int dtype, int N, int HW, int C, void* g, const void* z, const float* stats,
+                                     const float* gamma, float slope, float* dgamma, float* dbeta, const float* sums,
+                                     void* stream) {
+    NORM_COMMON_CHECKS("cu_instnorm_bwd_given");
+    CU_CHECK_ARG(g && z && stats && sums, "cu_instnorm_bwd_given: null pointer");
+    const size_t lds = sizeof(float) * (size_t)rm.rows * rm.tpp * 2 * PIECE;
+    dim3 grid(N, nchunks);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL(bwd_apply_kernel<bf16_t>, grid, dim3(NT), lds, st, (bf16_t*)g, (const bf16_t*)z, stats, gamma, slope,
+                           sums, dgamma, dbeta, (float*)nullptr, N, HW, C, rm.tpp, rm.rows, chunk);
+    else
+        hipLaunchKernelGGL(bwd_apply_kernel<float>, grid, dim3(NT), lds, st, (float*)g, (const float*)z, stats, gamma, slope,
+                           sums, dgamma, dbeta, (float*)nullptr, N, HW, C, rm.tpp, rm.rows, chunk);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int cu_instnorm_bwd_fused(int dtype, int N, int HW, int C, void* g, const void* z, const float* stats,
                                      const float* gamma, float slope, float* dgamma, float* dbeta, float* ws, int mode,
                                      void* stream) {

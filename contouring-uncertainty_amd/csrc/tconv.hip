@@ -29,8 +29,11 @@ struct TcArgs {
     int tap_w[9];                   // weight tap of gather tap t
     int D0, DC0, DC1;               // columns [0, D0) -> dst0, the rest -> dst1; channel strides
     int ntiles, tiles_x, tiles_y;   // tiles of TH x 32 pixels
-    float* stat_sums;               // STATS instances: [N][CO][2] += (sum, sum of squares) of the outputs minus their bias
-    int run;                        // STATS instances: consecutive tiles per workgroup (all of one image)
+    float* stat_sums;               // MODE 1: [N][CO][2] += (sum, sum of squares) of the outputs minus their bias
+                                    // MODE 2: [N][CO][2] += the two sums of the InstanceNorm backward (see below)
+    int run;                        // MODE 1, 2: consecutive tiles per workgroup (all of one image)
+    const void* nz; const float* nstats; float nslope;      // MODE 2: raw output z, statistics planes, LeakyReLU slope of
+                                                            // the layer whose output gradient this launch produces
 };
 
 __device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
@@ -38,12 +41,17 @@ __device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // CIP = input channels / 32, NB = output channels / 32, TH = tile rows, R = ring slots.
-// STATS: the InstanceNorm statistics of the layer are gathered here: a workgroup walks `run`
+// MODE 1: the InstanceNorm statistics of the layer are gathered here: a workgroup walks `run`
 // CONSECUTIVE tiles of one image, every lane keeps running sums of its 16 channels' f32 accumulators (one add and one
 // fma per accumulator register and tile -- the stream has the vector slack), and ONE 32-lane reduction + one set of
 // atomics per workgroup hands sum / sum of squares of (z - bias) to the norm kernels' finalize step.
-template <int CIP, int NB, int TH, int R, bool STATS>
+// MODE 2 (this launch is an input gradient g = dL/da of a layer a = LeakyReLU(scale z + shift); item 1(ii)): the reduction
+// pass of that layer's InstanceNorm backward happens here -- the lane reads its pixel's z (8-byte loads issued by hand
+// right after the barrier, so that they are OLDER than this iteration's LDS-DMA and waiting for them does not wait for
+// the prefetch), forms gl = g * LeakyReLU'(y) and keeps running sums of gl and gl * zhat; same flush as MODE 1.
+template <int CIP, int NB, int TH, int R, int MODE>
 __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
+    constexpr bool STATS = MODE != 0;
     constexpr int CI = 32 * CIP, CO = 32 * NB;
     constexpr int HW34 = 34, HALO = (TH + 2) * HW34, HPAD = (HALO + 15) / 16 * 16;     // plane stride: whole DMA instructions
     constexpr int XPIECES = CIP * HPAD * 4, D = (XPIECES + 511) / 512, SLOT_B = D * 8192;
@@ -51,7 +59,8 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
     constexpr int WPIECES = CIP * WROWS * 4, WD = (WPIECES + 511) / 512, W_B = WD * 8192;
     constexpr int NBW = NB * TH / 8;            // 32-column blocks per wave
     constexpr int S = 2 * NBW;                  // 16-byte stores per thread and tile
-    static_assert(NBW >= 1 && W_B + R * SLOT_B <= 160 * 1024, "tconv: bad instance");
+    constexpr int ZL = MODE == 2 ? 4 * NBW : 0; // hand-issued 8-byte loads of z per thread and tile
+    static_assert(NBW >= 1 && W_B + R * SLOT_B + 1024 <= 160 * 1024, "tconv: bad instance");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const unsigned w_base = lds_addr(smem), x_base = w_base + W_B;
@@ -128,6 +137,15 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             bv[b][g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + (b0 + b) * 32 + 8 * g + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float* s_par = reinterpret_cast<float*>(smem + W_B + R * SLOT_B);      // MODE 2: [CO][4] = scale, shift, rstd, -mean*rstd
+    if constexpr (MODE == 2) {
+        if (tid < CO) {
+            const int n_img = ((int)blockIdx.x * p.run) / (p.tiles_x * p.tiles_y);
+            const size_t NC = (size_t)p.N * CO, i = (size_t)n_img * CO + tid;
+            const float mean = p.nstats[i], rstd = p.nstats[NC + i];
+            *reinterpret_cast<f32x4*>(s_par + 4 * tid) = f32x4{p.nstats[2 * NC + i], p.nstats[3 * NC + i], rstd, -mean * rstd};
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weights + bias have landed (before any counted wait below)
 
     const bf16_t* W16 = reinterpret_cast<const bf16_t*>(smem);
@@ -143,15 +161,29 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
     if (R == 3) issue(l + l_step, 1);
     for (int it = 0; l < l_end; ++it, l += l_step) {
         // DMA(it) must have landed; younger operations, in issue order: [R == 3: stores(it-2), DMA(it+1)], stores(it-1)
+        // (MODE 2 adds ZL hand-issued loads per iteration, issued BEFORE that iteration's DMA)
         if (R == 3) {
             if (it == 0) wait_vm<D>();
-            else if (it == 1) wait_vm<D + S>();
-            else wait_vm<D + 2 * S>();
+            else if (it == 1) wait_vm<ZL + D + S>();
+            else wait_vm<ZL + D + 2 * S>();
         } else {
             if (it == 0) wait_vm<0>();
             else wait_vm<S>();
         }
         __syncthreads();        // tile `it` is complete for every wave, and nobody reads the slot of tile it-1 any more
+        const int tile = tile_of(l);
+        const int tx = tile % p.tiles_x, rest = tile / p.tiles_x;
+        const int ty = rest % p.tiles_y, n = rest / p.tiles_y;
+        const size_t opix = ((size_t)n * p.H + ty * TH + row) * p.W + tx * 32 + r;
+        u32x2 zq[MODE == 2 ? NBW : 1][4];
+        if constexpr (MODE == 2) {
+            const bf16_t* zp = reinterpret_cast<const bf16_t*>(p.nz) + opix * CO + b0 * 32 + 4 * h;
+#pragma unroll
+            for (int b = 0; b < NBW; ++b)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(zq[b][g]) : "v"(zp + b * 32 + 8 * g) : "memory");
+        }
         issue(l + (R - 1) * l_step, (it + R - 1) % R);
         const bf16_t* X16 = reinterpret_cast<const bf16_t*>(smem + W_B + (it % R) * SLOT_B);
 
@@ -177,7 +209,7 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
             }
         }
 
-        if constexpr (STATS) {
+        if constexpr (MODE == 1) {
 #pragma unroll
             for (int b = 0; b < NBW; ++b)
 #pragma unroll
@@ -186,11 +218,29 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
                     ssq[b][i] = fmaf(acc[b][i], acc[b][i], ssq[b][i]);
                 }
         }
+        if constexpr (MODE == 2) {
+            // the z loads are older than this iteration's D DMA instructions: wait for them only (the asm ties the
+            // registers to the wait, so no use is scheduled above it)
+#pragma unroll
+            for (int b = 0; b < NBW; ++b)
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(zq[b][0]), "+v"(zq[b][1]), "+v"(zq[b][2]), "+v"(zq[b][3]) : "n"(D) : "memory");
+#pragma unroll
+            for (int b = 0; b < NBW; ++b)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned wd = zq[b][g][e >> 1];
+                        const float zf = __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16));
+                        const f32x4 pr = *reinterpret_cast<const f32x4*>(s_par + 4 * ((b0 + b) * 32 + 8 * g + 4 * h + e));
+                        const float gv = acc[b][4 * g + e];
+                        const float gl = zf * pr[0] + pr[1] > 0.f ? gv : gv * p.nslope;
+                        ssum[b][4 * g + e] += gl;
+                        ssq[b][4 * g + e] = fmaf(gl, fmaf(zf, pr[2], pr[3]), ssq[b][4 * g + e]);
+                    }
+                }
+        }
         // ---- epilogue: register i of a block = channel (i & 3) + 8 * (i >> 2) + 4 * h of pixel r
-        const int tile = tile_of(l);
-        const int tx = tile % p.tiles_x, rest = tile / p.tiles_x;
-        const int ty = rest % p.tiles_y, n = rest / p.tiles_y;
-        const size_t opix = ((size_t)n * p.H + ty * TH + row) * p.W + tx * 32 + r;
 #pragma unroll
         for (int b = 0; b < NBW; ++b) {
             const int colb = (b0 + b) * 32;
@@ -245,7 +295,7 @@ template <int CIP, int NB, int TH, int R>
 int launch_tc(TcArgs& a, hipStream_t st) {
     constexpr int HPAD = ((TH + 2) * 34 + 15) / 16 * 16;
     constexpr int D = (CIP * HPAD * 4 + 511) / 512, WD = (CIP * 9 * 32 * NB * 4 + 511) / 512;
-    const size_t lds = (size_t)WD * 8192 + (size_t)R * D * 8192;
+    const size_t lds = (size_t)WD * 8192 + (size_t)R * D * 8192 + 1024;      // + the MODE 2 parameter table
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;       // workgroups that fit a CU (LDS; <= 128 VGPRs in every instance)
     int grid = a.ntiles < 256 * per_cu ? a.ntiles : 256 * per_cu;
     // statistics: every workgroup needs a run of consecutive tiles inside ONE image
@@ -253,7 +303,7 @@ int launch_tc(TcArgs& a, hipStream_t st) {
     const bool stats = a.stat_sums && a.ntiles % grid == 0 && per_img % (a.ntiles / grid) == 0;
     if (!stats) a.stat_sums = nullptr;
     a.run = stats ? a.ntiles / grid : 0;
-    auto k = stats ? tconv_kernel<CIP, NB, TH, R, true> : tconv_kernel<CIP, NB, TH, R, false>;
+    auto k = !stats ? tconv_kernel<CIP, NB, TH, R, 0> : (a.nz ? tconv_kernel<CIP, NB, TH, R, 2> : tconv_kernel<CIP, NB, TH, R, 1>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     CU_CHECK_ARG(e == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
@@ -263,10 +313,10 @@ int launch_tc(TcArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// 2 = launched and the statistics were gathered, 1 = launched, 0 = not this kernel's shape, < 0 = error.  Called by
-// cu_conv_gemm for plain bf16 operands.  stat_sums ([N][CO][2] f32, zero on entry) or NULL.
+// 2 = launched and the sums were gathered, 1 = launched, 0 = not this kernel's shape, < 0 = error.  Called by cu_conv_gemm
+// for plain bf16 operands.  ep (or NULL): the epilogue extension of cu_conv_gemm_ex.
 int cu_tconv_try(const cu_conv_desc* d, const void* src0, const void* src1, const void* w, const float* bias, void* dst0,
-                 void* dst1, float* stat_sums, void* stream) {
+                 void* dst1, const cu_conv_epilogue* ep, void* stream) {
     if (d->dtype != CU_BF16 || d->ntaps != 9 || d->IS != 1 || d->OS != 1 || d->OY0 || d->OX0 || d->out_nchw_f32 ||
         d->par_co || d->accum0 || d->accum1 || d->slope0 != 1.0f || (d->C1 && d->slope1 != 1.0f))
         return 0;
@@ -286,7 +336,10 @@ int cu_tconv_try(const cu_conv_desc* d, const void* src0, const void* src1, cons
     a.src0_bytes = (unsigned)b0; a.src1_bytes = (unsigned)b1; a.w_bytes = (unsigned)((size_t)9 * d->CO * CI * 2);
     a.N = d->N; a.H = d->PH; a.W = d->PW; a.C0 = d->C0; a.C1 = d->C1;
     a.D0 = d->D0; a.DC0 = d->DC0; a.DC1 = d->DC1;
-    a.stat_sums = two ? nullptr : stat_sums;
+    if (ep && !two && ep->sums && (ep->mode == 1 || (ep->mode == 2 && ep->z && ep->stats && !bias))) {
+        a.stat_sums = ep->sums;
+        if (ep->mode == 2) { a.nz = ep->z; a.nstats = ep->stats; a.nslope = ep->slope; }
+    }
     for (int t = 0; t < 9; ++t) {
         if (d->tap_dy[t] < -1 || d->tap_dy[t] > 1 || d->tap_dx[t] < -1 || d->tap_dx[t] > 1 || d->tap_w[t] < 0 || d->tap_w[t] > 8)
             return 0;
@@ -300,7 +353,8 @@ int cu_tconv_try(const cu_conv_desc* d, const void* src0, const void* src1, cons
     // per CU beat three slots and one workgroup (32 -> 32: 129 vs 143 us forward, 130 vs 162 us input gradient); for the
     // two-destination input gradient the 4-row tile that would fit two workgroups loses to 8 rows x 3 slots (248 vs 237)
     const int var = cu_env_int("CU_TCONV_VAR", 1);      // tuning knob: 0 = three slots, one workgroup per CU
-    if (CI == 32 && d->CO == 32) return var == 1 ? launch_tc<1, 1, 8, 2>(a, st) : launch_tc<1, 1, 8, 3>(a, st);
+    // (the norm-backward epilogue needs 146 registers: one workgroup per CU either way, so it takes the three-slot ring)
+    if (CI == 32 && d->CO == 32) return (var == 1 && !a.nz) ? launch_tc<1, 1, 8, 2>(a, st) : launch_tc<1, 1, 8, 3>(a, st);
     if (CI == 32 && d->CO == 64) return launch_tc<1, 2, 8, 3>(a, st);
     if (CI == 64 && d->CO == 32) return launch_tc<2, 1, 8, 2>(a, st);
     return launch_tc<2, 2, 4, 2>(a, st);

@@ -128,6 +128,9 @@ class UNetEngine:
         # resident-chunk launch that reads every tensor once (norm.hip); False: the two-pass kernels
         self.fused_norm = True
         self.fused_stats = os.environ.get("CONTOUR_FUSED_STATS", "1") != "0"
+        self.fused_norm_bwd = os.environ.get("CONTOUR_FUSED_NORM_BWD", "1") != "0"
+        self._given_sums: Dict[str, Tensor] = {}       # layer prefix -> norm-backward sums gathered by the producer of its g
+        self._producer: Dict[int, str] = {}            # id(Act) of a layer's output -> its prefix (valid for one step)
         # Dropout2d(p=0.5) between conv and norm in the listed ConvLayers (reference unet2.py:129-136,302: the last
         # downsample block and the bottleneck when task.model.drop_block=True); active in training mode only
         self.drop_layers: set = set()
@@ -209,6 +212,7 @@ class UNetEngine:
             if not ctx.keep and out.a is not None:
                 return Act(out.a, None, 1.0)
             ctx.convs[prefix] = _ConvRec(prefix, srcs, out, stride, drop_mask=None)
+            self._producer[id(out)] = prefix
             return out
         mask = None
         if ctx.training and prefix in self.drop_layers:
@@ -222,6 +226,7 @@ class UNetEngine:
         if not ctx.keep and out.a is not None:
             return Act(out.a, None, 1.0)      # inference: z, the statistics and the layer record die here
         ctx.convs[prefix] = _ConvRec(prefix, srcs, out, stride, drop_mask=mask)
+        self._producer[id(out)] = prefix
         return out
 
     def _norm_act_fwd(self, P, prefix: str, z: Tensor) -> Act:
@@ -250,6 +255,7 @@ class UNetEngine:
         if not ctx.keep and out.a is not None:
             return Act(out.a, None, 1.0)
         ctx.convs[prefix] = _ConvRec(prefix, [], out, 1, first=True)
+        self._producer[id(out)] = prefix
         return out
 
     def _block_fwd(self, P, ctx, prefix: str, srcs: List[Act], stride: int) -> Act:
@@ -284,6 +290,7 @@ class UNetEngine:
         st = self.strides
         assert st[0] == 1
         self._arena["fwd"].begin(img.device)
+        self._producer.clear()
         self._prep_all(P)
         a = self._first_layer_fwd(P, ctx, "input_block.conv1", img)
         a = self._conv_layer_fwd(P, ctx, "input_block.conv2", [a], 1)
@@ -359,7 +366,11 @@ class UNetEngine:
             self.debug[f"{prefix}:da"] = g.float().clone()
         # d(conv bias) = sum_p dz is identically zero behind an InstanceNorm (dz has zero mean per (n, c)); the reference
         # accumulates rounding noise there.  G[conv.bias] stays exactly 0 (no kernel work, no atomics contention).
-        if self.fused_norm:
+        given = self._given_sums.pop(prefix, None)
+        if given is not None:          # the launch that produced g already did the reduction pass (tconv epilogue)
+            ops.instnorm_bwd_given(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
+                                   G[f"{prefix}.norm.bias"], given)
+        elif self.fused_norm:
             ws = self._arena["bwd"].take(ops.resident_ws_floats(g.shape[0], g.shape[3]), g.device)
             ops.instnorm_bwd_fused(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
                                    G[f"{prefix}.norm.bias"], ws, mode=ops.NORM_WS_CLEAN)
@@ -392,8 +403,18 @@ class UNetEngine:
         gz = Act(g, None, 1.0)
         sh, sw = rec.srcs[0].z.shape[1:3]
         if rec.stride == 1:
-            ops.conv_gemm([gz], wd, None, grid=(sh, sw), in_stride=1, taps=TAPS3_D, dsts=dsts, dst_cols=cols,
-                          accum=acc)
+            # single destination = the output gradient of the layer that feeds this one: its norm backward's reduction
+            # pass can ride in this launch's epilogue (thin, large layers; no Dropout2d between its conv and norm)
+            nb = None
+            src = rec.srcs[0] if len(rec.srcs) == 1 else None
+            tgt = self._producer.get(id(src)) if src is not None else None
+            if (tgt is not None and self.fused_norm_bwd and self.fused_norm and self.dtype == torch.bfloat16 and not acc[0]
+                    and n * sh * sw >= (1 << 20) and ctx.convs[tgt].drop_mask is None and ctx.convs[tgt].out.stats is not None):
+                nb = (ctx.convs[tgt].out, self._arena["bwd"].take(2 * n * cols[0], g.device))
+            got = ops.conv_gemm([gz], wd, None, grid=(sh, sw), in_stride=1, taps=TAPS3_D, dsts=dsts, dst_cols=cols,
+                                accum=acc, norm_bwd=nb)
+            if got:
+                self._given_sums[tgt] = nb[1]
         elif ONE_PASS_S2_DGRAD and self.dtype == torch.bfloat16 and len(dsts) == 1 and cols[0] % 32 == 0:
             # all four input parities in one pass: gather taps = the 2x2 neighbourhood of dz, the weight tap of
             # (gather tap, parity) from S2_PARITY_TAPS (9 of the 16 pairs exist, the others are skipped); dz is read once.
@@ -433,6 +454,7 @@ class UNetEngine:
         last = ctx.last
         n, h, w_, c_last = last.z.shape
         self._arena["bwd"].begin(last.z.device)
+        self._given_sums.clear()
         # ---- 1x1 output conv
         if dl_nhwc is not None:
             assert dl_nhwc.dtype == dt and dl_nhwc.shape == (n, h, w_, 32)

@@ -32,6 +32,10 @@ class ConvDesc(C.Structure):
     ]
 
 
+class ConvEpilogue(C.Structure):      # cu_conv_epilogue
+    _fields_ = [("mode", C.c_int), ("sums", C.c_void_p), ("z", C.c_void_p), ("stats", C.c_void_p), ("slope", C.c_float)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("N", C.c_int), ("PH", C.c_int), ("PW", C.c_int), ("SH", C.c_int), ("SW", C.c_int),
@@ -50,6 +54,7 @@ _SIGS = {
     "cu_conv_gemm": (C.c_int, [C.POINTER(ConvDesc)] + [_P] * 11),
     "cu_conv_gemm_ws": (C.c_int, [C.POINTER(ConvDesc)] + [_P] * 11 + [C.c_size_t, _P]),
     "cu_conv_gemm_stats": (C.c_int, [C.POINTER(ConvDesc)] + [_P] * 11 + [C.c_size_t, _P, C.POINTER(C.c_int), _P]),
+    "cu_conv_gemm_ex": (C.c_int, [C.POINTER(ConvDesc)] + [_P] * 11 + [C.c_size_t, C.POINTER(ConvEpilogue), C.POINTER(C.c_int), _P]),
     "cu_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc)] + [_P] * 9),
     "cu_conv_c1_fwd": (C.c_int, [C.c_int] * 5 + [_P] * 5),
     "cu_conv_c1_wgrad": (C.c_int, [C.c_int] * 5 + [_P] * 4),
@@ -59,6 +64,7 @@ _SIGS = {
     "cu_instnorm_resident_ws_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "cu_instnorm_fwd_fused": (C.c_int, [C.c_int] * 4 + [_P] * 3 + [C.c_float, C.c_float] + [_P] * 3 + [C.c_int, _P]),
     "cu_instnorm_fwd_given": (C.c_int, [C.c_int] * 4 + [_P] * 3 + [C.c_float, C.c_float] + [_P] * 5),
+    "cu_instnorm_bwd_given": (C.c_int, [C.c_int] * 4 + [_P] * 4 + [C.c_float] + [_P] * 4),
     "cu_instnorm_bwd_fused": (C.c_int, [C.c_int] * 4 + [_P] * 4 + [C.c_float] + [_P] * 3 + [C.c_int, _P]),
     "cu_channel_scale": (C.c_int, [C.c_int] * 4 + [_P] * 3),
     "cu_maxpool2_fwd": (C.c_int, [C.c_int] * 5 + [_P] * 4),

@@ -82,7 +82,8 @@ def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: T
               taps: Sequence[Tuple[int, int, int]], dsts: Sequence[Tensor], dst_cols: Sequence[int],
               out_stride: int = 1, out_off: Tuple[int, int] = (0, 0), accum: Sequence[int] = (0, 0),
               out_nchw: bool = False, n_cols: Optional[int] = None, parity_cols: int = 0,
-              parity_taps: Optional[Sequence[int]] = None, stat_sums: Optional[Tensor] = None) -> bool:
+              parity_taps: Optional[Sequence[int]] = None, stat_sums: Optional[Tensor] = None,
+              norm_bwd: Optional[Tuple[Act, Tensor]] = None) -> bool:
     """D[p, n] = bias[n] + sum_t sum_c act(S[p*IS + off_t, c]) W[tap_w[t]][n][c]  (cu_conv_gemm).
     ``parity_taps`` (16 ints, with ``parity_cols``): weight tap of (gather tap t, parity group g) at [t*4+g], -1 = none."""
     lib = L.load()
@@ -128,13 +129,19 @@ def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: T
     ws = _split_k_ws(t0.device)
     import ctypes as _C
     done = _C.c_int(0)
+    ep = None
+    if stat_sums is not None:                 # forward: the output's InstanceNorm statistics (sums of z - bias)
+        ep = L.ConvEpilogue(1, L.ptr(stat_sums), None, None, 1.0)
+    elif norm_bwd is not None:                # input gradient: the reduction pass of the target layer's norm backward
+        tgt, sums = norm_bwd
+        ep = L.ConvEpilogue(2, L.ptr(sums), L.ptr(tgt.z), L.ptr(tgt.stats), float(tgt.slope))
     with _Prof("igemm_conv", flops, note, nbytes):
-        rc = lib.cu_conv_gemm_stats(d, L.ptr(t0), L.ptr(sc0), L.ptr(sh0), L.ptr(t1), L.ptr(sc1), L.ptr(sh1), L.ptr(w),
-                                    L.ptr(bias), L.ptr(dst0), L.ptr(dsts[1]) if len(dsts) > 1 else None, L.ptr(ws),
-                                    ws.numel(), L.ptr(stat_sums), _C.byref(done) if stat_sums is not None else None,
-                                    L.stream_ptr())
-    L.check(rc, "cu_conv_gemm_stats")
-    return bool(done.value)          # True: stat_sums (N, CO, 2; zero on entry) now holds the output's statistics sums
+        rc = lib.cu_conv_gemm_ex(d, L.ptr(t0), L.ptr(sc0), L.ptr(sh0), L.ptr(t1), L.ptr(sc1), L.ptr(sh1), L.ptr(w),
+                                 L.ptr(bias), L.ptr(dst0), L.ptr(dsts[1]) if len(dsts) > 1 else None, L.ptr(ws),
+                                 ws.numel(), _C.byref(ep) if ep is not None else None,
+                                 _C.byref(done) if ep is not None else None, L.stream_ptr())
+    L.check(rc, "cu_conv_gemm_ex")
+    return bool(done.value)          # True: the epilogue's sums (N, CO, 2; zero on entry) were gathered by this launch
 
 
 _SPLIT_K_WS: Dict[str, Tensor] = {}
@@ -269,6 +276,15 @@ def instnorm_fwd_given(z: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor
                                                slope, L.ptr(sums), L.ptr(shift), L.ptr(stats), L.ptr(out), L.stream_ptr()),
                 "cu_instnorm_fwd_given")
     return Act(z, stats, slope, out, None)
+
+
+def instnorm_bwd_given(g: Tensor, act: Act, gamma: Optional[Tensor], dgamma, dbeta, sums: Tensor):
+    """In place g -> dL/dz from the two sums the producing input-gradient launch gathered (cu_instnorm_bwd_given)."""
+    n, h, w_, c = g.shape
+    with _Prof("instnorm_bwd", 0.0, f"N{n} {h}x{w_} C{c}", 3 * g.numel() * g.element_size()):
+        L.check(L.load().cu_instnorm_bwd_given(L.dtype_code(g.dtype), n, h * w_, c, L.ptr(g), L.ptr(act.z), L.ptr(act.stats),
+                                               L.ptr(gamma), act.slope, L.ptr(dgamma), L.ptr(dbeta), L.ptr(sums),
+                                               L.stream_ptr()), "cu_instnorm_bwd_given")
 
 
 def instnorm_bwd_fused(g: Tensor, act: Act, gamma: Optional[Tensor], dgamma, dbeta, ws: Optional[Tensor] = None,

@@ -94,6 +94,24 @@ int cu_conv_gemm_stats(const cu_conv_desc* d,
                        const void* w, const float* bias, void* dst0, void* dst1, float* ws, size_t ws_floats,
                        float* stat_sums, int* stats_done, void* stream);
 
+/* General form of the epilogue extension.  mode 1 = as cu_conv_gemm_stats.  mode 2 = this launch is the INPUT GRADIENT
+ * g = dL/da of a layer a = LeakyReLU(scale * z + shift) (InstanceNorm + LeakyReLU, layers.py:193-194): sums [N][CO][2]
+ * (zero on entry) += {sum of gl, sum of gl * zhat} with gl = g * LeakyReLU'(scale z + shift), zhat = (z - mean) * rstd --
+ * the reduction pass of that layer's norm backward (z [N][H][W][CO] of the launch's dtype, stats = the four planes of
+ * cu_instnorm_stats).  Consumer: cu_instnorm_bwd_given.  *done as in cu_conv_gemm_stats. */
+typedef struct {
+    int mode;
+    float* sums;
+    const void* z;
+    const float* stats;
+    float slope;
+} cu_conv_epilogue;
+int cu_conv_gemm_ex(const cu_conv_desc* d,
+                    const void* src0, const float* scale0, const float* shift0,
+                    const void* src1, const float* scale1, const float* shift1,
+                    const void* w, const float* bias, void* dst0, void* dst1, float* ws, size_t ws_floats,
+                    const cu_conv_epilogue* ep, int* done, void* stream);
+
 /* Weight gradient of the same gather convolution:  dW[t][n][c] += sum_p Z[p*ZS + zoff_t, n] * act(S[p*IS + off_t, c])
  * (autograd of nn.Conv2d / nn.ConvTranspose2d weights).  dW is f32, accumulated with atomics. */
 typedef struct {
@@ -161,6 +179,9 @@ int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* z, const 
 int cu_instnorm_fwd_given(int dtype, int N, int HW, int C, const void* z, const float* gamma, const float* beta,
                           float eps, float slope, const float* sums, const float* shift, float* stats, void* out,
                           void* stream);
+/* backward from the two sums a convolution epilogue gathered (cu_conv_gemm_ex mode 2): the apply pass only. */
+int cu_instnorm_bwd_given(int dtype, int N, int HW, int C, void* g, const void* z, const float* stats,
+                          const float* gamma, float slope, float* dgamma, float* dbeta, const float* sums, void* stream);
 int cu_instnorm_bwd_fused(int dtype, int N, int HW, int C, void* g, const void* z, const float* stats,
                           const float* gamma, float slope, float* dgamma, float* dbeta, float* ws, int mode,
                           void* stream);

@@ -662,9 +662,30 @@ def test_thin_streaming_conv(case):
     gx = F.conv_transpose2d(dz, wq, None, padding=1)
     gz = ops.Act(nhwc(dz, dtype), None, 1.0)
     if ci in (32, 64) and co in (32, 64):
+        # ... with the reduction pass of the TARGET layer's InstanceNorm backward in the epilogue (cu_conv_gemm_ex mode 2):
+        # the launch produces g = dL/da of a layer a = LeakyReLU(scale z + shift) and the sums of gl and gl * zhat
+        zt = rq(torch.randn(n, ci, size, size, device=DEV, generator=g), dtype)
+        gm = 1 + 0.1 * torch.randn(ci, device=DEV, generator=g)
+        bt = 0.1 * torch.randn(ci, device=DEV, generator=g)
+        tgt = ops.Act(nhwc(zt, dtype), None, 0.01)
+        tgt.stats = ops.instnorm_stats(tgt.z, gm, bt)
+        sums = torch.zeros(n, ci, 2, device=DEV)
         d0 = torch.empty(n, size, size, ci, device=DEV, dtype=dtype)
-        ops.conv_gemm([gz], wd, None, grid=(size, size), in_stride=1, taps=TAPS3_D, dsts=[d0], dst_cols=[ci])
+        got = ops.conv_gemm([gz], wd, None, grid=(size, size), in_stride=1, taps=TAPS3_D, dsts=[d0], dst_cols=[ci],
+                            norm_bwd=(tgt, sums))
         assert rel_err(nchw(d0), gx) < tol(dtype)
+        assert got == (n != 20)
+        if got:
+            mean, rstd, scale, shift = (tgt.stats[i][:, :, None, None] for i in range(4))
+            gl = torch.where(zt * scale + shift > 0, gx, gx * 0.01)
+            zhat = (zt - mean) * rstd
+            assert rel_err(sums[..., 0], gl.sum((2, 3))) < 5e-3 and rel_err(sums[..., 1], (gl * zhat).sum((2, 3))) < 5e-3
+            # the apply pass from those sums == the two-pass backward
+            g1, g2 = d0.clone(), d0.clone()
+            dg1, db1, dg2, db2 = (torch.zeros(ci, device=DEV) for _ in range(4))
+            ops.instnorm_bwd_given(g1, tgt, gm, dg1, db1, sums)
+            ops.instnorm_lrelu_bwd(g2, tgt, gm, dg2, db2, None)
+            assert rel_err(g1.float(), g2.float()) < 1e-2 and rel_err(dg1, dg2) < 1e-2 and rel_err(db1, db2) < 1e-2
     if ci == 64 and co == 32:
         da = torch.empty(n, size, size, 32, device=DEV, dtype=dtype)
         db = torch.empty(n, size, size, 32, device=DEV, dtype=dtype)

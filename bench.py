@@ -7,11 +7,15 @@
 
 A "step" = one full training step of the hot path (U-Net forward, skew head, DSNT head + skew-normal NLL, hand-written
 backward, RCCL gradient all-reduce for N > 1, fused Adam) on one synthetic minibatch already resident in HBM.
-Per-GPU batch is fixed (64, BASELINE.json configs[2] / configs[3] = 512 over 8 GPUs), so scaling is "weak".
+Default: the per-GPU batch is fixed (64, BASELINE.json configs[2] / configs[3] = 512 over 8 GPUs), "scaling": "weak";
+--scaling strong fixes the GLOBAL batch (--batch) and splits it over the GPUs.  The eager step runs its weight gradients on
+a second HIP stream; up to 16 images per GPU (one GPU) the step is replayed as one hipGraph instead (--graph).
 
 Prints ONE JSON line on rank 0 with the driver's contract plus:
   roofline     : the dominant kernel family (MFMA implicit-GEMM convolution), algorithmic FLOPs / measured launch time
-                 (HIP events on the launch stream, in a separate profiled pass after the timed region) vs 2.5 PFLOP/s.
+                 (HIP events on the launch stream, in a separate profiled pass after the timed region, with the step on
+                 ONE stream so that an event pair times one launch) vs 2.5 PFLOP/s; traffic = HBM bytes per launch from
+                 the committed PMC passes (profiles/r02_pmc_hbm_traffic.json).
   cpu_baseline : the CPU oracle (PyTorch-CPU restatement of the reference step, kind "port") timed on this box's host
                  cores on a bounded sample of the same workload.
 """
@@ -242,7 +246,7 @@ def main():
             famrec = json.loads(pmc.read_text())["families"].get(name)
             if famrec:
                 traffic = round(famrec["bytes_per_launch"])
-        symbols = {"igemm_conv": "igemm_conv_kernel<*> + igemm_conv_dma_kernel<*> + pconv_kernel<*> (all instantiations; + ksplit_finish_kernel)",
+        symbols = {"igemm_conv": "igemm_conv_kernel<*> + igemm_conv_dma_kernel<*> + igemm_conv_dma_ring_kernel + pconv_kernel<*> + tconv_kernel<*> (all instantiations; + ksplit_finish_kernel)",
                    "igemm_wgrad": "igemm_wgrad_kernel<*> + igemm_wgrad_dma_kernel<*> (all instantiations)"}
         result["roofline"] = {"bound": "mfma", "kernel": name, "kernel_symbols": symbols.get(name, name),
                               "achieved": round(achieved, 2),

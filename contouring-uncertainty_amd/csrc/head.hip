@@ -27,76 +27,85 @@ __device__ __forceinline__ float block_sum(float v, float* lds) {
     return r;
 }
 
+__device__ __forceinline__ double block_sum_f64(double v, double* lds) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += lds[w];
+    return r;
+}
+
+// One workgroup per heat map, ONE streaming pass (round 1 read every map twice: maximum, then moments about the arg-max,
+// 704 MB per step at batch 64).  Every thread keeps a running maximum m and the raw moments of w = exp(v - m) in f64,
+// rescaled when its maximum grows (online softmax); at the end the threads' moments are brought to the common maximum
+// and summed.  f64 for the accumulation and the final E[x^2] - E[x]^2 is what replaces the centring: the variance of a
+// sharp off-centre peak (sigma ~ 1e-2 in normalised units) loses 2500x in that subtraction, 1e-16 * 2500 is nothing.
+// The f32 rounding of expf and of the rescaling factors only re-weights pixels by 1e-7 (no cancellation involved).
 __global__ __launch_bounds__(HT) void dsnt_fwd_kernel(const float* __restrict__ logits, int H, int W, int use_covar,
                                                       float* __restrict__ mu, float* __restrict__ sigma,
                                                       float* __restrict__ aux) {
     __shared__ float lds[16];
-    __shared__ int lidx[4];
+    __shared__ double ldd[16];
     const int map = blockIdx.x;
     const int HWn = H * W;
     const float* lp = logits + (size_t)map * HWn;
     const int tid = threadIdx.x;
     const int nvec = HWn >> 2;
+    const float invW = 1.f / (float)W;       // normalised coordinates (utils.py:50-68): lin[j] = (2j + 1)/W - 1
 
-    // ---- pass 1: max + arg-max (first occurrence)
-    float mx = -INFINITY;
-    int mi = 0;
+    float m = -INFINITY;
+    double s0 = 0.0, sx = 0.0, sy = 0.0, sxx = 0.0, syy = 0.0, sxy = 0.0;
     for (int i = tid; i < nvec; i += HT) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(lp + 4 * i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (v[e] > mx) { mx = v[e]; mi = 4 * i + e; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float om = __shfl_xor(mx, o, 64);
-        const int oi = __shfl_xor(mi, o, 64);
-        if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
-    }
-    if ((tid & 63) == 0) { lds[tid >> 6] = mx; lidx[tid >> 6] = mi; }
-    __syncthreads();
-    mx = lds[0]; mi = lidx[0];
-    for (int w = 1; w < HT / 64; ++w)
-        if (lds[w] > mx || (lds[w] == mx && lidx[w] < mi)) { mx = lds[w]; mi = lidx[w]; }
-    __syncthreads();
-
-    // normalised coordinates (utils.py:50-68): lin[j] = (2j + 1)/W - 1
-    const float invW = 1.f / (float)W;
-    const int cy = mi / W, cx = mi - cy * W;
-    const float x0 = (2.f * cx + 1.f) * invW - 1.f, y0 = (2.f * cy + 1.f) * invW - 1.f;
-
-    // ---- pass 2: moments about (x0, y0)
-    float s0 = 0.f, sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
-    for (int i = tid; i < nvec; i += HT) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(lp + 4 * i);
+        const float lm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        if (lm > m) {
+            const double sc = m == -INFINITY ? 0.0 : (double)expf(m - lm);
+            s0 *= sc; sx *= sc; sy *= sc; sxx *= sc; syy *= sc; sxy *= sc;
+            m = lm;
+        }
         const int p = 4 * i;
         const int yy = p / W, xx = p - yy * W;      // W % 4 == 0: the 4 elements share a row
-        const float dy = (2.f * yy + 1.f) * invW - 1.f - y0;
+        const double Y = (double)((2.f * yy + 1.f) * invW - 1.f);
+        double r0 = 0.0, rx = 0.0, rxx = 0.0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float w = expf(v[e] - mx);
-            const float dx = (2.f * (xx + e) + 1.f) * invW - 1.f - x0;
-            s0 += w; sx += w * dx; sy += w * dy;
-            sxx += w * dx * dx; syy += w * dy * dy; sxy += w * dx * dy;
+            const double w = (double)expf(v[e] - m);
+            const double X = (double)((2.f * (xx + e) + 1.f) * invW - 1.f);
+            r0 += w; rx += w * X; rxx += w * X * X;
         }
+        s0 += r0; sx += rx; sxx += rxx;
+        sy += r0 * Y; syy += r0 * Y * Y; sxy += rx * Y;
     }
-    s0 = block_sum(s0, lds); sx = block_sum(sx, lds); sy = block_sum(sy, lds);
-    sxx = block_sum(sxx, lds); syy = block_sum(syy, lds); sxy = block_sum(sxy, lds);
+    // ---- common maximum, then the sums
+    float mx = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) lds[tid >> 6] = mx;
+    __syncthreads();
+    mx = lds[0];
+    for (int w = 1; w < HT / 64; ++w) mx = fmaxf(mx, lds[w]);
+    const double sc = m == -INFINITY ? 0.0 : (double)expf(m - mx);
+    s0 = block_sum_f64(s0 * sc, ldd); sx = block_sum_f64(sx * sc, ldd); sy = block_sum_f64(sy * sc, ldd);
+    sxx = block_sum_f64(sxx * sc, ldd); syy = block_sum_f64(syy * sc, ldd); sxy = block_sum_f64(sxy * sc, ldd);
     if (tid == 0) {
-        const float inv = 1.f / s0;
-        const float mxr = sx * inv, myr = sy * inv;            // mean relative to (x0, y0)
-        const float xbar = x0 + mxr, ybar = y0 + myr;
-        const float vx = sxx * inv - mxr * mxr, vy = syy * inv - myr * myr;
-        const float cv = sxy * inv - mxr * myr;
-        const float half = 0.5f * (float)W;                    // image_size / 2
+        const double inv = 1.0 / s0;
+        const double xbar = sx * inv, ybar = sy * inv;
+        const double vx = sxx * inv - xbar * xbar, vy = syy * inv - ybar * ybar;
+        const double cv = sxy * inv - xbar * ybar;
+        const double half = 0.5 * (double)W;                    // image_size / 2
         // normalized_to_pixel_coordinates: 0.5*((c + 1)*size - 1)
-        mu[2 * map] = 0.5f * ((xbar + 1.f) * (float)W - 1.f);
-        mu[2 * map + 1] = 0.5f * ((ybar + 1.f) * (float)H - 1.f);
-        sigma[3 * map] = vx * half * half;
-        sigma[3 * map + 1] = vy * half * half;
-        sigma[3 * map + 2] = use_covar ? cv * half * half : 0.f;
+        mu[2 * map] = (float)(0.5 * ((xbar + 1.0) * (double)W - 1.0));
+        mu[2 * map + 1] = (float)(0.5 * ((ybar + 1.0) * (double)H - 1.0));
+        sigma[3 * map] = (float)(vx * half * half);
+        sigma[3 * map + 1] = (float)(vy * half * half);
+        sigma[3 * map + 2] = use_covar ? (float)(cv * half * half) : 0.f;
         float* a = aux + 8 * (size_t)map;
-        a[0] = mx; a[1] = inv; a[2] = xbar; a[3] = ybar; a[4] = vx; a[5] = vy; a[6] = cv; a[7] = 0.f;
+        a[0] = mx; a[1] = (float)inv; a[2] = (float)xbar; a[3] = (float)ybar; a[4] = (float)vx; a[5] = (float)vy;
+        a[6] = (float)cv; a[7] = 0.f;
     }
 }
 

@@ -1122,7 +1122,9 @@ extern "C" int cu_conv_gemm_ex(const cu_conv_desc* d, const void* src0, const fl
         if (bf && plain0 && (d->IS == 1 || (d->IS == 2 && (d->CO % 128 == 0 || (d->CO > 256 && !cu_env_set("CU_CONV_S2_RAGGED_OFF"))))) && d->ntaps == 9 &&
             !d->out_nchw_f32 && d->CO >= (d->IS == 1 ? 32 : 128) && CI >= min_ci && d->C0 % 32 == 0 &&
             d->D0 % 32 == 0 && d->CO % 16 == 0 && !d->par_co && b0 < lim && b1 < lim && bw < lim &&
-            (px_all / dbm) * cdiv(d->CO, 32 * dnb) >= 128 && !cu_env_set("CU_CONV_NODMA")) {
+            // (64 workgroups are enough for the 960-column input gradient at 8x8: 78 vs 112 us on the generic kernel; the
+            // 480-column layers there lose on this kernel, 79 vs 39 us: tools/small_dma.py)
+            (px_all / dbm) * cdiv(d->CO, 32 * dnb) >= cu_env_int("CU_CONV_DMA_MINWG", d->CO >= 768 ? 64 : 128) && !cu_env_set("CU_CONV_NODMA")) {
             int tw = d->PW < 32 ? d->PW : 32;
             int th = dbm / tw;
             if (th > d->PH) th = d->PH;

@@ -64,6 +64,16 @@ res["sequence_gauss (1 ED/ES pair)"] = {"pairs_per_s": round(1 / dt, 2), "ms": r
 ss = SequenceSkewPSMSampler(psm_path, seq_path)
 dt = timeit(lambda: ss(pair_mu, cov[:2], alpha[:2], n=NS), reps=3)
 res["sequence_skew (1 ED/ES pair)"] = {"pairs_per_s": round(1 / dt, 2), "ms": round(dt * 1e3, 3)}
+# all pairs of F / 2 views in ONE launch set (sample_pairs; round 2)
+P = F // 2
+pmu = torch.stack([torch.tensor(seq["X_val"][i % seq["X_val"].shape[0]] + seq["scaler_mean"]).float().reshape(2, 21, 2)
+                   for i in range(P)]).cuda()
+pcov, palpha = cov[: 2 * P].reshape(P, 2, 21, 2, 2), alpha[: 2 * P].reshape(P, 2, 21, 2)
+firsts = torch.randint(0, 2, (P, NS), generator=g)
+dt = timeit(lambda: sq.sample_pairs(pmu, pcov, firsts), reps=3)
+res[f"sequence_gauss ({P} pairs, one launch set)"] = {"pairs_per_s": round(P / dt, 1), "ms": round(dt * 1e3, 3)}
+dt = timeit(lambda: ss.sample_pairs(pmu, pcov, palpha, firsts), reps=3)
+res[f"sequence_skew ({P} pairs, one launch set)"] = {"pairs_per_s": round(P / dt, 1), "ms": round(dt * 1e3, 3)}
 
 # samples -> filled masks -> entropy map, device-resident end to end
 from cu_hip import ops

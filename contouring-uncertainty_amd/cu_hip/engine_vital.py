@@ -14,9 +14,11 @@ Every operator is a launch of the same C ABI the nnU-Net path uses:
     of 32, four parity launches otherwise) and the 4-tap weight gradient;
   * the 1x1 output convolution (+ bias) writes NCHW float32 logits.
 
-Channel counts must be multiples of 32 in bf16 and of 16 in f32 (the kernels' K-chunk): ``init_channels=32`` (the
-reference default, 16 channels at full resolution) runs in f32; bf16 needs ``init_channels >= 64``.
-``dropout > 0`` and ``bilinear=True`` are refused (no config of the dsnt path sets them).
+Channel counts must be multiples of 32 in bf16 and of 16 in f32 (the kernels' K-chunk).  The reference default
+(``init_channels=32``: 16 channels at full resolution) therefore runs natively in f32; in bf16 the 16-channel tensors are
+carried as 32 channels whose upper half is identically zero: ``_pad_params`` builds zero-padded copies of the eleven
+parameter tensors that touch them (padded BatchNorm channels get gamma 1 / beta 0, so they stay zero through the ReLU),
+and ``backward`` slices the gradients back.  ``dropout > 0`` and ``bilinear=True`` are refused (no dsnt config sets them).
 """
 from __future__ import annotations
 
@@ -49,6 +51,7 @@ class VitalCtx:
     pools: List[Tensor] = field(default_factory=list)            # argmax bytes of the five poolings
     ups: List[Tuple[str, Act, Act]] = field(default_factory=list)  # (prefix, source, upsampled)
     last: Optional[Act] = None
+    P: Optional[Dict[str, Tensor]] = None
 
 
 class VitalUNetEngine:
@@ -59,13 +62,79 @@ class VitalUNetEngine:
         c = init_channels
         self.ch = [c // 2, c, 2 * c, 4 * c, 8 * c, 16 * c]
         self.num_classes, self.dtype, self.eps, self.momentum = num_classes, dtype, eps, momentum
+        self.pad16 = dtype == torch.bfloat16 and self.ch[0] == 16       # carry the 16-channel tensors as 32 channels
         need = 32 if dtype == torch.bfloat16 else 16
-        if self.ch[0] % need:
-            raise NotImplementedError(f"{self.ch[0]} channels at full resolution: the {dtype} kernels need multiples of "
-                                      f"{need} (use compute_dtype=f32, or init_channels >= 64 for bf16)")
+        if self.ch[0] % need and not self.pad16:
+            raise NotImplementedError(f"{self.ch[0]} channels at full resolution: the {dtype} kernels need multiples of {need}")
         if num_classes > 32:
             raise NotImplementedError("at most 32 output maps")
         self._opcache: Dict[str, Tuple] = {}
+
+    # ------------------------------------------------------------------------------------------------ 16 -> 32 channel padding
+    # name -> (dims padded on the output side, dims padded on the input side): conv weights are (O, I, kh, kw), transposed
+    # conv weights (I, O, kh, kw); "cat" = the input is the concat [skip 16 | up 16] -> [skip 16, 0 x 16, up 16, 0 x 16]
+    _PAD = {"layer1.net.0.weight": ("o", None), "layer1.net.0.bias": ("v", None), "layer1.net.1.weight": ("g", None),
+            "layer1.net.1.bias": ("v", None), "layer1.net.4.weight": ("o", "i"), "layer1.net.4.bias": ("v", None),
+            "layer1.net.5.weight": ("g", None), "layer1.net.5.bias": ("v", None), "layer2.net.1.net.0.weight": (None, "i"),
+            "layer11.upsample.weight": ("to", None), "layer11.upsample.bias": ("v", None),
+            "layer11.conv.net.0.weight": ("o", "cat"), "layer11.conv.net.0.bias": ("v", None),
+            "layer11.conv.net.1.weight": ("g", None), "layer11.conv.net.1.bias": ("v", None),
+            "layer11.conv.net.4.weight": ("o", "i"), "layer11.conv.net.4.bias": ("v", None),
+            "layer11.conv.net.5.weight": ("g", None), "layer11.conv.net.5.bias": ("v", None), "layer12.weight": (None, "i")}
+    _PAD_BUFFERS = ("layer1.net.1", "layer1.net.5", "layer11.conv.net.1", "layer11.conv.net.5")
+
+    @staticmethod
+    def _pad_tensor(t: Tensor, how) -> Tensor:
+        o, i = how
+        if o == "v":
+            return torch.cat([t, torch.zeros_like(t)])
+        if o == "g":
+            return torch.cat([t, torch.ones_like(t)])
+        if o == "o":
+            t = torch.cat([t, torch.zeros_like(t)], 0)
+        if o == "to":
+            t = torch.cat([t, torch.zeros_like(t)], 1)
+        if i == "i":
+            t = torch.cat([t, torch.zeros_like(t)], 1)
+        if i == "cat":
+            z = torch.zeros_like(t[:, :16])
+            t = torch.cat([t[:, :16], z, t[:, 16:], z], 1)
+        return t.contiguous()
+
+    @staticmethod
+    def _unpad_grad(gp: Tensor, how) -> Tensor:
+        o, i = how
+        if o in ("v", "g", "o"):
+            gp = gp[:16]
+        if o == "to":
+            gp = gp[:, :16]
+        if i == "i":
+            gp = gp[:, :16]
+        if i == "cat":
+            gp = torch.cat([gp[:, :16], gp[:, 32:48]], 1)
+        return gp
+
+    def _pad_params(self, P: Dict[str, Tensor], S: Dict[str, Tensor]):
+        if not self.pad16:
+            return P, S
+        P2 = dict(P)
+        for name, how in self._PAD.items():
+            P2[name] = self._pad_tensor(P[name].detach(), how)
+        S2 = dict(S)
+        for bn in self._PAD_BUFFERS:                      # padded running statistics: mean 0, variance 1 (never observed)
+            S2[f"{bn}.running_mean"] = torch.cat([S[f"{bn}.running_mean"], torch.zeros_like(S[f"{bn}.running_mean"])])
+            S2[f"{bn}.running_var"] = torch.cat([S[f"{bn}.running_var"], torch.ones_like(S[f"{bn}.running_var"])])
+            S2[f"{bn}.num_batches_tracked"] = S[f"{bn}.num_batches_tracked"].clone()
+        return P2, S2
+
+    def _unpad_buffers(self, S: Dict[str, Tensor], S2: Dict[str, Tensor]):
+        if not self.pad16:
+            return
+        with torch.no_grad():
+            for bn in self._PAD_BUFFERS:
+                S[f"{bn}.running_mean"].copy_(S2[f"{bn}.running_mean"][:16])
+                S[f"{bn}.running_var"].copy_(S2[f"{bn}.running_var"][:16])
+                S[f"{bn}.num_batches_tracked"].copy_(S2[f"{bn}.num_batches_tracked"])
 
     # ------------------------------------------------------------------------------------------------ operands
     def _operands(self, name: str, w: Tensor, kind: str, cop: Optional[int] = None):
@@ -158,6 +227,8 @@ class VitalUNetEngine:
         if h % 32 or w_ % 32:
             raise NotImplementedError("image sides must be multiples of 32 (five poolings; the reference pads otherwise)")
         img = img.contiguous()
+        S_user = S
+        P, S = self._pad_params(P, S)
         ctx = VitalCtx(img=img) if keep else None
         skips = [self._double_conv(P, S, ctx, "layer1.net", [img], training)]
         for k in range(2, 7):
@@ -177,8 +248,11 @@ class VitalUNetEngine:
         logits = torch.empty((n, self.num_classes, h, w_), dtype=torch.float32, device=img.device)
         ops.conv_gemm([out], wf, bias, grid=(h, w_), in_stride=1, taps=[(0, 0, 0)], dsts=[logits], dst_cols=[32],
                       out_nchw=True, n_cols=32)
+        if training:
+            self._unpad_buffers(S_user, S)
         if ctx is not None:
             ctx.last = out
+            ctx.P = P                         # the (padded) parameters the backward must use
         return logits, ctx
 
     # ------------------------------------------------------------------------------------------------ backward
@@ -215,6 +289,9 @@ class VitalUNetEngine:
 
     def backward(self, P: Dict[str, Tensor], G: Dict[str, Tensor], ctx: VitalCtx, dlogits: Tensor):
         """Accumulates every parameter gradient into G (float32, reference layouts)."""
+        if self.pad16:                               # gradients of the padded tensors, sliced back at the end
+            G_user, P = G, ctx.P
+            G = {k: (torch.zeros_like(P[k], dtype=torch.float32) if k in self._PAD else v) for k, v in G_user.items()}
         dt = self.dtype
         last = ctx.last
         n, h, w_, c_last = last.z.shape
@@ -258,3 +335,6 @@ class VitalUNetEngine:
         conv2, conv1 = layers.pop(), layers.pop()
         (g1,) = self._layer_bwd(P, G, ctx, conv2, g, True)
         self._layer_bwd(P, G, ctx, conv1, g1, False)
+        if self.pad16:
+            for name, how in self._PAD.items():
+                G_user[name] += self._unpad_grad(G[name], how)

@@ -411,7 +411,9 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
         } else {
             const int jz = j - p.s_iters;
             const int i = (tid + jz * NTHR) >> 2;
-            const int pl = (NBLK == 2 && i >= p.z_halo) ? 1 : 0;
+            int pl = 0;                     // 32-column plane of this item (NBLK planes, z_halo rows each)
+#pragma unroll
+            for (int q = 1; q < NBLK; ++q) pl += i >= q * p.z_halo ? 1 : 0;
             const int hp = i - pl * p.z_halo;
             const int im = __umulhi((unsigned)hp, p.mg_zhpi), rem = hp - im * z_hpi;
             const int hy = __umulhi((unsigned)rem, p.mg_zhw), hx = rem - hy * p.ZHW;
@@ -788,6 +790,20 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
         if (dma_nw == 8) CU_WDN(NBv, CBv, 8);                                   \
         CU_WDN(NBv, CBv, 4);                                                    \
     } while (0)
+        // 128 (n) x 64 (c) block per workgroup, eight computing waves (half the Z re-fetch of the 64 x 64
+        // block; 128-pixel tiles so that two images still fit): tuning knob CU_WGRAD_N128
+        if (wn && wc && d->ntaps == 9 && d->IS == 1 && d->ZS == 1 && d->CO >= 128 && cu_env_int("CU_WGRAD_N128", 0)) {
+            for (int BM = 128;; BM >>= 1) {
+                CU_CHECK_ARG(BM >= 32, "cu_conv_wgrad: patches do not fit in LDS");
+                const int rc = geometry(BM);
+                if (rc) return rc;
+                a.s_iters = cdiv(a.s_halo * 8, 512);
+                a.z_iters = cdiv(a.z_halo * 16, 512);
+                if ((size_t)(a.s_iters + a.z_iters) * 8192 <= (size_t)DMA_IMG_BYTES) break;
+            }
+            if (a.twl >= 4) return launch_dma<4, 2, 9, 8, false, true>(a, st);
+            return launch_dma<4, 2, 9, 8, false, false>(a, st);
+        }
         if (wn && wc) CU_WD(2, 2);
         if (wn) CU_WD(2, 1);
         if (wc) CU_WD(1, 2);

@@ -33,7 +33,26 @@ for size, c in shapes:
                                           taps=TAPS3_W, n_cols=c))
         row += f"{us:24.1f}"
     print(row, flush=True)
+os.environ["CU_CONV_DBG"] = "0"
+print("== 128 x 64 blocks (CU_WGRAD_N128=1) vs default, with the result compared")
+for size, c in ((64, 128), (32, 256), (16, 480)):
+    x = torch.randn(n, size, size, c, device=DEV).to(torch.bfloat16)
+    dz = torch.randn(n, size, size, c, device=DEV).to(torch.bfloat16)
+    outs = []
+    row = f"{size:4d} {c:<4d}"
+    for v in ("0", "1"):
+        os.environ["CU_WGRAD_N128"] = v
+        dwk = torch.zeros(9, c, c, device=DEV)
+        ops.conv_wgrad([ops.Act(x, None, 1.0)], dz, dwk, grid=(size, size), in_stride=1, z_stride=1, taps=TAPS3_W, n_cols=c)
+        outs.append(dwk.clone())
+        us = bench(lambda: ops.conv_wgrad([ops.Act(x, None, 1.0)], dz, dwk, grid=(size, size), in_stride=1, z_stride=1,
+                                          taps=TAPS3_W, n_cols=c))
+        row += f"   N128={v}: {us:7.1f} us"
+    row += f"   rel diff {float((outs[0] - outs[1]).norm() / outs[0].norm()):.2e}"
+    print(row, flush=True)
+os.environ["CU_WGRAD_N128"] = "0"
 os.environ["CU_CONV_DBG"] = "16"
+sys.exit(0)
 for size, c in shapes:
     x = torch.randn(n, size, size, c, device=DEV).to(torch.bfloat16)
     dz = torch.randn(n, size, size, c, device=DEV).to(torch.bfloat16)

@@ -294,6 +294,230 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(const PcArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile form for the MID levels (16^2 ... 64^2 maps, 128 ... 480 channels).  There the kernel above is bound by
+// its LDS-DMA staging, not by HBM or MFMA: a 128 x 128 tile stages (128 + 128) rows per 128 x 128 x 64 MACs, and the
+// stride-2 input gradient at 16^2 moves 1 GB through the DMA path in 156 us (6.5 TB/s, the chip's LDS-DMA ceiling,
+// MI355X_MICROARCH.md).  A 256 x 256 tile stages (256 + 256) rows per four times the MACs: half the bytes per FLOP.
+// Eight waves: wave = (pixel group of 64 rows, column half of 128) -> 2 x 4 MFMA blocks (128 accumulator registers), two
+// A-fragment and four W-fragment reads per eight MFMAs.  Two stages of 64 KiB (A 32 KiB | W 32 KiB), one workgroup per
+// CU, the same flat iteration ring across taps, chunks and tiles.  Few-tap forms only (<= 4 taps), weights streamed.
+constexpr int P2M = 256, P2N = 256, P2STAGE = (P2M + P2N) * PKC * 2;      // 64 KiB
+
+__device__ __forceinline__ void col_block2(const PcArgs& p, int ct, int b, int& group, int& c0) {
+    if (p.gcols >= P2N) {
+        const int tpg = (p.gcols + P2N - 1) / P2N;
+        group = ct / tpg;
+        c0 = (ct - group * tpg) * P2N + b * 32;
+    } else {
+        const int col = ct * P2N + b * 32;          // gcols in {32, 64, 128}: a tile holds whole groups
+        group = col / p.gcols;
+        c0 = col - group * p.gcols;
+    }
+}
+
+__global__ __launch_bounds__(512) void pconv2_kernel(const PcArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wr = wave & 3, wcol = wave >> 2;            // pixel group (64 rows), column half (4 blocks)
+    const int ct = blockIdx.y;
+    const unsigned a_base = lds_addr(smem);
+    const i32x4 rs = make_rsrc(p.src, p.src_bytes);
+    const i32x4 rw = make_rsrc(p.w, p.w_bytes);
+    constexpr unsigned OOB = 0x7ffffff0u;
+    const int niter = p.ntaps * p.kchunks;
+    __shared__ int s_tab[4 * 2 + 4 * 4];                  // dy[4], dx[4], wrow[tap][group]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (tid == i) { s_tab[i] = p.tap_dy[i]; s_tab[4 + i] = p.tap_dx[i]; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (tid == 64 + i) s_tab[8 + i] = p.wrow[i];
+    __syncthreads();
+    const int* s_wrow = s_tab + 8;
+
+    // ---- staging pieces of a stage half (A or W): piece i = s * 512 + tid -> row i >> 3 (0..255), slot i & 7
+    int prow[4], ppiece[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int i = s * 512 + tid;
+        prow[s] = i >> 3;
+        ppiece[s] = (i & 7) ^ ((prow[s] >> 1) & 7);
+    }
+    int wgrp[8], wc0[8];
+    unsigned benable = 0;                                 // bit t * 8 + b: MFMAs of (tap, column block) exist
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        col_block2(p, ct, b, wgrp[b], wc0[b]);
+        for (int t = 0; t < p.ntaps; ++t)
+            if (wgrp[b] < p.ngroups && wc0[b] < p.gcols && s_wrow[t * 4 + wgrp[b]] >= 0) benable |= 1u << (t * 8 + b);
+    }
+    auto issue_w = [&](int t, int kc, unsigned dst) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int row = prow[s], b = row >> 5;
+            int grp = 0, c0 = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { grp = b == q ? wgrp[q] : grp; c0 = b == q ? wc0[q] : c0; }
+            const int col = c0 + (row & 31);
+            const int k = kc * PKC + ppiece[s] * 8;
+            const int wrw = s_wrow[t * 4 + (grp < p.ngroups ? grp : 0)];
+            const bool ok = ((benable >> (t * 8 + b)) & 1u) && col < p.gcols && k < p.C;
+            const unsigned off = ok ? (unsigned)(((wrw + col) * p.C + k) * 2) : OOB;
+            dma16(rw, off, dst + (unsigned)(s * 8192 + wave * 1024));
+        }
+    };
+
+    int arow[2], asw[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) { arow[a] = wr * 64 + a * 32 + r; asw[a] = (arow[a] >> 1) & 7; }
+    int wsw[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) wsw[b] = (((wcol * 4 + b) * 32 + r) >> 1) & 7;
+
+    constexpr int D = 8;                                  // DMA wave-instructions per iteration and wave
+    const int pw = 1 << p.pwl, ph = 1 << p.phl;
+    const int my_tiles = (int)blockIdx.x < p.mtiles ? (p.mtiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int T = my_tiles * niter;
+    int iss = 0, iss_it = 0, iss_tile = blockIdx.x, iss_st = 0;
+    int sy0[4], sx0[4], nb[4];
+    unsigned rvalid = 0;
+    auto issue_geo = [&]() {
+        rvalid = 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int m = iss_tile * P2M + prow[s];
+            const int px = m & (pw - 1), py = (m >> p.pwl) & (ph - 1), n = m >> (p.pwl + p.phl);
+            sy0[s] = py * p.IS; sx0[s] = px * p.IS; nb[s] = n * p.SH;
+            rvalid |= (m < p.M ? 1u : 0u) << s;
+        }
+    };
+    auto issue_next = [&]() {
+        const int t = iss_it / p.kchunks, kc = iss_it - t * p.kchunks;
+        const unsigned stg = (unsigned)iss_st * P2STAGE;
+        iss_st ^= 1;
+        const int dy = s_tab[t], dx = s_tab[4 + t];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int sy = sy0[s] + dy, sx = sx0[s] + dx;
+            const int k = kc * PKC + ppiece[s] * 8;
+            const bool ok = ((rvalid >> s) & 1u) && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW && k < p.C;
+            const unsigned off = ok ? (unsigned)((((nb[s] + sy) * p.SW + sx) * p.C + k) * 2) : OOB;
+            dma16(rs, off, a_base + stg + (unsigned)(s * 8192 + wave * 1024));
+        }
+        issue_w(t, kc, a_base + stg + 32768u);
+        ++iss;
+        if (++iss_it == niter) { iss_it = 0; iss_tile += gridDim.x; issue_geo(); }
+    };
+    if (T > 0) { issue_geo(); issue_next(); }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    int tile = blockIdx.x, it = 0, st = 0;
+    for (int j = 0; j < T; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // two stages: iteration j is the only one in flight
+        __syncthreads();             // iteration j has landed for every wave; the other stage is no longer being read
+        if (iss < T) issue_next();
+        {
+            const int t = it / p.kchunks;
+            const unsigned char* A = smem + st * P2STAGE;
+            const unsigned char* W = A + 32768;
+            const unsigned en = (benable >> (t * 8 + wcol * 4)) & 15u;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 xf[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    xf[a] = *reinterpret_cast<const bf16x8*>(A + arow[a] * 128 + (((2 * kk + h) ^ asw[a]) << 4));
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if ((en >> b) & 1u) {            // uniform
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(
+                            W + ((wcol * 4 + b) * 32 + r) * 128 + (((2 * kk + h) ^ wsw[b]) << 4));
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[a], acc[a][b], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        st ^= 1;
+        if (++it < niter) continue;
+        it = 0;
+
+        // ---- epilogue (as pconv_kernel; the old values of an accumulating destination are read here)
+        unsigned any = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) any |= (benable >> (t * 8 + wcol * 4)) & 15u;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int m = tile * P2M + wr * 64 + a * 32 + r;
+            const bool mvalid = m < p.M;
+            const int px = m & (pw - 1), py = (m >> p.pwl) & (ph - 1), n = m >> (p.pwl + p.phl);
+            const long obase = (((long)n * p.OH + py * p.OS + p.OY0) * p.OW + px * p.OS + p.OX0) * p.DC;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (!((any >> b) & 1u)) continue;             // uniform: no tap feeds this block
+                const int bb = wcol * 4 + b;
+                int grp = 0, c0 = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { grp = bb == q ? wgrp[q] : grp; c0 = bb == q ? wc0[q] : c0; }
+                unsigned q[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e];
+                    if (p.bias && c0 + 8 * g + 4 * h < p.gcols) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + grp * p.gcols + c0 + 8 * g + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                    }
+                    q[g][0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    q[g][1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                }
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2) {
+                    auto r02 = __builtin_amdgcn_permlane32_swap(q[0][w2], q[2][w2], false, false);
+                    q[0][w2] = r02[0]; q[2][w2] = r02[1];
+                    auto r13 = __builtin_amdgcn_permlane32_swap(q[1][w2], q[3][w2], false, false);
+                    q[1][w2] = r13[0]; q[3][w2] = r13[1];
+                }
+                const int c = c0 + 16 * h;
+                if (mvalid && c < p.gcols) {
+                    const long poff = p.ngroups > 1 ? ((long)(grp >> 1) * p.OW + (grp & 1)) * p.DC : 0;
+                    bf16_t* o = reinterpret_cast<bf16_t*>(p.dst) + obase + poff + c;
+                    u32x4 lo = u32x4{q[0][0], q[0][1], q[2][0], q[2][1]};
+                    u32x4 hi = u32x4{q[1][0], q[1][1], q[3][0], q[3][1]};
+                    if (p.accum) {
+                        const u32x4 ol = *reinterpret_cast<const u32x4*>(o);
+                        const u32x4 oh = c + 8 < p.gcols ? *reinterpret_cast<const u32x4*>(o + 8) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a0 = __uint_as_float(lo[e] << 16) + __uint_as_float(ol[e] << 16);
+                            const float a1 = __uint_as_float(lo[e] & 0xffff0000u) + __uint_as_float(ol[e] & 0xffff0000u);
+                            lo[e] = (unsigned)f32_to_bf16(a0) | ((unsigned)f32_to_bf16(a1) << 16);
+                            const float b0 = __uint_as_float(hi[e] << 16) + __uint_as_float(oh[e] << 16);
+                            const float b1 = __uint_as_float(hi[e] & 0xffff0000u) + __uint_as_float(oh[e] & 0xffff0000u);
+                            hi[e] = (unsigned)f32_to_bf16(b0) | ((unsigned)f32_to_bf16(b1) << 16);
+                        }
+                    }
+                    *reinterpret_cast<u32x4*>(o) = lo;
+                    if (c + 8 < p.gcols) *reinterpret_cast<u32x4*>(o + 8) = hi;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+            }
+        }
+        tile += gridDim.x;
+    }
+}
+
 }  // namespace
 
 // Called by cu_conv_gemm before its own tiling: returns 1 if the launch was taken, 0 if the shape is not this kernel's,
@@ -368,6 +592,22 @@ int cu_pconv_try(const cu_conv_desc* d, const void* src0, const void* w, const f
         max_blocks = blocks > max_blocks ? blocks : max_blocks;
     }
     a.wres = max_blocks * 4096 <= 48 * 1024 && niter <= PMAXT * 8;
+    // ---- mid levels: the 256 x 256 tile form (half the staged bytes per FLOP; see pconv2_kernel)
+    if (few && d->ntaps <= 4 && !a.wres && d->C0 >= 128 && a.CO >= 256 && (gcols >= 256 || 256 % gcols == 0) &&
+        M >= 16384 && M <= (1l << 19) && !cu_env_set("CU_PCONV_NO256")) {
+        a.mtiles = cdiv((int)M, P2M);
+        a.coltiles = gcols >= P2N ? a.ngroups * cdiv(gcols, P2N) : cdiv(a.CO, P2N);
+        const size_t lds2 = 2 * (size_t)P2STAGE;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pconv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds2);
+        CU_CHECK_ARG(e == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        int gx = a.mtiles;
+        const int cap2 = 256 / (a.coltiles < 4 ? a.coltiles : 4);
+        if (gx > cap2 && cap2 > 0) gx = cap2;
+        hipLaunchKernelGGL(pconv2_kernel, dim3(gx, a.coltiles), dim3(512), lds2, reinterpret_cast<hipStream_t>(stream), a);
+        CU_LAUNCH_CHECK();
+        return 1;
+    }
     // ring depth: measured (profiles/r02_pconv_ring.txt) -- occupancy beats depth: two stages with 2-3 workgroups per CU
     // (their loads interleave) outrun four stages with one workgroup per CU
     int ring = cu_env_int("CU_PCONV_RING", 2);

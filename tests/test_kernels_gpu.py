@@ -565,7 +565,8 @@ def test_stride2_dgrad_single_pass(dtype, case):
     assert rel_err(nchw(d0), ref) < tol(dtype)
 
 
-@pytest.mark.parametrize("case", [(4, 64, 32, 64), (3, 128, 64, 128), (16, 480, 256, 16), (8, 256, 128, 32)])
+@pytest.mark.parametrize("case", [(4, 64, 32, 64), (3, 128, 64, 128), (16, 480, 256, 16), (8, 256, 128, 32),
+                                  (64, 480, 256, 16), (16, 256, 128, 32)])      # >= 16384 loop pixels: the 256 x 256 tile form
 def test_lean_gather_gemm_shapes(case):
     """The shapes cu_conv_gemm hands to the lean gather-GEMM (pconv.hip; bf16, >= 4096 / 16384 loop pixels): transposed
     conv forward (one pass, parity scatter), its input gradient (4 taps, stride-2 gather), and the stride-2 3x3 input

@@ -11,7 +11,7 @@ import sys
 from collections import defaultdict
 from pathlib import Path
 
-FAMILIES = [("igemm_conv", "igemm_conv"), ("pconv_kernel", "igemm_conv"), ("tconv_kernel", "igemm_conv"), ("ksplit_finish", "igemm_conv"),
+FAMILIES = [("igemm_conv", "igemm_conv"), ("pconv_kernel", "igemm_conv"), ("pconv2_kernel", "igemm_conv"), ("tconv_kernel", "igemm_conv"), ("ksplit_finish", "igemm_conv"),
             ("igemm_wgrad", "igemm_wgrad"), ("fwd_resident", "instnorm_apply"), ("stats_", "instnorm_stats"),
             ("apply_kernel", "instnorm_apply"), ("bwd_", "instnorm_bwd"), ("act_bwd", "instnorm_bwd"),
             ("weight_prep", "weight_prep"), ("grad_unprep", "weight_prep"), ("adam", "adam"), ("conv_c1", "conv_c1"),

@@ -246,7 +246,7 @@ def main():
             famrec = json.loads(pmc.read_text())["families"].get(name)
             if famrec:
                 traffic = round(famrec["bytes_per_launch"])
-        symbols = {"igemm_conv": "igemm_conv_kernel<*> + igemm_conv_dma_kernel<*> + igemm_conv_dma_ring_kernel + pconv_kernel<*> + tconv_kernel<*> (all instantiations; + ksplit_finish_kernel)",
+        symbols = {"igemm_conv": "igemm_conv_kernel<*> + igemm_conv_dma_kernel<*> + igemm_conv_dma_ring_kernel + pconv_kernel<*> + pconv2_kernel + tconv_kernel<*> (all instantiations; + ksplit_finish_kernel)",
                    "igemm_wgrad": "igemm_wgrad_kernel<*> + igemm_wgrad_dma_kernel<*> (all instantiations)"}
         result["roofline"] = {"bound": "mfma", "kernel": name, "kernel_symbols": symbols.get(name, name),
                               "achieved": round(achieved, 2),

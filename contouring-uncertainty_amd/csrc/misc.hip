@@ -106,6 +106,83 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
     }
 }
 
+// The same sums with the image rows of the chunk staged in LDS (zero-padded border) and four dz pieces in flight per thread:
+// the form above issues nine 4-byte global loads per 16-byte piece of dz and ran at a third of HBM speed (164 us for the
+// 268 MB of dz at 256^2 x 32 channels x 64 images).  Chunks are whole rows; CO / PIECE a power of two <= 16.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_c1_wgrad_rows_kernel(const float* __restrict__ img, const T* __restrict__ dz,
+                                                                 float* __restrict__ dw, int N, int H, int W, int CO, int R) {
+    constexpr int PIECE = Elem<T>::PIECE;
+    extern __shared__ float lds[];                 // (R + 2) x (W + 2) image rows, afterwards the reduction scratch
+    const int ppp = CO / PIECE, rows = 256 / ppp;
+    const int piece = threadIdx.x % ppp, prow = threadIdx.x / ppp;
+    const int n = blockIdx.y, y0 = blockIdx.x * R;
+    const int WP = W + 2;
+    const int Rv = min(R, H - y0);
+    for (int i = threadIdx.x; i < (R + 2) * WP; i += 256) {
+        const int ry = i / WP, rx = i - ry * WP;
+        const int sy = y0 + ry - 1, sx = rx - 1;
+        lds[i] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? img[((size_t)n * H + sy) * W + sx] : 0.f;
+    }
+    __syncthreads();
+    float acc[9][PIECE];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) acc[t][e] = 0.f;
+    const int npx = Rv * W;
+    const T* dzb = dz + ((size_t)n * H + y0) * W * CO + piece * PIECE;
+    auto add = [&](int q, const float (&g)[PIECE]) {
+        const int y = q / W, x = q - y * W;
+        const float* s = lds + y * WP + x;         // top-left of the 3x3 window in padded coordinates
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float v = s[(t / 3) * WP + t % 3];
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) acc[t][e] += v * g[e];
+        }
+    };
+    int p = prow;
+    for (; p + 3 * rows < npx; p += 4 * rows) {
+        float g[4][PIECE];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load_piece<T>(dzb + (size_t)(p + u * rows) * CO, g[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add(p + u * rows, g[u]);
+    }
+    for (; p < npx; p += rows) {
+        float g[PIECE];
+        load_piece<T>(dzb + (size_t)p * CO, g);
+        add(p, g);
+    }
+    // lane = (prow % (64 / ppp)) * ppp + piece: lanes 16 and 32 apart hold the same piece of other pixel rows
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+            acc[t][e] += __shfl_xor(acc[t][e], 32);
+            acc[t][e] += __shfl_xor(acc[t][e], 16);
+        }
+    __syncthreads();                               // every wave is done with the image rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rpw = 16 / ppp;                      // partial rows per wave that are left
+    if (lane < 16) {
+        float* d = lds + ((size_t)(wave * rpw + lane / ppp) * ppp + piece) * 9 * PIECE;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) d[t * PIECE + e] = acc[t][e];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 9 * CO; o += 256) {
+        const int t = o / CO, c = o - t * CO;
+        const int pc = c / PIECE, e = c - pc * PIECE;
+        float sum = 0.f;
+        for (int rr = 0; rr < 4 * rpw; ++rr) sum += lds[((size_t)rr * ppp + pc) * 9 * PIECE + t * PIECE + e];
+        unsafeAtomicAdd(dw + o, sum);
+    }
+}
+
 // ---------------------------------------------------------------------------------------- operand copies
 // The nn.Parameters keep the reference's logical layouts (Conv2d: [CO][CI][kh][kw]; ConvTranspose2d: [CI][CO][kh][kw]) so
 // that reference checkpoints load with strict=True.  The MFMA kernels want tap-major operands:
@@ -161,33 +238,63 @@ __global__ __launch_bounds__(256) void grad_unprep_kernel(float* __restrict__ dw
 // 8 x 32 block of (slow channel, fast channel) with ALL its taps in LDS and writes the logical gradient in contiguous
 // rows of 32*T floats (the per-tap kernel above touches every logical line T times, 4 useful bytes per 36).
 constexpr int UNPREP_MAXT = 9;
-__global__ __launch_bounds__(256) void grad_unprep_rows_kernel(float* __restrict__ dwk, float* __restrict__ g, int NT,
+// NT = compile-time tap count (all NT loads of a thread are in flight before the first use; the run-time form waited for
+// every load in turn: 10 us per launch on average, 41 launches per step) or 0 = run-time count NTr.
+template <int NT>
+__global__ __launch_bounds__(256) void grad_unprep_rows_kernel(float* __restrict__ dwk, float* __restrict__ g, int NTr,
                                                                int CO, int CI, int COP, long s_co, long s_ci, int accumulate) {
     __shared__ float tile[8 * (32 * UNPREP_MAXT + 1)];
+    const int nt = NT ? NT : NTr;
     const bool co_rows = s_co > s_ci;                  // conv: rows = co, columns = ci; transposed conv: the other way
     const int r0 = blockIdx.y * 8, c0 = blockIdx.x * 32;
     const int RN = co_rows ? CO : CI, CN = co_rows ? CI : CO;
-    const int pitch = 32 * NT + 1;
+    const int pitch = 32 * nt + 1;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // column tx of row ty
     {
         const int r = r0 + ty, c = c0 + tx;
         const int co = co_rows ? r : c, ci = co_rows ? c : r;
         const bool ok = r < RN && c < CN;
-        for (int t = 0; t < NT; ++t)
-        {
-            float* src = dwk + ((size_t)t * COP + co) * CI + ci;
-            tile[ty * pitch + tx * NT + t] = ok ? *src : 0.f;
-            if (ok && (accumulate & 2)) *src = 0.f;      // read-and-clear: the accumulator is ready for the next layer
+        float* src = dwk + ((size_t)co) * CI + ci;
+        const size_t tstride = (size_t)COP * CI;
+        if constexpr (NT > 0) {
+            float v[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] = ok ? src[t * tstride] : 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                tile[ty * pitch + tx * NT + t] = v[t];
+                if (ok && (accumulate & 2)) src[t * tstride] = 0.f;      // read-and-clear: ready for the next layer
+            }
+        } else {
+            for (int t = 0; t < nt; ++t) {
+                tile[ty * pitch + tx * nt + t] = ok ? src[t * tstride] : 0.f;
+                if (ok && (accumulate & 2)) src[t * tstride] = 0.f;
+            }
         }
     }
     __syncthreads();
     const long s_r = co_rows ? s_co : s_ci;
-    const int cvalid = min(32, CN - c0) * NT;
+    const int cvalid = min(32, CN - c0) * nt;
     if (r0 + ty < RN) {
-        float* dst = g + (size_t)(r0 + ty) * s_r + (size_t)c0 * NT;
-        for (int k = tx; k < cvalid; k += 32) {
-            const float v = tile[ty * pitch + k];
-            dst[k] = (accumulate & 1) ? dst[k] + v : v;
+        float* dst = g + (size_t)(r0 + ty) * s_r + (size_t)c0 * nt;
+        if constexpr (NT > 0) {
+            if (accumulate & 1) {
+                float o[NT];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) o[i] = (tx + 32 * i < cvalid) ? dst[tx + 32 * i] : 0.f;
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    if (tx + 32 * i < cvalid) dst[tx + 32 * i] = o[i] + tile[ty * pitch + tx + 32 * i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    if (tx + 32 * i < cvalid) dst[tx + 32 * i] = tile[ty * pitch + tx + 32 * i];
+            }
+        } else {
+            for (int k = tx; k < cvalid; k += 32) {
+                const float v = tile[ty * pitch + k];
+                dst[k] = (accumulate & 1) ? dst[k] + v : v;
+            }
         }
     }
 }
@@ -205,44 +312,105 @@ __device__ __forceinline__ const cu_prep_item* find_item(const cu_prep_item* ite
 // 4 useful bytes per 36: 0.5 ms per pass over the 25 M weights; it survives as the non-batched entry point.)
 constexpr int PREP_MAXT = 9;
 
-template <typename T>
-__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const cu_prep_item* __restrict__ items, int n) {
-    __shared__ float tile[32 * (32 * PREP_MAXT + 1)];
-    const cu_prep_item* it = find_item(items, n, blockIdx.x);
-    const int b = blockIdx.x - it->blk0;
+template <typename T> __device__ __forceinline__ void store_pair(T* p, float a, float b);
+template <> __device__ __forceinline__ void store_pair<float>(float* p, float a, float b) {
+    f32x2 t = {a, b};
+    *reinterpret_cast<f32x2*>(p) = t;
+}
+template <> __device__ __forceinline__ void store_pair<bf16_t>(bf16_t* p, float a, float b) {
+    *reinterpret_cast<unsigned*>(p) = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+}
+
+// NT = compile-time tap count: the 4 NT loads of a thread are all in flight before the first LDS store (the run-time loop
+// waited for each in turn and the pass ran at a quarter of HBM speed), and the copies leave as pairs (4-byte stores for
+// bf16).  NT = 0: run-time count, scalar stores (odd channel counts).
+template <typename T, int NT>
+__device__ __forceinline__ void prep_tile(const cu_prep_item* it, int b, float* tile) {
     const int tci = b % it->tiles_ci, tco = b / it->tiles_ci;
-    const int NT = it->T, CO = it->CO, CI = it->CI, COP = it->COP;
-    const int pitch = 32 * NT + 1;
+    const int nt = NT ? NT : it->T;
+    const int CO = it->CO, CI = it->CI, COP = it->COP;
+    const int pitch = 32 * nt + 1;
     const bool co_rows = it->s_co > it->s_ci;        // conv: rows = co (stride CI*T); transposed conv: rows = ci
     const int co0 = tco * 32, ci0 = tci * 32;
     const int R0 = co_rows ? co0 : ci0, C0 = co_rows ? ci0 : co0;
     const int RN = co_rows ? CO : CI, CN = co_rows ? CI : CO;
     const long long s_r = co_rows ? it->s_co : it->s_ci;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    const int cvalid = min(32, CN - C0) * NT;                 // valid floats of a slab row
-    for (int r = ty; r < 32; r += 8) {
-        const float* src = it->master + (size_t)(R0 + r) * s_r + (size_t)C0 * NT;
-        for (int k = tx; k < 32 * NT; k += 32)
-            tile[r * pitch + k] = (R0 + r < RN && k < cvalid) ? src[k] : 0.f;
+    const int cvalid = min(32, CN - C0) * nt;                 // valid floats of a slab row
+    if constexpr (NT > 0) {
+        float v[4][NT];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = ty + 8 * j;
+            const float* src = it->master + (size_t)(R0 + r) * s_r + (size_t)C0 * NT;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) v[j][i] = (R0 + r < RN && tx + 32 * i < cvalid) ? src[tx + 32 * i] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) tile[(ty + 8 * j) * pitch + tx + 32 * i] = v[j][i];
+    } else {
+        for (int r = ty; r < 32; r += 8) {
+            const float* src = it->master + (size_t)(R0 + r) * s_r + (size_t)C0 * nt;
+            for (int k = tx; k < 32 * nt; k += 32)
+                tile[r * pitch + k] = (R0 + r < RN && k < cvalid) ? src[k] : 0.f;
+        }
     }
     __syncthreads();
     T* wf = reinterpret_cast<T*>(it->w_fwd);
     T* wd = reinterpret_cast<T*>(it->w_dgrad);
-    for (int t = 0; t < NT; ++t) {
+    if (NT > 0 && !(CI & 1) && !(COP & 1)) {
+        const int q = (threadIdx.x & 15) * 2, a0 = threadIdx.x >> 4;      // fast-index pair q, q + 1 of slow index a
+#pragma unroll
+        for (int t = 0; t < (NT ? NT : 1); ++t) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int a = a0 + 16 * k;
+                if (wf) {                                // wf[t][co][ci]: co = a, ci = q, q + 1
+                    const int co = co0 + a, ci = ci0 + q;
+                    const float v0 = co_rows ? tile[a * pitch + q * nt + t] : tile[q * pitch + a * nt + t];
+                    const float v1 = co_rows ? tile[a * pitch + (q + 1) * nt + t] : tile[(q + 1) * pitch + a * nt + t];
+                    if (co < COP && ci < CI) store_pair<T>(wf + ((size_t)t * COP + co) * CI + ci, v0, v1);
+                }
+                if (wd) {                                // wd[t][ci][co]: ci = a, co = q, q + 1
+                    const int ci = ci0 + a, co = co0 + q;
+                    const float v0 = co_rows ? tile[q * pitch + a * nt + t] : tile[a * pitch + q * nt + t];
+                    const float v1 = co_rows ? tile[(q + 1) * pitch + a * nt + t] : tile[a * pitch + (q + 1) * nt + t];
+                    if (co < COP && ci < CI) store_pair<T>(wd + ((size_t)t * CI + ci) * COP + co, v0, v1);
+                }
+            }
+        }
+        return;
+    }
+    for (int t = 0; t < nt; ++t) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int a = ty + 8 * k;                // slow index of the output row, tx = fast index
             if (wf) {                                // wf[t][co][ci]: co = a, ci = tx
                 const int co = co0 + a, ci = ci0 + tx;
-                const float v = co_rows ? tile[a * pitch + tx * NT + t] : tile[tx * pitch + a * NT + t];
+                const float v = co_rows ? tile[a * pitch + tx * nt + t] : tile[tx * pitch + a * nt + t];
                 if (co < COP && ci < CI) Elem<T>::st(wf + ((size_t)t * COP + co) * CI + ci, v);
             }
             if (wd) {                                // wd[t][ci][co]: ci = a, co = tx
                 const int ci = ci0 + a, co = co0 + tx;
-                const float v = co_rows ? tile[tx * pitch + a * NT + t] : tile[a * pitch + tx * NT + t];
+                const float v = co_rows ? tile[tx * pitch + a * nt + t] : tile[a * pitch + tx * nt + t];
                 if (co < COP && ci < CI) Elem<T>::st(wd + ((size_t)t * CI + ci) * COP + co, v);
             }
         }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const cu_prep_item* __restrict__ items, int n) {
+    __shared__ float tile[32 * (32 * PREP_MAXT + 1)];
+    const cu_prep_item* it = find_item(items, n, blockIdx.x);
+    const int b = blockIdx.x - it->blk0;
+    switch (it->T) {                                  // uniform per workgroup
+        case 9: prep_tile<T, 9>(it, b, tile); break;
+        case 4: prep_tile<T, 4>(it, b, tile); break;
+        case 1: prep_tile<T, 1>(it, b, tile); break;
+        default: prep_tile<T, 0>(it, b, tile); break;
     }
 }
 
@@ -370,11 +538,26 @@ extern "C" int cu_conv_c1_wgrad(int dtype, int N, int H, int W, int CO, const fl
                  "cu_conv_c1_wgrad: bad argument");
     const int ppp = CO / PIECE, rows = 256 / ppp;
     int want = cdiv(1024, N);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if ((ppp & (ppp - 1)) == 0 && ppp <= 16 && !cu_env_set("CU_C1_WGRAD_OLD")) {
+        int R = cdiv(H, want < H ? want : H);
+        while (R > 1 && (size_t)(R + 2) * (W + 2) * 4 > 48 * 1024) --R;
+        const size_t img_b = sizeof(float) * (size_t)(R + 2) * (W + 2), red_b = sizeof(float) * (size_t)64 * 9 * PIECE;
+        const size_t lds_r = img_b > red_b ? img_b : red_b;
+        if (lds_r <= 64 * 1024) {
+            dim3 grid_r(cdiv(H, R), N);
+            if (dtype == CU_BF16)
+                hipLaunchKernelGGL(conv_c1_wgrad_rows_kernel<bf16_t>, grid_r, dim3(256), lds_r, st, img, (const bf16_t*)dz, dw, N, H, W, CO, R);
+            else
+                hipLaunchKernelGGL(conv_c1_wgrad_rows_kernel<float>, grid_r, dim3(256), lds_r, st, img, (const float*)dz, dw, N, H, W, CO, R);
+            CU_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     int chunk = cdiv(cdiv(H * W, want), rows) * rows;
     if (chunk < rows) chunk = rows;
     dim3 grid(cdiv(H * W, chunk), N);
     const size_t lds = sizeof(float) * (size_t)rows * ppp * 9 * PIECE;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == CU_BF16)
         hipLaunchKernelGGL(conv_c1_wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, img, (const bf16_t*)dz, dw, N, H, W, CO, chunk);
     else
@@ -405,8 +588,11 @@ extern "C" int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_
     const bool co_rows = s_co > s_ci;
     if (T <= UNPREP_MAXT && ((co_rows && s_ci == T) || (!co_rows && s_co == T))) {
         dim3 grid(cdiv(co_rows ? CI : CO, 32), cdiv(co_rows ? CO : CI, 8));
-        hipLaunchKernelGGL(grad_unprep_rows_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dwk, grad, T,
-                           CO, CI, COP, s_co, s_ci, accumulate);
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        if (T == 9) hipLaunchKernelGGL(grad_unprep_rows_kernel<9>, grid, dim3(256), 0, st, dwk, grad, T, CO, CI, COP, s_co, s_ci, accumulate);
+        else if (T == 4) hipLaunchKernelGGL(grad_unprep_rows_kernel<4>, grid, dim3(256), 0, st, dwk, grad, T, CO, CI, COP, s_co, s_ci, accumulate);
+        else if (T == 1) hipLaunchKernelGGL(grad_unprep_rows_kernel<1>, grid, dim3(256), 0, st, dwk, grad, T, CO, CI, COP, s_co, s_ci, accumulate);
+        else hipLaunchKernelGGL(grad_unprep_rows_kernel<0>, grid, dim3(256), 0, st, dwk, grad, T, CO, CI, COP, s_co, s_ci, accumulate);
         CU_LAUNCH_CHECK();
         return 0;
     }

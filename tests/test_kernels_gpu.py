@@ -182,20 +182,23 @@ def test_conv_transpose(dtype, case):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_first_conv(dtype):
+@pytest.mark.parametrize("geom", [(3, 64, 64), (40, 40, 24), (64, 40, 56)])
+def test_first_conv(dtype, geom):
+    """Cin = 1 layer, forward and weight gradient (row chunks of 1, 2 and 3 rows, the last chunk partial)."""
     ops = _ops()
     g = torch.Generator(device=DEV).manual_seed(4)
-    n, co, size = 3, 32, 64
-    img = torch.rand(n, 1, size, size, device=DEV, generator=g)
+    n, hh, ww = geom
+    co = 32
+    img = torch.rand(n, 1, hh, ww, device=DEV, generator=g)
     w = torch.randn(co, 1, 3, 3, device=DEV, generator=g)
     b = torch.randn(co, device=DEV, generator=g)
     w9, _ = ops.weight_prep(w, "conv", torch.float32, want_dgrad=False)
-    z = torch.empty(n, size, size, co, device=DEV, dtype=dtype)
+    z = torch.empty(n, hh, ww, co, device=DEV, dtype=dtype)
     ops.conv_c1_fwd(img, w9, b, z)
     wr = w.clone().requires_grad_(True)
     ref = F.conv2d(img, wr, b, padding=1)
     assert rel_err(nchw(z), ref) < tol(dtype)
-    dz = rq(torch.randn(n, co, size, size, device=DEV, generator=g), dtype)
+    dz = rq(torch.randn(n, co, hh, ww, device=DEV, generator=g), dtype)
     ref.backward(dz)
     dw9 = torch.zeros(9, co, device=DEV)
     ops.conv_c1_wgrad(img, nhwc(dz, dtype), dw9)
@@ -488,7 +491,9 @@ def test_weight_prep_batch_matches_per_layer(dtype):
     g = torch.Generator(device=DEV).manual_seed(7)
     layers = [(torch.randn(64, 32, 3, 3, device=DEV, generator=g), "conv", None),
               (torch.randn(480, 256, 3, 3, device=DEV, generator=g), "conv", None),
+              (torch.randn(40, 24, 3, 3, device=DEV, generator=g), "conv", None),
               (torch.randn(128, 64, 2, 2, device=DEV, generator=g), "convT", None),
+              (torch.randn(24, 40, 2, 2, device=DEV, generator=g), "convT", None),
               (torch.randn(21, 32, 1, 1, device=DEV, generator=g), "conv", 32)]
     entries, outs = [], []
     for w, kind, cop in layers:

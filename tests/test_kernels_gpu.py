@@ -683,9 +683,16 @@ def test_thin_streaming_conv(case):
         assert got == (n != 20)
         if got:
             mean, rstd, scale, shift = (tgt.stats[i][:, :, None, None] for i in range(4))
-            gl = torch.where(zt * scale + shift > 0, gx, gx * 0.01)
+            y = zt * scale + shift
+            gl = torch.where(y > 0, gx, gx * 0.01)
             zhat = (zt - mean) * rstd
-            assert rel_err(sums[..., 0], gl.sum((2, 3))) < 5e-3 and rel_err(sums[..., 1], (gl * zhat).sum((2, 3))) < 5e-3
+            # z is bf16: when -shift / scale of an (image, channel) falls on a representable value, every pixel holding that
+            # value has y = 0 to within the rounding of its two terms, and its LeakyReLU branch hangs on the last bit of the
+            # statistics (atomics: run to run) and on fma against mul + add.  Those pixels' contributions are slack.
+            amb = (y.abs() <= 4e-7 * (zt.abs() * scale.abs() + shift.abs())).float()
+            for j, ref_j, w_j in ((0, gl.sum((2, 3)), gx.abs()), (1, (gl * zhat).sum((2, 3)), (gx * zhat).abs())):
+                slack = (amb * w_j).sum((2, 3))
+                assert bool(((sums[..., j] - ref_j).abs() <= 5e-3 * ref_j.abs().max() + slack).all())
             # the apply pass from those sums == the two-pass backward
             g1, g2 = d0.clone(), d0.clone()
             dg1, db1, dg2, db2 = (torch.zeros(ci, device=DEV) for _ in range(4))

@@ -293,19 +293,35 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
         }
     }
 
-    if (!wave_active || CU_DBG(p, 1)) return;
+    if (CU_DBG(p, 1)) return;
     // ---- atomics: col (lane&31) = c, rows = n
     const int r = lane & 31, hh = lane >> 5;
     const int c = c_base + cblk * 32 + r;
-    if (c >= CI) return;
+    auto flush = [&]() {
+        if (!wave_active || c >= CI) return;
 #pragma unroll
-    for (int t = 0; t < NTAPS; ++t) {
+        for (int t = 0; t < NTAPS; ++t) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int n = n_base + nblk * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            if (n < p.CO) unsafeAtomicAdd(p.dw + ((size_t)p.tap_w[t] * p.CO + n) * CI + c, acc[t][i]);
+            for (int i = 0; i < 16; ++i) {
+                const int n = n_base + nblk * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                if (n < p.CO) unsafeAtomicAdd(p.dw + ((size_t)p.tap_w[t] * p.CO + n) * CI + c, acc[t][i]);
+            }
+        }
+    };
+    if constexpr (KSPLIT > 1) {
+        // one pixel split (cu_wgrad_desc.splits == 1, the deterministic mode): this workgroup is the only adder of its dW
+        // block, and its KSPLIT k-parts add one after the other -- a fixed summation order
+        if (p.splits == 1) {
+#pragma unroll
+            for (int kp = 0; kp < KSPLIT; ++kp) {
+                if (kp == kpart) flush();
+                __threadfence();
+                __syncthreads();
+            }
+            return;
         }
     }
+    flush();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

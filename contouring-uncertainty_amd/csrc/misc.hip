@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
 // 268 MB of dz at 256^2 x 32 channels x 64 images).  Chunks are whole rows; CO / PIECE a power of two <= 16.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_c1_wgrad_rows_kernel(const float* __restrict__ img, const T* __restrict__ dz,
-                                                                 float* __restrict__ dw, int N, int H, int W, int CO, int R) {
+                                                                 float* __restrict__ dw, int N, int H, int W, int CO, int R,
+                                                                 float* __restrict__ part) {
     constexpr int PIECE = Elem<T>::PIECE;
     extern __shared__ float lds[];                 // (R + 2) x (W + 2) image rows, afterwards the reduction scratch
     const int ppp = CO / PIECE, rows = 256 / ppp;
@@ -179,8 +180,19 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_rows_kernel(const float* __
         const int pc = c / PIECE, e = c - pc * PIECE;
         float sum = 0.f;
         for (int rr = 0; rr < 4 * rpw; ++rr) sum += lds[((size_t)rr * ppp + pc) * 9 * PIECE + t * PIECE + e];
-        unsafeAtomicAdd(dw + o, sum);
+        if (part) part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 9 * CO + o] = sum;      // deterministic mode
+        else unsafeAtomicAdd(dw + o, sum);
     }
+}
+
+// deterministic mode: dw[o] += the workgroups' partial sums in workgroup order
+__global__ __launch_bounds__(256) void conv_c1_wgrad_finish_kernel(const float* __restrict__ part, int nwg, int n_out,
+                                                                   float* __restrict__ dw) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_out) return;
+    float s = 0.f;
+    for (int g = 0; g < nwg; ++g) s += part[(size_t)g * n_out + o];
+    dw[o] += s;
 }
 
 // ---------------------------------------------------------------------------------------- operand copies
@@ -530,8 +542,22 @@ extern "C" int cu_conv_c1_fwd(int dtype, int N, int H, int W, int CO, const floa
     return 0;
 }
 
+static int conv_c1_wgrad_impl(int dtype, int N, int H, int W, int CO, const float* img, const void* dz, float* dw,
+                              float* part, size_t part_floats, void* stream);
+
 extern "C" int cu_conv_c1_wgrad(int dtype, int N, int H, int W, int CO, const float* img, const void* dz, float* dw,
                                 void* stream) {
+    return conv_c1_wgrad_impl(dtype, N, H, W, CO, img, dz, dw, nullptr, 0, stream);
+}
+
+extern "C" int cu_conv_c1_wgrad_det(int dtype, int N, int H, int W, int CO, const float* img, const void* dz, float* dw,
+                                    float* ws, size_t ws_floats, void* stream) {
+    CU_CHECK_ARG(ws != nullptr, "cu_conv_c1_wgrad_det: null workspace");
+    return conv_c1_wgrad_impl(dtype, N, H, W, CO, img, dz, dw, ws, ws_floats, stream);
+}
+
+static int conv_c1_wgrad_impl(int dtype, int N, int H, int W, int CO, const float* img, const void* dz, float* dw,
+                              float* part, size_t part_floats, void* stream) {
     CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_conv_c1_wgrad: bad dtype");
     const int PIECE = dtype == CU_BF16 ? 8 : 4;
     CU_CHECK_ARG(N > 0 && H > 0 && W > 0 && CO > 0 && CO % PIECE == 0 && CO / PIECE <= 256 && img && dz && dw,
@@ -546,14 +572,20 @@ extern "C" int cu_conv_c1_wgrad(int dtype, int N, int H, int W, int CO, const fl
         const size_t lds_r = img_b > red_b ? img_b : red_b;
         if (lds_r <= 64 * 1024) {
             dim3 grid_r(cdiv(H, R), N);
+            const size_t nwg = (size_t)grid_r.x * grid_r.y;
+            CU_CHECK_ARG(!part || nwg * 9 * CO <= part_floats, "cu_conv_c1_wgrad_det: workspace of %zu floats, need %zu",
+                         part_floats, nwg * 9 * CO);
             if (dtype == CU_BF16)
-                hipLaunchKernelGGL(conv_c1_wgrad_rows_kernel<bf16_t>, grid_r, dim3(256), lds_r, st, img, (const bf16_t*)dz, dw, N, H, W, CO, R);
+                hipLaunchKernelGGL(conv_c1_wgrad_rows_kernel<bf16_t>, grid_r, dim3(256), lds_r, st, img, (const bf16_t*)dz, dw, N, H, W, CO, R, part);
             else
-                hipLaunchKernelGGL(conv_c1_wgrad_rows_kernel<float>, grid_r, dim3(256), lds_r, st, img, (const float*)dz, dw, N, H, W, CO, R);
+                hipLaunchKernelGGL(conv_c1_wgrad_rows_kernel<float>, grid_r, dim3(256), lds_r, st, img, (const float*)dz, dw, N, H, W, CO, R, part);
+            if (part)
+                hipLaunchKernelGGL(conv_c1_wgrad_finish_kernel, dim3(cdiv(9 * CO, 256)), dim3(256), 0, st, part, (int)nwg, 9 * CO, dw);
             CU_LAUNCH_CHECK();
             return 0;
         }
     }
+    CU_CHECK_ARG(!part, "cu_conv_c1_wgrad_det: CO / piece must be a power of two <= 16 (CO=%d)", CO);
     int chunk = cdiv(cdiv(H * W, want), rows) * rows;
     if (chunk < rows) chunk = rows;
     dim3 grid(cdiv(H * W, chunk), N);

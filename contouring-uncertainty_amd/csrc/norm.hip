@@ -953,7 +953,26 @@ __global__ __launch_bounds__(NT, 2) void bwd_resident_kernel(T* __restrict__ g, 
     }
 }
 
-static int pick_chunk(int N, int HW, int rows, int* nchunks) {
+// dgamma[c] += sum_n ws[n][c][1], dbeta[c] += sum_n ws[n][c][0] in image order (deterministic mode: the backward kernels
+// leave the parameter gradients alone and this pass is their single writer)
+__global__ __launch_bounds__(256) void norm_param_grads_kernel(const float* __restrict__ ws, int N, int C,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int n = 0; n < N; ++n) {
+        s0 += ws[((size_t)n * C + c) * 2];
+        s1 += ws[((size_t)n * C + c) * 2 + 1];
+    }
+    if (dbeta) dbeta[c] += s0;
+    if (dgamma) dgamma[c] += s1;
+}
+
+static int pick_chunk(int N, int HW, int rows, int* nchunks, bool det = false) {
+    if (det) {      // one workgroup per image: its LDS reduction has a fixed order and it is the only adder of its sums
+        *nchunks = 1;
+        return cdiv(HW, rows) * rows;
+    }
     // aim for ~2048 workgroups in total; every chunk a multiple of the rows handled per iteration
     int want = cdiv(2048, N);
     if (want < 1) want = 1;
@@ -983,17 +1002,17 @@ static int pick_chunk(int N, int HW, int rows, int* nchunks) {
 // ---- launch helpers: `nimg` images starting at the pointers given, inside a tensor of N images (plane stride of stats)
 template <typename T>
 static int launch_stats(int nimg, int N, int HW, int C, const void* z, const float* gamma, const float* beta, float eps,
-                        float* stats, float* ws, hipStream_t st, bool clean = false) {
+                        float* stats, float* ws, hipStream_t st, bool clean = false, bool det = false) {
     constexpr int PIECE = Elem<T>::PIECE;
     const RowMap rm = row_map(C, PIECE);
-    if (HW <= 1024) {       // small feature maps: one fused launch
+    if (HW <= 1024) {       // small feature maps: one fused launch (no atomics: deterministic as it is)
         dim3 sgrid(nimg, cdiv(C / PIECE, SG));
         hipLaunchKernelGGL(stats_small_kernel<T>, sgrid, dim3(NT), 0, st, (const T*)z, gamma, beta, eps, stats, N, HW, C);
         CU_LAUNCH_CHECK();
         return 0;
     }
     int nchunks = 1;
-    const int chunk = pick_chunk(nimg, HW, rm.rows, &nchunks);
+    const int chunk = pick_chunk(nimg, HW, rm.rows, &nchunks, det);
     if (!clean) {
         hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)nimg * C, st);
         CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_stats: memset failed: %s", hipGetErrorString(e));
@@ -1021,10 +1040,11 @@ static int launch_apply(int nimg, int N, int HW, int C, const void* z, const flo
 
 template <typename T>
 static int launch_bwd(int nimg, int N, int HW, int C, void* g, const void* z, const float* stats, const float* gamma,
-                      float slope, float* dgamma, float* dbeta, float* dbias, float* ws, hipStream_t st, bool clean = false) {
+                      float slope, float* dgamma, float* dbeta, float* dbias, float* ws, hipStream_t st, bool clean = false,
+                      bool det = false) {
     constexpr int PIECE = Elem<T>::PIECE;
     const RowMap rm = row_map(C, PIECE);
-    if (HW <= 1024) {       // small feature maps: one fused launch
+    if (HW <= 1024 && !det) {       // small feature maps: one fused launch
         dim3 sgrid(nimg, cdiv(C / PIECE, SG));
         hipLaunchKernelGGL(bwd_small_kernel<T>, sgrid, dim3(NT), 0, st, (T*)g, (const T*)z, stats, gamma, slope, dgamma, dbeta,
                            dbias, N, HW, C);
@@ -1032,7 +1052,8 @@ static int launch_bwd(int nimg, int N, int HW, int C, void* g, const void* z, co
         return 0;
     }
     int nchunks = 1;
-    const int chunk = pick_chunk(nimg, HW, rm.rows, &nchunks);
+    const int chunk = pick_chunk(nimg, HW, rm.rows, &nchunks, det);
+    if (det) dgamma = dbeta = nullptr;      // the caller's norm_param_grads_kernel pass writes them
     if (!clean) {
         hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)nimg * C, st);
         CU_CHECK_ARG(e == hipSuccess, "cu_instnorm_lrelu_bwd: memset failed: %s", hipGetErrorString(e));
@@ -1123,8 +1144,10 @@ extern "C" int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void
     NORM_COMMON_CHECKS("cu_instnorm_fwd_fused");
     CU_CHECK_ARG(z && stats && out && ws, "cu_instnorm_fwd_fused: null pointer");
     const bool clean = (mode & CU_NORM_WS_CLEAN) != 0;       // the caller hands over a zeroed workspace: no memset launch
-    mode &= ~CU_NORM_WS_CLEAN;
+    const bool det = (mode & CU_NORM_DETERMINISTIC) != 0;    // two-pass kernels, one workgroup per image: fixed summation order
+    mode &= ~(CU_NORM_WS_CLEAN | CU_NORM_DETERMINISTIC);
     CU_CHECK_ARG(mode >= 0 && mode <= 2, "cu_instnorm_fwd_fused: mode %d", mode);
+    if (det) mode = 2;
     const int np = rc_pick_np(HW, rm.rows);
     const int nch = cdiv(HW, rm.rows * np);
     if (mode == 0) mode = (HW <= 256 && nch <= RC_MAX_CHUNKS) ? 1 : 2;      // measured crossover (see the kernels' header)
@@ -1146,8 +1169,8 @@ extern "C" int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void
         const char* zp = (const char*)z + (size_t)n0 * HW * C * esz;
         char* op = (char*)out + (size_t)n0 * HW * C * esz;
         float* sp = stats + (size_t)n0 * C;
-        int rc = dtype == CU_BF16 ? launch_stats<bf16_t>(ni, N, HW, C, zp, gamma, beta, eps, sp, ws + (size_t)n0 * C * 2, st, clean)
-                                  : launch_stats<float>(ni, N, HW, C, zp, gamma, beta, eps, sp, ws + (size_t)n0 * C * 2, st, clean);
+        int rc = dtype == CU_BF16 ? launch_stats<bf16_t>(ni, N, HW, C, zp, gamma, beta, eps, sp, ws + (size_t)n0 * C * 2, st, clean, det)
+                                  : launch_stats<float>(ni, N, HW, C, zp, gamma, beta, eps, sp, ws + (size_t)n0 * C * 2, st, clean, det);
         if (rc) return rc;
         rc = dtype == CU_BF16 ? launch_apply<bf16_t>(ni, N, HW, C, zp, sp, slope, op, st)
                               : launch_apply<float>(ni, N, HW, C, zp, sp, slope, op, st);
@@ -1190,8 +1213,10 @@ extern "C" int cu_instnorm_bwd_fused(int dtype, int N, int HW, int C, void* g, c
     NORM_COMMON_CHECKS("cu_instnorm_bwd_fused");
     CU_CHECK_ARG(g && z && stats && ws, "cu_instnorm_bwd_fused: null pointer");
     const bool clean = (mode & CU_NORM_WS_CLEAN) != 0;       // the caller hands over a zeroed workspace: no memset launch
-    mode &= ~CU_NORM_WS_CLEAN;
+    const bool det = (mode & CU_NORM_DETERMINISTIC) != 0;
+    mode &= ~(CU_NORM_WS_CLEAN | CU_NORM_DETERMINISTIC);
     CU_CHECK_ARG(mode >= 0 && mode <= 2, "cu_instnorm_bwd_fused: mode %d", mode);
+    if (det) mode = 2;
     const int np = rc_pick_np(HW, rm.rows);
     const int nch = cdiv(HW, rm.rows * np);
     if (mode == 0) mode = (HW > 1024 && HW <= 4096 && nch <= RC_MAX_CHUNKS) ? 1 : 2;
@@ -1214,9 +1239,13 @@ extern "C" int cu_instnorm_bwd_fused(int dtype, int N, int HW, int C, void* g, c
         const char* zp = (const char*)z + (size_t)n0 * HW * C * esz;
         const float* sp = stats + (size_t)n0 * C;
         const int rc = dtype == CU_BF16
-            ? launch_bwd<bf16_t>(ni, N, HW, C, gp, zp, sp, gamma, slope, dgamma, dbeta, nullptr, ws + (size_t)n0 * C * 2, st, clean)
-            : launch_bwd<float>(ni, N, HW, C, gp, zp, sp, gamma, slope, dgamma, dbeta, nullptr, ws + (size_t)n0 * C * 2, st, clean);
+            ? launch_bwd<bf16_t>(ni, N, HW, C, gp, zp, sp, gamma, slope, dgamma, dbeta, nullptr, ws + (size_t)n0 * C * 2, st, clean, det)
+            : launch_bwd<float>(ni, N, HW, C, gp, zp, sp, gamma, slope, dgamma, dbeta, nullptr, ws + (size_t)n0 * C * 2, st, clean, det);
         if (rc) return rc;
+    }
+    if (det && (dgamma || dbeta)) {
+        hipLaunchKernelGGL(norm_param_grads_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, ws, N, C, dgamma, dbeta);
+        CU_LAUNCH_CHECK();
     }
     return 0;
 }
@@ -1233,6 +1262,29 @@ extern "C" int cu_act_bwd(int dtype, int N, int HW, int C, void* g, const void* 
                            C, rm.tpp, rm.rows, chunk);
     else
         hipLaunchKernelGGL(act_bwd_kernel<float>, grid, dim3(NT), lds, st, (float*)g, (const float*)z, slope, dbias, HW, C,
+                           rm.tpp, rm.rows, chunk);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_act_bwd_det(int dtype, int N, int HW, int C, void* g, const void* z, float slope, float* dbias,
+                              void* stream) {
+    // elementwise in g; dbias sums over every pixel of every image: ONE workgroup walks the batch as one image of N * HW
+    // pixels, so the sum has a fixed order and a single adder (the heads this serves are a few hundred pixels)
+    CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_act_bwd_det: bad dtype %d", dtype);
+    const int PIECE = dtype == CU_BF16 ? 8 : 4;
+    CU_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % PIECE == 0 && C / PIECE <= NT && g && z, "cu_act_bwd_det: bad argument");
+    CU_CHECK_ARG((long long)N * HW <= (1 << 20), "cu_act_bwd_det: %d x %d pixels for one workgroup", N, HW);
+    const RowMap rm = row_map(C, PIECE);
+    const int px = N * HW;
+    const int chunk = cdiv(px, rm.rows) * rm.rows;
+    const size_t lds = sizeof(float) * (size_t)rm.rows * rm.tpp * PIECE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(1, 1), dim3(NT), lds, st, (bf16_t*)g, (const bf16_t*)z, slope, dbias, px,
+                           C, rm.tpp, rm.rows, chunk);
+    else
+        hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(1, 1), dim3(NT), lds, st, (float*)g, (const float*)z, slope, dbias, px, C,
                            rm.tpp, rm.rows, chunk);
     CU_LAUNCH_CHECK();
     return 0;

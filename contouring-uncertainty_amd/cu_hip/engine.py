@@ -129,6 +129,11 @@ class UNetEngine:
         self.fused_norm = True
         self.fused_stats = os.environ.get("CONTOUR_FUSED_STATS", "1") != "0"
         self.fused_norm_bwd = os.environ.get("CONTOUR_FUSED_NORM_BWD", "1") != "0"
+        # True (CONTOUR_DETERMINISTIC=1): every f32 sum of the step has a fixed order and a single adder -- weight gradients
+        # with one pixel split, InstanceNorm sums by one workgroup per image, dgamma / dbeta by a finish pass, no epilogue
+        # fusions: bit-identical gradients run to run, at a fraction of the speed
+        self.deterministic = os.environ.get("CONTOUR_DETERMINISTIC", "0") == "1"
+        self._det_ws: Optional[Tensor] = None
         self._given_sums: Dict[str, Tensor] = {}       # layer prefix -> norm-backward sums gathered by the producer of its g
         self._producer: Dict[int, str] = {}            # id(Act) of a layer's output -> its prefix (valid for one step)
         # Dropout2d(p=0.5) between conv and norm in the listed ConvLayers (reference unet2.py:129-136,302: the last
@@ -200,7 +205,7 @@ class UNetEngine:
         z = torch.empty((n, oh, ow, co), dtype=self.dtype, device=w.device)
         # thin, large layers: the streaming kernel gathers the InstanceNorm statistics in its epilogue (no statistics pass)
         sums = None
-        fusable = (self.fused_stats and self.fused_norm and self.materialize and stride == 1 and self.dtype == torch.bfloat16
+        fusable = (self.fused_stats and not self.deterministic and self.fused_norm and self.materialize and stride == 1 and self.dtype == torch.bfloat16
                    and n * oh * ow >= (1 << 20) and not (ctx.training and prefix in self.drop_layers))
         if fusable:
             sums = self._arena["fwd"].take(2 * n * co, z.device)
@@ -233,7 +238,7 @@ class UNetEngine:
         gamma, beta = P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"]
         if self.fused_norm and self.materialize:
             ws = self._arena["fwd"].take(ops.resident_ws_floats(z.shape[0], z.shape[3]), z.device)
-            return ops.instnorm_fwd_fused(z, gamma, beta, self.slope, self.eps, ws=ws, mode=ops.NORM_WS_CLEAN)
+            return ops.instnorm_fwd_fused(z, gamma, beta, self.slope, self.eps, ws=ws, mode=self._norm_mode())
         out = Act(z, ops.instnorm_stats(z, gamma, beta, self.eps), self.slope)
         if self.materialize:
             ops.instnorm_apply(out)
@@ -335,6 +340,14 @@ class UNetEngine:
             ws = self._dwk_ws = torch.zeros(max(n, 9 * 480 * 960), dtype=torch.float32, device=device)
         return ws[:n].view(shape)
 
+    def _norm_mode(self) -> int:
+        return ops.NORM_WS_CLEAN | (ops.NORM_DETERMINISTIC if self.deterministic else 0)
+
+    def _splits(self) -> int:
+        """pixel splits of a weight-gradient launch: 0 = the library's choice, 1 = one workgroup per dWk block (each
+        element of the zeroed accumulator then receives exactly one add: deterministic)."""
+        return 1 if self.deterministic else 0
+
     def _wgrad_stream(self, *reads: Tensor):
         """``with`` block whose launches go to the weight-gradient stream, ordered after everything enqueued so far.  The
         tensors it reads are kept alive until ``_join_wgrad`` (no caching-allocator reuse under the side stream)."""
@@ -373,7 +386,7 @@ class UNetEngine:
         elif self.fused_norm:
             ws = self._arena["bwd"].take(ops.resident_ws_floats(g.shape[0], g.shape[3]), g.device)
             ops.instnorm_bwd_fused(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
-                                   G[f"{prefix}.norm.bias"], ws, mode=ops.NORM_WS_CLEAN)
+                                   G[f"{prefix}.norm.bias"], ws, mode=self._norm_mode())
         else:
             ops.instnorm_lrelu_bwd(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
                                    G[f"{prefix}.norm.bias"], None)
@@ -386,13 +399,19 @@ class UNetEngine:
         if rec.first:
             with self._wgrad_stream(g, ctx.img):
                 dw9 = self._dwk((9, co), g.device)
-                ops.conv_c1_wgrad(ctx.img, g, dw9)
+                det_ws = None
+                if self.deterministic:
+                    if self._det_ws is None or self._det_ws.device != g.device:
+                        self._det_ws = torch.empty(1 << 20, dtype=torch.float32, device=g.device)
+                    det_ws = self._det_ws
+                ops.conv_c1_wgrad(ctx.img, g, dw9, det_ws)
                 self._unprep(dw9.view(9, co, 1), G[f"{prefix}.conv.weight"], "conv", prefix)
             return
         ci = w.shape[1]
         with self._wgrad_stream(g, *[s_.z for s_ in rec.srcs]):
             dwk = self._dwk((9, co, ci), g.device)
-            ops.conv_wgrad(rec.srcs, g, dwk, grid=(oh, ow), in_stride=rec.stride, z_stride=1, taps=TAPS3_W, n_cols=co)
+            ops.conv_wgrad(rec.srcs, g, dwk, grid=(oh, ow), in_stride=rec.stride, z_stride=1, taps=TAPS3_W, n_cols=co,
+                           splits=self._splits())
             self._unprep(dwk, G[f"{prefix}.conv.weight"], "conv", prefix)
         if dsrc is None:
             return
@@ -408,7 +427,7 @@ class UNetEngine:
             nb = None
             src = rec.srcs[0] if len(rec.srcs) == 1 else None
             tgt = self._producer.get(id(src)) if src is not None else None
-            if (tgt is not None and self.fused_norm_bwd and self.fused_norm and self.dtype == torch.bfloat16 and not acc[0]
+            if (tgt is not None and self.fused_norm_bwd and not self.deterministic and self.fused_norm and self.dtype == torch.bfloat16 and not acc[0]
                     and n * sh * sw >= (1 << 20) and ctx.convs[tgt].drop_mask is None and ctx.convs[tgt].out.stats is not None):
                 nb = (ctx.convs[tgt].out, self._arena["bwd"].take(2 * n * cols[0], g.device))
             got = ops.conv_gemm([gz], wd, None, grid=(sh, sw), in_stride=1, taps=TAPS3_D, dsts=dsts, dst_cols=cols,
@@ -437,7 +456,8 @@ class UNetEngine:
         with self._wgrad_stream(du, rec.src.z):
             dwk = self._dwk((4, co, ci), du.device)
             taps = [(0, 0, dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)]
-            ops.conv_wgrad([rec.src], du, dwk, grid=(h, w_), in_stride=1, z_stride=2, taps=taps, n_cols=co)
+            ops.conv_wgrad([rec.src], du, dwk, grid=(h, w_), in_stride=1, z_stride=2, taps=taps, n_cols=co,
+                           splits=self._splits())
             self._unprep(dwk, G[f"{rec.prefix}.weight"], "convT", rec.prefix)
         _, wd = self._operands(f"{rec.prefix}.weight", w, "convT")
         ops.conv_gemm([Act(du, None, 1.0)], wd, None, grid=(h, w_), in_stride=2,
@@ -464,7 +484,8 @@ class UNetEngine:
         w = P["output_block.conv.weight"]
         with self._wgrad_stream(dl, last.z):
             dwk = self._dwk((1, 32, c_last), dl.device)
-            ops.conv_wgrad([last], dl, dwk, grid=(h, w_), in_stride=1, z_stride=1, taps=[(0, 0, 0, 0, 0)], n_cols=32)
+            ops.conv_wgrad([last], dl, dwk, grid=(h, w_), in_stride=1, z_stride=1, taps=[(0, 0, 0, 0, 0)], n_cols=32,
+                           splits=self._splits())
             self._unprep(dwk, G["output_block.conv.weight"], "conv", "output_block")
         _, wd = self._operands("output_block.conv.weight", w, "conv", cop=32)
         g = torch.empty_like(last.z)
@@ -519,6 +540,7 @@ class ConfidenceEngine:
     def __init__(self, dtype: torch.dtype = torch.bfloat16):
         self.dtype = dtype
         self._opcache: Dict[str, Tuple] = {}
+        self.deterministic = os.environ.get("CONTOUR_DETERMINISTIC", "0") == "1"      # as UNetEngine.deterministic
 
     def _operands(self, name, w):
         key = (w.data_ptr(), w._version, ops.PARAM_EPOCH[0])
@@ -554,9 +576,10 @@ class ConfidenceEngine:
             src, out = acts[li], acts[li + 1]
             w = P[f"model.{i}.weight"]
             co, ci = w.shape[0], w.shape[1]
-            ops.act_bwd(g, out.z, 0.0, G[f"model.{i}.bias"])
+            ops.act_bwd(g, out.z, 0.0, G[f"model.{i}.bias"], deterministic=self.deterministic)
             dwk = torch.zeros((9, co, ci), dtype=torch.float32, device=g.device)
-            ops.conv_wgrad([src], g, dwk, grid=(h, w_), in_stride=1, z_stride=1, taps=TAPS3_W, n_cols=co)
+            ops.conv_wgrad([src], g, dwk, grid=(h, w_), in_stride=1, z_stride=1, taps=TAPS3_W, n_cols=co,
+                           splits=1 if self.deterministic else 0)
             ops.grad_unprep(dwk, G[f"model.{i}.weight"], "conv", accumulate=True)
             if li == 0 and not need_input_grad:
                 return None

@@ -58,6 +58,7 @@ _SIGS = {
     "cu_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc)] + [_P] * 9),
     "cu_conv_c1_fwd": (C.c_int, [C.c_int] * 5 + [_P] * 5),
     "cu_conv_c1_wgrad": (C.c_int, [C.c_int] * 5 + [_P] * 4),
+    "cu_conv_c1_wgrad_det": (C.c_int, [C.c_int] * 5 + [_P] * 4 + [C.c_size_t, _P]),
     "cu_instnorm_stats": (C.c_int, [C.c_int] * 4 + [_P] * 3 + [C.c_float] + [_P] * 3),
     "cu_instnorm_apply": (C.c_int, [C.c_int] * 4 + [_P] * 2 + [C.c_float] + [_P] * 2),
     "cu_instnorm_lrelu_bwd": (C.c_int, [C.c_int] * 4 + [_P] * 4 + [C.c_float] + [_P] * 5),
@@ -70,6 +71,7 @@ _SIGS = {
     "cu_maxpool2_fwd": (C.c_int, [C.c_int] * 5 + [_P] * 4),
     "cu_maxpool2_bwd": (C.c_int, [C.c_int] * 5 + [_P] * 4),
     "cu_act_bwd": (C.c_int, [C.c_int] * 4 + [_P] * 2 + [C.c_float] + [_P] * 2),
+    "cu_act_bwd_det": (C.c_int, [C.c_int] * 4 + [_P] * 2 + [C.c_float] + [_P] * 2),
     "cu_act_to_nchw_f32": (C.c_int, [C.c_int] * 4 + [_P] * 2 + [C.c_float] + [_P] * 2),
     "cu_nchw_f32_to_nhwc": (C.c_int, [C.c_int] * 5 + [_P] * 3),
     "cu_nhwc_to_nchw_f32": (C.c_int, [C.c_int] * 4 + [_P] * 2 + [C.c_int, _P]),

@@ -199,11 +199,16 @@ def conv_c1_fwd(img: Tensor, w9: Tensor, bias: Optional[Tensor], dst: Tensor):
                                         L.ptr(dst), L.stream_ptr()), "cu_conv_c1_fwd")
 
 
-def conv_c1_wgrad(img: Tensor, dz: Tensor, dw9: Tensor):
+def conv_c1_wgrad(img: Tensor, dz: Tensor, dw9: Tensor, det_ws: Optional[Tensor] = None):
+    """``det_ws`` (float32 workspace): per-workgroup partial sums + a fixed-order finish instead of atomics."""
     n, h, w_, co = dz.shape
     with _Prof("conv_c1"):
-        L.check(L.load().cu_conv_c1_wgrad(L.dtype_code(dz.dtype), n, h, w_, co, L.ptr(img), L.ptr(dz), L.ptr(dw9),
-                                          L.stream_ptr()), "cu_conv_c1_wgrad")
+        if det_ws is not None:
+            L.check(L.load().cu_conv_c1_wgrad_det(L.dtype_code(dz.dtype), n, h, w_, co, L.ptr(img), L.ptr(dz), L.ptr(dw9),
+                                                  L.ptr(det_ws), det_ws.numel(), L.stream_ptr()), "cu_conv_c1_wgrad_det")
+        else:
+            L.check(L.load().cu_conv_c1_wgrad(L.dtype_code(dz.dtype), n, h, w_, co, L.ptr(img), L.ptr(dz), L.ptr(dw9),
+                                              L.stream_ptr()), "cu_conv_c1_wgrad")
 
 
 def instnorm_stats(z: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float = 1e-5) -> Tensor:
@@ -242,6 +247,7 @@ def _resident_ws(n: int, c: int, device) -> Tensor:
 
 
 NORM_WS_CLEAN = 16     # include/contour_hip.h: CU_NORM_WS_CLEAN
+NORM_DETERMINISTIC = 32    # CU_NORM_DETERMINISTIC: one workgroup per image, fixed summation order
 
 
 def resident_ws_floats(n: int, c: int) -> int:
@@ -333,11 +339,11 @@ def channel_scale(x: Tensor, mask: Tensor):
                 "cu_channel_scale")
 
 
-def act_bwd(g: Tensor, z: Tensor, slope: float, dbias):
+def act_bwd(g: Tensor, z: Tensor, slope: float, dbias, deterministic: bool = False):
     n, h, w_, c = g.shape
     with _Prof("small"):
-        L.check(L.load().cu_act_bwd(L.dtype_code(g.dtype), n, h * w_, c, L.ptr(g), L.ptr(z), slope, L.ptr(dbias),
-                                    L.stream_ptr()), "cu_act_bwd")
+        fn = L.load().cu_act_bwd_det if deterministic else L.load().cu_act_bwd
+        L.check(fn(L.dtype_code(g.dtype), n, h * w_, c, L.ptr(g), L.ptr(z), slope, L.ptr(dbias), L.stream_ptr()), "cu_act_bwd")
 
 
 def act_to_nchw_f32(act: Act) -> Tensor:

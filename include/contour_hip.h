@@ -126,7 +126,8 @@ typedef struct {
     int tap_zy[CU_MAX_TAPS], tap_zx[CU_MAX_TAPS];     /* Z offsets */
     int tap_w[CU_MAX_TAPS];
     float slope0, slope1;
-    int splits;                    /* pixel-range splits (grid.z); 0 = auto */
+    int splits;                    /* pixel-range splits (grid.y); 0 = auto; 1 = one workgroup per dW block whose partial
+                                    * sums are added in a fixed order: bit-identical results run to run (slow) */
 } cu_wgrad_desc;
 
 int cu_conv_wgrad(const cu_wgrad_desc* d,
@@ -139,6 +140,10 @@ int cu_conv_c1_fwd(int dtype, int N, int H, int W, int CO, const float* img /* [
                    const float* w /* [9][CO] f32 */, const float* bias, void* dst /* NHWC */, void* stream);
 int cu_conv_c1_wgrad(int dtype, int N, int H, int W, int CO, const float* img, const void* dz /* NHWC */,
                      float* dw /* [9][CO] f32, += */, void* stream);
+/* The same with the workgroups' partial sums stored in ws (>= (rows chunks x N) x 9 x CO floats; 2^20 covers every shape
+ * of the path) and added to dw in workgroup order by a finish pass: no atomics, bit-identical run to run. */
+int cu_conv_c1_wgrad_det(int dtype, int N, int H, int W, int CO, const float* img, const void* dz, float* dw, float* ws,
+                         size_t ws_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * InstanceNorm2d(affine) + LeakyReLU (layers.py:193-194) in its fused form.
@@ -170,6 +175,9 @@ int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, const void* 
  * all layers of a step instead of one launch per layer); the call leaves it dirty.  After the
  * stream has drained, ((unsigned*)ws)[1] != 0 after a mode-1 call reports that its bounded arrival wait gave up. */
 #define CU_NORM_WS_CLEAN 16
+/* + CU_NORM_DETERMINISTIC: two-pass kernels with one workgroup per image (fixed summation order, every sum has a single
+ * adder) and, in the backward, dgamma / dbeta summed over the images by a finish pass: bit-identical results run to run. */
+#define CU_NORM_DETERMINISTIC 32
 size_t cu_instnorm_resident_ws_floats(int N, int C);
 int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* z, const float* gamma, const float* beta,
                           float eps, float slope, float* stats, void* out, float* ws, int mode, void* stream);
@@ -195,6 +203,9 @@ int cu_maxpool2_fwd(int dtype, int N, int OH, int OW, int C, const void* x, void
 int cu_maxpool2_bwd(int dtype, int N, int OH, int OW, int C, const void* dy, const unsigned char* idx, void* dx, void* stream);
 /* plain activation backward for layers without norm (ConfidenceNet ReLU): g *= (z > 0 ? 1 : slope); dbias[c] += sum g */
 int cu_act_bwd(int dtype, int N, int HW, int C, void* g, const void* z, float slope, float* dbias, void* stream);
+/* The same by ONE workgroup over the whole batch (N * HW <= 2^20 pixels: the ConfidenceNet head): dbias has a fixed
+ * summation order and a single adder -- deterministic mode. */
+int cu_act_bwd_det(int dtype, int N, int HW, int C, void* g, const void* z, float slope, float* dbias, void* stream);
 /* materialise act(z*scale+shift) as NCHW f32 (the bottleneck clone handed to the skew head, unet2.py:186) and back */
 int cu_act_to_nchw_f32(int dtype, int N, int HW, int C, const void* z, const float* stats, float slope,
                        float* out, void* stream);

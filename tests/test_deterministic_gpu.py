@@ -1,0 +1,61 @@
+"""Deterministic mode: with ``engine.deterministic`` every f32 sum of the training step has a
+fixed order and a single adder -- weight gradients with one pixel split (one workgroup per dWk block), InstanceNorm sums
+by one workgroup per image (``CU_NORM_DETERMINISTIC``), dgamma / dbeta by a finish pass over the images, the first
+layer's weight gradient from per-workgroup partials (``cu_conv_c1_wgrad_det``), the ConfidenceNet bias gradient by one
+workgroup (``cu_act_bwd_det``), no epilogue fusions -- so two runs of the same step give bit-identical losses and
+gradients, and those agree with the default (atomics) mode to rounding."""
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def _step(task, batch):
+    for p in task.parameters():
+        p.grad = None
+    out = task.training_step(batch, 0)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    grads = {k: p.grad.detach().clone() for k, p in task.named_parameters() if p.grad is not None}
+    return float(out["loss"].detach()), grads
+
+
+@pytest.mark.parametrize("kind,stages,size,dtype,n", [("dsnt-skew", 6, 64, "bf16", 6), ("dsnt-al", 4, 64, "f32", 4)])
+def test_two_runs_of_a_step_are_bit_identical(kind, stages, size, dtype, n):
+    from test_model_gpu import make_task
+    from contour_uncertainty.data.synthetic import synthetic_batch
+    torch.manual_seed(0)
+    task = make_task(kind, stages, size, dtype).to("cuda")
+    img, contour = synthetic_batch(n, size, 21, seed=5)
+    batch = {"img": img.cuda(), "contour": contour.cuda()}
+    engines = [task.model.engine] + ([task.skew_block.engine] if hasattr(task, "skew_block") else [])
+    _step(task, batch)                                  # warm-up: operand copies, workspaces
+    loss_default, g_default = _step(task, batch)
+    for e in engines:
+        e.deterministic = True
+    runs = [_step(task, batch) for _ in range(3)]
+    for e in engines:
+        e.deterministic = False
+    l0, g0 = runs[0]
+    assert len(g0) > 20
+    for l, g in runs[1:]:
+        assert l == l0
+        assert g.keys() == g0.keys()
+        for k in g0:
+            assert torch.equal(g[k], g0[k]), k
+    # the same numbers as the default mode up to summation order.  Per-parameter comparison on the well-conditioned f32
+    # network only: the 6-stage bf16 network normalises 2 x 2 maps, where the last bit of a statistic moves the deep
+    # layers' gradients by tens of per cent between two DEFAULT runs already (tests/test_graph_gpu.py)
+    assert abs(l0 - loss_default) <= (2e-3 if dtype == "bf16" else 1e-5) * max(1.0, abs(loss_default))
+    if dtype == "f32":
+        worst = 0.0
+        for k in g0:
+            den = float(g_default[k].norm())
+            if den > 0:
+                worst = max(worst, float((g0[k] - g_default[k]).norm()) / den)
+        assert worst < 1e-3, worst

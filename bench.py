@@ -88,6 +88,52 @@ def cpu_baseline(size: int, n_stages: int, task_name: str, batch: int, steps: in
             "kind": "port", "sample": f"{steps} steps of batch {batch} at {size}x{size}, fp32, oracle/step.py"}
 
 
+def parity_report(dev, steps: int = 20):
+    """Parity checks printed WITH the number, at the smoke size (6 stages, 64x64, batch 2,
+    the seeded weights and inputs the committed golden vectors were made with -- product code only, no oracle):
+      f32 : max relative error of mu / Sigma / alpha of ``predict_on_batch`` (f32 parity mode) vs the REFERENCE's own outputs
+            (tests/golden/train_step.npz, written by oracle/make_golden.py from the imported reference); north_star bound 1e-4.
+      bf16: contour NLL (the `loss` log) of the bf16 production mode vs the f32 parity mode after `steps` identical Adam
+            steps on one fixed batch, same initial weights."""
+    import numpy as np
+    from contour_uncertainty.data.synthetic import synthetic_batch
+    from contour_uncertainty.data.synthetic.weights import seeded_confidence_state, seeded_unet_state
+    gold = ROOT / "tests" / "golden" / "train_step.npz"
+    if not gold.exists():
+        return None
+    g = np.load(gold)
+    img, contour = synthetic_batch(2, 64, 21, seed=1234)
+    batch = {"img": img.to(dev), "contour": contour.to(dev)}
+    out = {}
+    finals = {}
+    for dtype in ("f32", "bf16"):
+        task, _ = build_task(64, dtype, "dsnt-skew")
+        gen = torch.Generator().manual_seed(0)
+        task.model.load_state_dict(seeded_unet_state(task.model, gen), strict=True)
+        task.skew_block.load_state_dict(seeded_confidence_state(task.skew_block, gen), strict=True)
+        task = task.to(dev)
+        if dtype == "f32":
+            mu, sigma, alpha = task.predict_on_batch(batch["img"], task.model)[:3]
+            for name, got, key in (("mu", mu, "dsnt-skew_mu0"), ("sigma", sigma, "dsnt-skew_sigma0"),
+                                   ("alpha", alpha, "dsnt-skew_alpha0_predict")):
+                ref = torch.from_numpy(g[key])
+                out[f"f32_{name}_max_rel_vs_reference"] = float(f"{float((got.cpu() - ref).abs().max() / ref.abs().max()):.3e}")
+        opt = task.configure_optimizers()["optimizer"]
+        for i in range(steps):
+            opt.zero_grad(set_to_none=True)
+            o = task.training_step(batch, i)
+            o["loss"].backward()
+            opt.step()
+        with torch.no_grad():
+            finals[dtype] = float(task._shared_step(batch, 0)["loss"])
+    out["reference_bound"] = 1e-4
+    out[f"nll_f32_after_{steps}_steps"] = round(finals["f32"], 5)
+    out[f"nll_bf16_after_{steps}_steps"] = round(finals["bf16"], 5)
+    out["nll_bf16_minus_f32"] = round(finals["bf16"] - finals["f32"], 5)
+    out["sample"] = "dsnt-skew, 6-stage unet2, 64x64, batch 2, seed 0 weights / seed 1234 inputs (tests/golden/train_step.npz)"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,6 +151,9 @@ def main():
                          "on the eager step is faster: its weight-gradient stream runs beside the main one, which a "
                          "replayed graph serialises -- profiles/r02_small_batch_graph.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-comm-probe", action="store_true",
+                    help="N > 1: skip the extra timed pass without gradient exchange (exposed_comm_ms)")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -193,6 +242,39 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
 
+    # ---- N > 1: make the run diagnosable: the process group really has N ranks on N devices, every
+    #      rank holds the same parameters after the timed steps, and how much of the step the gradient exchange costs
+    multi = None
+    if world > 1:
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == backend
+        flat, _ = task.model.flat_params()
+        cs = torch.stack([flat.double().sum(), flat.double().abs().sum()])
+        gathered = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(gathered, cs)
+        same = all(bool(torch.equal(gathered[0], x)) for x in gathered)
+        devs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(devs, torch.tensor([torch.cuda.current_device()], device=dev))
+        multi = {"backend": backend, "world": dist.get_world_size(), "devices": [int(x) for x in devs],
+                 "param_checksums_equal": same, "param_checksum": [float(x) for x in gathered[0]],
+                 "comm": "native cu_comm_* (RCCL)" if sync.native is not None else f"torch.distributed {backend}"}
+        if not args.no_comm_probe and captured is None:
+            # the same K steps with the collectives replaced by nothing (the ranks then drift apart: the result is
+            # discarded; this is the last thing the model is used for): step time - this = exposed communication
+            sync.dry = True
+            for i in range(2):
+                step(i)
+            fence()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                step(i)
+            fence()
+            dt_dry = time.perf_counter() - t1
+            sync.dry = False
+            t = torch.tensor([dt_dry], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            multi["ms_per_step_without_exchange"] = round(float(t) / args.steps * 1e3, 3)
+            multi["exposed_comm_ms"] = round(dt / args.steps * 1e3 - float(t) / args.steps * 1e3, 3)
+
     result = None
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -210,6 +292,8 @@ def main():
                        "parallelism": f"dp{world}", "final_loss": round(loss, 4),
                        "mfma_roofline_frac_whole_step": round(value / world * flops_step_img / PEAK_BF16_DENSE, 4)},
         }
+        if multi is not None:
+            result["multi_gpu"] = multi
 
     # ---- roofline of the dominant kernel family: separate profiled pass (events around every launch).  Every rank
     #      runs the two extra steps (they contain collectives); only rank 0 records.
@@ -230,37 +314,51 @@ def main():
             e.side_wgrad = s_
     if rank == 0 and not args.no_roofline:
         fam = {}
-        for name, flops, e0, e1, *_ in ops.PROFILE:
+        for name, flops, e0, e1, _note, _bytes, xflops in ops.PROFILE:
             ms_k = e0.elapsed_time(e1)
-            f = fam.setdefault(name, [0.0, 0.0, 0])
-            f[0] += flops
+            f = fam.setdefault(name, [0.0, 0.0, 0, 0.0])
+            f[0] += flops              # ALGORITHMIC FLOPs (cu_hip/ops.py: existing (tap, parity) pairs, true class count)
             f[1] += ms_k
             f[2] += 1
+            f[3] += xflops             # executed (padding and absent taps included): reported beside, never in `frac`
         total_ms = sum(v[1] for v in fam.values())
         dom = max(fam.items(), key=lambda kv: kv[1][1])
-        name, (fl, ms_k, cnt) = dom
+        name, (fl, ms_k, cnt, xfl) = dom
         achieved = fl / (ms_k * 1e-3) / 1e12
-        traffic = None
-        pmc = ROOT / "profiles" / "r02_pmc_hbm_traffic.json"     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this bench
-        if pmc.exists() and per_gpu == 64 and args.size == 256 and args.dtype == "bf16":
-            famrec = json.loads(pmc.read_text())["families"].get(name)
-            if famrec:
-                traffic = round(famrec["bytes_per_launch"])
+        traffic, pmc_used = None, None
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes of this very command (FETCH_SIZE x 2 + WRITE_SIZE,
+        # MI355X_MICROARCH.md HBM section), committed under profiles/: a COMMITTED constant of the newest such file, not a
+        # measurement of this run (traffic_source says which)
+        for cand in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+            pmc = ROOT / "profiles" / cand
+            if pmc.exists() and per_gpu == 64 and args.size == 256 and args.dtype == "bf16":
+                famrec = json.loads(pmc.read_text())["families"].get(name)
+                if famrec:
+                    traffic, pmc_used = round(famrec["bytes_per_launch"]), cand
+                    break
         symbols = {"igemm_conv": "igemm_conv_kernel<*> + igemm_conv_dma_kernel<*> + igemm_conv_dma_ring_kernel + pconv_kernel<*> + pconv2_kernel + tconv_kernel<*> (all instantiations; + ksplit_finish_kernel)",
                    "igemm_wgrad": "igemm_wgrad_kernel<*> + igemm_wgrad_dma_kernel<*> (all instantiations)"}
         result["roofline"] = {"bound": "mfma", "kernel": name, "kernel_symbols": symbols.get(name, name),
                               "achieved": round(achieved, 2),
                               "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
                               "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": traffic,
-                              "traffic_source": "profiles/r02_pmc_hbm_traffic.json (HBM bytes per launch, PMC)" if traffic else None,
+                              "traffic_source": f"committed: profiles/{pmc_used} (HBM bytes per launch from separate --pmc passes "
+                                                f"of this command; not measured in this run)" if traffic else None,
+                              "flops": "algorithmic (existing taps, true class count)",
+                              "executed_tflops": round(xfl / (ms_k * 1e-3) / 1e12, 2),
                               "launches_per_step": cnt // 2, "avg_launch_ms": round(ms_k / cnt, 4),
                               "flops_per_launch": fl / cnt,
                               "family_ms_per_step": {k: round(v[1] / 2, 3) for k, v in fam.items()},
                               "family_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 2) for k, v in fam.items()
                                                 if v[1] > 0 and v[0] > 0},
+                              "mfma_ms_per_step": round(sum(v[1] for v in fam.values() if v[0] > 0) / 2, 3),
+                              "mfma_algorithmic_tflop_per_step": round(sum(v[0] for v in fam.values()) / 2 / 1e12, 4),
                               "profiled_ms_per_step": round(total_ms / 2, 3)}
     if world > 1:
         dist.barrier()
+    if rank == 0 and world == 1 and not args.no_parity:
+        print("[bench] parity checks at the smoke size ...", file=sys.stderr, flush=True)
+        result["parity"] = parity_report(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         print("[bench] timing the CPU oracle baseline ...", file=sys.stderr, flush=True)
         # bounded sample of the same workload: ~15 s of host work (24 steps of batch 4 at 256x256)

@@ -33,6 +33,12 @@ struct WgKArgs {
     int pc_items;                              // producer/consumer kernel: staging rounds issued by the producer waves
     int pc_early;                              // ... and rounds the computing waves issue before their k-loop
     int dbg;                                   // CU_CONV_DBG bits (timing experiments): 1 no atomics, 2 no MFMA, 4 no commit, 8 no loads
+    // partial-tile mode (cu_conv_wgrad_parts): part_stride != 0 -> every adder of a dW block STORES its partial tile into
+    // its own slab dw + part * part_stride (plain stores, no atomics); the slabs are summed in a fixed order by
+    // cu_grad_unprep_parts.  max_parts / nparts are host-side only (slab capacity in, slabs written out).
+    size_t part_stride;
+    int max_parts, nparts;
+    int* nparts_out;
 };
 
 template <typename T> struct WCfg;
@@ -299,15 +305,22 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
     const int c = c_base + cblk * 32 + r;
     auto flush = [&]() {
         if (!wave_active || c >= CI) return;
+        // partial-tile mode: slab of (pixel split, k-part) -- each (tap, n, c) of a slab has exactly one writer
+        float* dwp = p.dw + (size_t)(blockIdx.y * KSPLIT + kpart) * p.part_stride;
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int n = n_base + nblk * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                if (n < p.CO) unsafeAtomicAdd(p.dw + ((size_t)p.tap_w[t] * p.CO + n) * CI + c, acc[t][i]);
+                if (n < p.CO) {
+                    float* o = dwp + ((size_t)p.tap_w[t] * p.CO + n) * CI + c;
+                    if (p.part_stride) *o = acc[t][i];
+                    else unsafeAtomicAdd(o, acc[t][i]);
+                }
             }
         }
     };
+    if (p.part_stride) { flush(); return; }
     if constexpr (KSPLIT > 1) {
         // one pixel split (cu_wgrad_desc.splits == 1, the deterministic mode): this workgroup is the only adder of its dW
         // block, and its KSPLIT k-parts add one after the other -- a fixed summation order
@@ -616,12 +629,17 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     const int r = lane & 31, h2 = lane >> 5;
     const int c = c_base + cblk * 32 + r;
     if (c >= CI) return;
+    float* dwp = p.dw + (size_t)byi * p.part_stride;      // partial-tile mode: the slab of this pixel split
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int n = n_base + nblk * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
-            if (n < p.CO) unsafeAtomicAdd(p.dw + ((size_t)p.tap_w[t] * p.CO + n) * CI + c, acc[t][i]);
+            if (n < p.CO) {
+                float* o = dwp + ((size_t)p.tap_w[t] * p.CO + n) * CI + c;
+                if (p.part_stride) *o = acc[t][i];
+                else unsafeAtomicAdd(o, acc[t][i]);
+            }
         }
     }
 }
@@ -639,6 +657,11 @@ int launch_dma(WgKArgs& a, hipStream_t st) {
         a.splits = want < 1 ? 1 : want;
     }
     if (a.splits > a.ntiles) a.splits = a.ntiles;
+    if (a.part_stride) {
+        if (a.splits > a.max_parts) a.splits = a.max_parts;
+        a.nparts = a.splits;
+        *a.nparts_out = a.nparts;
+    }
     hipLaunchKernelGGL(k, dim3(a.ctiles * ntn, a.splits), dim3(64 * NW), 0, st, a);
     CU_LAUNCH_CHECK();
     return 0;
@@ -666,6 +689,13 @@ int launch_k(WgKArgs& a, hipStream_t st) {
         a.splits = want < 1 ? 1 : want;
     }
     if (a.splits > a.ntiles) a.splits = a.ntiles;
+    if (a.part_stride) {
+        constexpr int KS = 4 / (NBLK * CBLK);          // k-parts of a block: one slab each
+        if (a.splits * KS > a.max_parts) a.splits = a.max_parts / KS;
+        CU_CHECK_ARG(a.splits >= 1, "cu_conv_wgrad_parts: workspace holds %d slabs, this shape needs >= %d", a.max_parts, KS);
+        a.nparts = a.splits * KS;
+        *a.nparts_out = a.nparts;
+    }
     dim3 grid(a.ctiles * ntn, a.splits);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
     CU_LAUNCH_CHECK();
@@ -674,9 +704,9 @@ int launch_k(WgKArgs& a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const float* scale0, const float* shift0,
-                             const void* src1, const float* scale1, const float* shift1, const void* z, float* dw,
-                             void* stream) {
+static int wgrad_impl(const cu_wgrad_desc* d, const void* src0, const float* scale0, const float* shift0,
+                      const void* src1, const float* scale1, const float* shift1, const void* z, float* dw,
+                      size_t parts_floats, int* nparts, void* stream) {
     CU_CHECK_ARG(d != nullptr, "cu_conv_wgrad: null descriptor");
     CU_CHECK_ARG(d->dtype == CU_F32 || d->dtype == CU_BF16, "cu_conv_wgrad: bad dtype %d", d->dtype);
     CU_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= CU_MAX_TAPS, "cu_conv_wgrad: ntaps %d", d->ntaps);
@@ -695,6 +725,15 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
     a.ZH = d->ZH; a.ZW = d->ZW; a.ZC = d->ZC; a.ZS = d->ZS; a.CO = d->CO; a.ntaps = d->ntaps;
     a.slope0 = d->slope0; a.slope1 = d->slope1; a.splits = d->splits;
     a.dbg = cu_env_int("CU_CONV_DBG", 0);
+    if (nparts) {         // partial-tile mode: slabs of [wtaps][CO][C0+C1] floats
+        size_t wt = 0;
+        for (int t = 0; t < d->ntaps; ++t) wt = (size_t)d->tap_w[t] + 1 > wt ? (size_t)d->tap_w[t] + 1 : wt;
+        a.part_stride = wt * (size_t)d->CO * (size_t)(d->C0 + d->C1);
+        const size_t cap = parts_floats / a.part_stride;
+        CU_CHECK_ARG(cap >= 1, "cu_conv_wgrad_parts: workspace of %zu floats holds no slab of %zu", parts_floats, a.part_stride);
+        a.max_parts = cap > 4096 ? 4096 : (int)cap;
+        a.nparts_out = nparts;
+    }
 
     const int CI_all = d->C0 + d->C1;
     // 64-wide blocks of dW unless the loop grid is tiny (<= CU_WGRAD_SMALLPX pixels, tuning knob): then 32 x 32 blocks put
@@ -870,4 +909,18 @@ extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const flo
     }
 #undef CU_WT
 #undef CU_W
+}
+
+extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const float* scale0, const float* shift0,
+                             const void* src1, const float* scale1, const float* shift1, const void* z, float* dw,
+                             void* stream) {
+    return wgrad_impl(d, src0, scale0, shift0, src1, scale1, shift1, z, dw, 0, nullptr, stream);
+}
+
+extern "C" int cu_conv_wgrad_parts(const cu_wgrad_desc* d, const void* src0, const float* scale0, const float* shift0,
+                                   const void* src1, const float* scale1, const float* shift1, const void* z, float* parts,
+                                   size_t parts_floats, int* nparts, void* stream) {
+    CU_CHECK_ARG(nparts != nullptr && parts != nullptr, "cu_conv_wgrad_parts: null pointer");
+    *nparts = 0;
+    return wgrad_impl(d, src0, scale0, shift0, src1, scale1, shift1, z, parts, parts_floats, nparts, stream);
 }

@@ -254,7 +254,8 @@ constexpr int UNPREP_MAXT = 9;
 // every load in turn: 10 us per launch on average, 41 launches per step) or 0 = run-time count NTr.
 template <int NT>
 __global__ __launch_bounds__(256) void grad_unprep_rows_kernel(float* __restrict__ dwk, float* __restrict__ g, int NTr,
-                                                               int CO, int CI, int COP, long s_co, long s_ci, int accumulate) {
+                                                               int CO, int CI, int COP, long s_co, long s_ci, int accumulate,
+                                                               int nparts = 1, size_t pstride = 0) {
     __shared__ float tile[8 * (32 * UNPREP_MAXT + 1)];
     const int nt = NT ? NT : NTr;
     const bool co_rows = s_co > s_ci;                  // conv: rows = co, columns = ci; transposed conv: the other way
@@ -272,6 +273,13 @@ __global__ __launch_bounds__(256) void grad_unprep_rows_kernel(float* __restrict
             float v[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) v[t] = ok ? src[t * tstride] : 0.f;
+            // partial-tile form (cu_grad_unprep_parts): slabs 1 .. nparts-1 added in slab order (a fixed summation order)
+#pragma unroll 4
+            for (int s = 1; s < nparts; ++s) {
+                const float* sp = src + (size_t)s * pstride;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] += ok ? sp[t * tstride] : 0.f;
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 tile[ty * pitch + tx * NT + t] = v[t];
@@ -279,7 +287,9 @@ __global__ __launch_bounds__(256) void grad_unprep_rows_kernel(float* __restrict
             }
         } else {
             for (int t = 0; t < nt; ++t) {
-                tile[ty * pitch + tx * nt + t] = ok ? src[t * tstride] : 0.f;
+                float v = ok ? src[t * tstride] : 0.f;
+                for (int s = 1; s < nparts; ++s) v += ok ? src[(size_t)s * pstride + t * tstride] : 0.f;
+                tile[ty * pitch + tx * nt + t] = v;
                 if (ok && (accumulate & 2)) src[t * tstride] = 0.f;
             }
         }
@@ -309,6 +319,24 @@ __global__ __launch_bounds__(256) void grad_unprep_rows_kernel(float* __restrict
             }
         }
     }
+}
+
+// Partial tiles of the weight gradient (cu_conv_wgrad_parts): parts[s][e], s < S slabs of E floats.  Workgroups of
+// grid.y = group j sum the G consecutive slabs j*G .. j*G+G-1 INTO slab j*G, in slab order (fixed summation order, no
+// atomics): the thin layers have up to 256 slabs of a small tile, which the un-preparation's few workgroups would walk
+// one L2 round trip at a time.
+__global__ __launch_bounds__(256) void parts_reduce_kernel(float* __restrict__ parts, size_t E4, int S, int G) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= E4) return;
+    const int s0 = blockIdx.y * G, n = min(G, S - s0);
+    f32x4* base = reinterpret_cast<f32x4*>(parts) + (size_t)s0 * E4 + i;
+    f32x4 acc = base[0];
+#pragma unroll 8
+    for (int s = 1; s < n; ++s) {
+        const f32x4 v = base[(size_t)s * E4];
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    base[0] = acc;
 }
 
 // ---- batched form: the operand copies of every conv layer of the network in ONE launch ---------------------------------
@@ -631,6 +659,33 @@ extern "C" int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_
     dim3 grid(cdiv(CI, 32), cdiv(CO, 32), T);
     hipLaunchKernelGGL(grad_unprep_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dwk, grad, CO, CI,
                        COP, s_co, s_ci, accumulate);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_grad_unprep_parts(int T, int CO, int CI, int COP, long s_co, long s_ci, float* parts, int nparts,
+                                    float* grad, int accumulate, void* stream) {
+    CU_CHECK_ARG(T > 0 && CO > 0 && CI > 0 && COP >= CO && parts && grad && nparts >= 1, "cu_grad_unprep_parts: bad argument");
+    const bool co_rows = s_co > s_ci;
+    CU_CHECK_ARG((T == 9 || T == 4 || T == 1) && ((co_rows && s_ci == T) || (!co_rows && s_co == T)),
+                 "cu_grad_unprep_parts: taps must be innermost in the logical layout (T = 9, 4 or 1)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t E = (size_t)T * COP * CI;
+    CU_CHECK_ARG(E % 4 == 0, "cu_grad_unprep_parts: slab size must be a multiple of 4 floats");
+    size_t pstride = E;
+    if (nparts > 16) {          // first level: <= 16 group sums, by the whole chip
+        const int G = cdiv(nparts, 16), groups = cdiv(nparts, G);
+        hipLaunchKernelGGL(parts_reduce_kernel, dim3((unsigned)((E / 4 + 255) / 256), groups), dim3(256), 0, st, parts, E / 4,
+                           nparts, G);
+        CU_LAUNCH_CHECK();
+        nparts = groups;
+        pstride = (size_t)G * E;
+    }
+    dim3 grid(cdiv(co_rows ? CI : CO, 32), cdiv(co_rows ? CO : CI, 8));
+    const int acc = accumulate & 1;
+    if (T == 9) hipLaunchKernelGGL(grad_unprep_rows_kernel<9>, grid, dim3(256), 0, st, parts, grad, T, CO, CI, COP, s_co, s_ci, acc, nparts, pstride);
+    else if (T == 4) hipLaunchKernelGGL(grad_unprep_rows_kernel<4>, grid, dim3(256), 0, st, parts, grad, T, CO, CI, COP, s_co, s_ci, acc, nparts, pstride);
+    else hipLaunchKernelGGL(grad_unprep_rows_kernel<1>, grid, dim3(256), 0, st, parts, grad, T, CO, CI, COP, s_co, s_ci, acc, nparts, pstride);
     CU_LAUNCH_CHECK();
     return 0;
 }

@@ -730,7 +730,7 @@ __device__ __forceinline__ float rc_read(const float* p) {
 // floats), and the totals come back through LDS from one coalesced agent-scope load per workgroup.
 template <int PIECE>
 __device__ __forceinline__ void rc_exchange(const float (&acc)[2][PIECE], float* lds, float* row, unsigned* flag, int C,
-                                            int piece, bool holder, int nchunks, int dbg) {
+                                            int piece, bool holder, int nchunks, int dbg, unsigned* s_flag) {
     __syncthreads();                      // reduce_rows is done with the LDS scratch
     if (holder) {
 #pragma unroll
@@ -748,19 +748,27 @@ __device__ __forceinline__ void rc_exchange(const float (&acc)[2][PIECE], float*
         if (threadIdx.x == 0) {
             unsigned* arrived = reinterpret_cast<unsigned*>(row) + rc_ctr_off(C);
             __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
+            unsigned spins = 0, gave_up = 0;
             while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nchunks) {
                 __builtin_amdgcn_s_sleep(32);
                 if (++spins > RC_SPIN_LIMIT) {
                     __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gave_up = 1;
                     break;
                 }
             }
+            *s_flag = gave_up;        // (the ticket in this word was read by every thread before the first barrier above)
         }
+    } else if (threadIdx.x == 0) {
+        *s_flag = 0;
     }
     __syncthreads();
+    // A wait that gave up must not pass incomplete sums on as if they were totals (the flag word lives in the
+    // per-pass arena and nobody on the training path reads it): the workgroup POISONS its totals, so the statistics, the
+    // activations / gradients and with them the step's loss turn NaN -- loud, and sticky through the optimiser step.
+    const bool gave_up = *s_flag != 0;
     if (!RC_DBG(dbg, 4))
-        for (int i = threadIdx.x; i < 2 * C; i += NT) lds[i] = rc_read(row + i);
+        for (int i = threadIdx.x; i < 2 * C; i += NT) lds[i] = gave_up ? __builtin_nanf("") : rc_read(row + i);
     __syncthreads();
 }
 
@@ -823,7 +831,7 @@ __global__ __launch_bounds__(NT, 4) void fwd_resident_kernel(const T* __restrict
     }
     reduce_rows<2, PIECE>(acc, lds, piece, prow, rows, tpp, active);
     rc_exchange<PIECE>(acc, lds, ws + RC_HDR + (size_t)n * rc_block_words(C), ctr + 1, C, piece, active && prow == 0,
-                       nchunks, dbg);
+                       nchunks, dbg, &s_slot);
     if (!active) return;
     // only the PACKED pieces stay live across the wait (the compiler would otherwise keep their unpacked floats too)
 #pragma unroll
@@ -919,7 +927,7 @@ __global__ __launch_bounds__(NT, 2) void bwd_resident_kernel(T* __restrict__ g, 
     }
     reduce_rows<2, PIECE>(acc, lds, piece, prow, rows, tpp, active);
     rc_exchange<PIECE>(acc, lds, ws + RC_HDR + (size_t)n * rc_block_words(C), ctr + 1, C, piece, active && prow == 0,
-                       nchunks, dbg);
+                       nchunks, dbg, &s_slot);
     if (!active) return;
 #pragma unroll
     for (int j = 0; j < NP; ++j) asm volatile("" : "+v"(zr[j]), "+v"(gr_[j]));

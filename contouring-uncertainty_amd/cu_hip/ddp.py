@@ -74,6 +74,15 @@ class BucketedAllReduce:
         if self._frontier - tail >= self.bucket:
             self._launch(tail, self._frontier)
 
+    def drain(self):
+        """Wait for the collectives launched so far and forget the step (an aborted backward: nothing new is launched)."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self.native is not None:
+            self.native.wait()
+        self.flat = None
+
     def finish(self):
         """Flush what is left (in at most two collectives) and make the current stream wait for all of them."""
         tail = self._contiguous_tail()
@@ -134,6 +143,7 @@ class GradSync:
             from .comm import NativeComm
             self.native = NativeComm.create(group=group)
         self.bar = BucketedAllReduce(sum(sizes), bucket_elems, group, self.native)
+        self.dry = False                  # True: hooks run, no collective is launched (bench.py's exposed-communication probe)
         self.overlap = True               # False: never reduce during a backward (gradient accumulation)
         self.overlapped = False           # mode of the backward in flight
         self.deferred_steps = 0           # statistics (tests): backwards that could not overlap
@@ -152,6 +162,8 @@ class GradSync:
             dist.broadcast(sflat, 0, group=self.group)
 
     def _begin(self, flat: torch.Tensor):
+        if self.dry:
+            return
         if self.overlapped:
             raise RuntimeError("GradSync: a second backward started before finish() consumed the first one; set "
                                "overlap = False when accumulating gradients over micro-batches")
@@ -166,6 +178,15 @@ class GradSync:
             return
         lo, hi = self.ranges[prefix]
         self.bar.ready(lo, hi)
+
+    def abort(self):
+        """The backward in flight died (``UNetEngine.backward`` calls this before re-raising): wait for the collectives
+        already launched on the dead step's buffer and leave overlapped mode, so the next backward can begin."""
+        if self.overlapped:
+            try:
+                self.bar.drain()
+            finally:
+                self.overlapped = False
 
     def _allreduce_now(self, buf: torch.Tensor):
         if self.native is not None:
@@ -208,7 +229,7 @@ class GradSync:
 
     def finish(self):
         """Call after ``loss.backward()`` (of the LAST micro-batch when accumulating) and before the optimizer step."""
-        if self.world == 1:
+        if self.world == 1 or self.dry:
             return
         if self.skew is not None:
             splist = [p for _, p in self.skew.named_parameters()]

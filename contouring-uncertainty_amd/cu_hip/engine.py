@@ -143,7 +143,8 @@ class UNetEngine:
         self.drop_mask_fn: Optional[Callable[[str, int, int, torch.device], Tensor]] = None   # tests inject masks
         self.debug: Optional[Dict[str, Tensor]] = None    # tests/tools: set to {} to capture per-layer gradients (NHWC)
         self._prep_state = None     # (pointer key, item table, blocks, names) of the batched operand preparation
-        self._dwk_ws: Optional[Tensor] = None
+        self._dwk_ws: Optional[Tensor] = None       # partial-tile scratch of the weight gradients
+        self._dw9_ws: Optional[Tensor] = None       # first layer's 9 x CO accumulator (zero between uses)
         # InstanceNorm workspaces (atomics targets) of all layers of one pass: slices of ONE arena per direction that
         # is zeroed by one fill at the start of the pass (instead of one memset launch per layer)
         self._arena = {"fwd": _WsArena(), "bwd": _WsArena()}
@@ -329,24 +330,19 @@ class UNetEngine:
             self.grad_ready_hook(prefix)
 
     def _dwk(self, shape, device) -> Tensor:
-        """Weight-gradient accumulator (kernel layout, f32, atomics target) of one layer: a view of ONE persistent
-        workspace that is zeroed once and handed back clean by every un-preparation (read-and-clear), so a step launches
-        no per-layer memset and every layer's atomics land in the same cache-resident block."""
+        """The first layer's 9 x CO weight-gradient accumulator (f32 atomics target): a persistent buffer that is zeroed
+        once and handed back clean by its un-preparation (read-and-clear).  ``backward`` drops it when a step aborts, so a
+        half-accumulated buffer can never leak into the next step."""
         n = 1
         for d in shape:
             n *= d
-        ws = self._dwk_ws
+        ws = self._dw9_ws
         if ws is None or ws.numel() < n or ws.device != device:
-            ws = self._dwk_ws = torch.zeros(max(n, 9 * 480 * 960), dtype=torch.float32, device=device)
+            ws = self._dw9_ws = torch.zeros(max(n, 9 * 64), dtype=torch.float32, device=device)
         return ws[:n].view(shape)
 
     def _norm_mode(self) -> int:
         return ops.NORM_WS_CLEAN | (ops.NORM_DETERMINISTIC if self.deterministic else 0)
-
-    def _splits(self) -> int:
-        """pixel splits of a weight-gradient launch: 0 = the library's choice, 1 = one workgroup per dWk block (each
-        element of the zeroed accumulator then receives exactly one add: deterministic)."""
-        return 1 if self.deterministic else 0
 
     def _wgrad_stream(self, *reads: Tensor):
         """``with`` block whose launches go to the weight-gradient stream, ordered after everything enqueued so far.  The
@@ -364,6 +360,26 @@ class UNetEngine:
         if self._side is not None and self._side_keep:
             torch.cuda.current_stream(device).wait_stream(self._side)
         self._side_keep.clear()
+
+    PARTS_FLOATS = 24 << 20       # 96 MiB: 256 slabs of a 64 x 64 x 9 block are 9.4 M floats; the library caps the splits
+
+    def _parts_ws(self, device) -> Tensor:
+        """Scratch of the weight gradients' partial tiles (cu_conv_wgrad_parts): every pixel split of a launch stores its
+        tile into a slab of its own and cu_grad_unprep_parts adds the slabs in a fixed order -- no f32 atomics (they ran
+        at the chip-wide ~1.3 TB/s atomic rate: 29 us per launch whatever the layer), no zeroing, no read-and-clear
+        invariant, and bit-identical weight gradients run to run.  One buffer per engine: its users are stream-ordered
+        (wgrad -> un-preparation pairs, all on the weight-gradient stream)."""
+        ws = self._dwk_ws
+        if ws is None or ws.device != device or ws.numel() < self.PARTS_FLOATS:
+            ws = self._dwk_ws = torch.empty(self.PARTS_FLOATS, dtype=torch.float32, device=device)
+        return ws
+
+    def _wgrad(self, srcs, z: Tensor, shape, grad: Tensor, kind: str, prefix: str, **kw):
+        """weight gradient of one layer -> ``grad`` (+=): partial tiles + ordered sum."""
+        ws = self._parts_ws(z.device)
+        nparts = ops.conv_wgrad(srcs, z, ws, parts=True, **kw)
+        ops.grad_unprep_parts(ws, nparts, shape[1], grad, kind, accumulate=True)
+        self._ready(prefix)
 
     def _unprep(self, dwk: Tensor, grad: Tensor, kind: str, prefix: str):
         """kernel-layout dWk -> logical gradient, layer by layer (measured in round 1: one batched launch at the end of the
@@ -398,7 +414,7 @@ class UNetEngine:
         n, oh, ow, co = g.shape
         if rec.first:
             with self._wgrad_stream(g, ctx.img):
-                dw9 = self._dwk((9, co), g.device)
+                dw9 = self._dwk((9, co), g.device)      # 9 x CO floats: the first layer keeps its small atomics target
                 det_ws = None
                 if self.deterministic:
                     if self._det_ws is None or self._det_ws.device != g.device:
@@ -409,10 +425,8 @@ class UNetEngine:
             return
         ci = w.shape[1]
         with self._wgrad_stream(g, *[s_.z for s_ in rec.srcs]):
-            dwk = self._dwk((9, co, ci), g.device)
-            ops.conv_wgrad(rec.srcs, g, dwk, grid=(oh, ow), in_stride=rec.stride, z_stride=1, taps=TAPS3_W, n_cols=co,
-                           splits=self._splits())
-            self._unprep(dwk, G[f"{prefix}.conv.weight"], "conv", prefix)
+            self._wgrad(rec.srcs, g, (9, co, ci), G[f"{prefix}.conv.weight"], "conv", prefix, grid=(oh, ow),
+                        in_stride=rec.stride, z_stride=1, taps=TAPS3_W, n_cols=co)
         if dsrc is None:
             return
         _, wd = self._operands(f"{prefix}.conv.weight", w, "conv")
@@ -454,11 +468,9 @@ class UNetEngine:
         ci, co = w.shape[0], w.shape[1]
         n, h, w_, _ = rec.src.z.shape
         with self._wgrad_stream(du, rec.src.z):
-            dwk = self._dwk((4, co, ci), du.device)
             taps = [(0, 0, dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)]
-            ops.conv_wgrad([rec.src], du, dwk, grid=(h, w_), in_stride=1, z_stride=2, taps=taps, n_cols=co,
-                           splits=self._splits())
-            self._unprep(dwk, G[f"{rec.prefix}.weight"], "convT", rec.prefix)
+            self._wgrad([rec.src], du, (4, co, ci), G[f"{rec.prefix}.weight"], "convT", rec.prefix, grid=(h, w_),
+                        in_stride=1, z_stride=2, taps=taps, n_cols=co)
         _, wd = self._operands(f"{rec.prefix}.weight", w, "convT")
         ops.conv_gemm([Act(du, None, 1.0)], wd, None, grid=(h, w_), in_stride=2,
                       taps=[(dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)], dsts=[d_in], dst_cols=[ci],
@@ -470,6 +482,25 @@ class UNetEngine:
         """Accumulates parameter gradients into G (float32, reference layouts; every touched tensor is ``+=``).
         dL/dlogits arrives as ``dlogits`` (N, K, H, W) float32 and / or as ``dl_nhwc`` (N, H, W, 32) in the engine's
         element type (``cu_dsnt_head_bwd_nhwc``); both given = their sum."""
+        try:
+            self._backward(P, G, ctx, dlogits, dfeats, dl_nhwc)
+        except BaseException:
+            # an aborted step (launch error, OOM, KeyboardInterrupt, an exception from the DDP ready hook) must not leave
+            # state behind that a later step would silently consume: join the weight-gradient stream, drop the epilogue
+            # sums and the (possibly half-accumulated) first-layer accumulator
+            try:
+                if self._side is not None:
+                    torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+            finally:
+                self._side_keep.clear()
+                self._given_sums.clear()
+                self._dw9_ws = None
+                hook = getattr(self.grad_ready_hook, "__self__", None)
+                if hook is not None and hasattr(hook, "abort"):
+                    hook.abort()
+            raise
+
+    def _backward(self, P, G, ctx: UNetCtx, dlogits, dfeats, dl_nhwc):
         dt = self.dtype
         last = ctx.last
         n, h, w_, c_last = last.z.shape
@@ -483,14 +514,12 @@ class UNetEngine:
             dl = ops.nchw_f32_to_nhwc(dlogits.contiguous(), dt, cp=32)
         w = P["output_block.conv.weight"]
         with self._wgrad_stream(dl, last.z):
-            dwk = self._dwk((1, 32, c_last), dl.device)
-            ops.conv_wgrad([last], dl, dwk, grid=(h, w_), in_stride=1, z_stride=1, taps=[(0, 0, 0, 0, 0)], n_cols=32,
-                           splits=self._splits())
-            self._unprep(dwk, G["output_block.conv.weight"], "conv", "output_block")
+            self._wgrad([last], dl, (1, 32, c_last), G["output_block.conv.weight"], "conv", "output_block", grid=(h, w_),
+                        in_stride=1, z_stride=1, taps=[(0, 0, 0, 0, 0)], n_cols=32, alg_cols=self.num_classes)
         _, wd = self._operands("output_block.conv.weight", w, "conv", cop=32)
         g = torch.empty_like(last.z)
         ops.conv_gemm([Act(dl, None, 1.0)], wd, None, grid=(h, w_), in_stride=1, taps=[(0, 0, 0)], dsts=[g],
-                      dst_cols=[c_last])
+                      dst_cols=[c_last], alg_cin=self.num_classes)
         del dl
         # ---- decoder
         d_enc: List[Optional[Tensor]] = [None] * len(ctx.enc)
@@ -540,6 +569,7 @@ class ConfidenceEngine:
     def __init__(self, dtype: torch.dtype = torch.bfloat16):
         self.dtype = dtype
         self._opcache: Dict[str, Tuple] = {}
+        self._parts: Optional[Tensor] = None        # partial-tile scratch of the three weight gradients
         self.deterministic = os.environ.get("CONTOUR_DETERMINISTIC", "0") == "1"      # as UNetEngine.deterministic
 
     def _operands(self, name, w):
@@ -577,10 +607,11 @@ class ConfidenceEngine:
             w = P[f"model.{i}.weight"]
             co, ci = w.shape[0], w.shape[1]
             ops.act_bwd(g, out.z, 0.0, G[f"model.{i}.bias"], deterministic=self.deterministic)
-            dwk = torch.zeros((9, co, ci), dtype=torch.float32, device=g.device)
-            ops.conv_wgrad([src], g, dwk, grid=(h, w_), in_stride=1, z_stride=1, taps=TAPS3_W, n_cols=co,
-                           splits=1 if self.deterministic else 0)
-            ops.grad_unprep(dwk, G[f"model.{i}.weight"], "conv", accumulate=True)
+            if self._parts is None or self._parts.device != g.device:
+                self._parts = torch.empty(4 << 20, dtype=torch.float32, device=g.device)
+            nparts = ops.conv_wgrad([src], g, self._parts, grid=(h, w_), in_stride=1, z_stride=1, taps=TAPS3_W, n_cols=co,
+                                    parts=True)
+            ops.grad_unprep_parts(self._parts, nparts, co, G[f"model.{i}.weight"], "conv", accumulate=True)
             if li == 0 and not need_input_grad:
                 return None
             _, wd = self._operands(f"model.{i}.weight", w)

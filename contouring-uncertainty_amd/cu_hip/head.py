@@ -23,12 +23,22 @@ class GradSlot:
     returns (``logits._cu_grad_slot``); the head's backward then writes the gradient ONCE, as NHWC in the engine's
     element type (``cu_dsnt_head_bwd_nhwc``), puts it here and returns a stride-0 zero tensor to autograd; the UNet's
     backward takes it (and adds whatever else autograd accumulated into its incoming gradient).  Logits that did not
-    come straight from such a UNet carry no slot and get the ordinary NCHW float32 gradient."""
-    __slots__ = ("dtype", "dl")
+    come straight from such a UNet carry no slot and get the ordinary NCHW float32 gradient.
+
+    Several heads on the same logits (two loss terms, a retained graph walked twice) ADD into the slot (an
+    overwrite lost every gradient but the last).  What the hand-over cannot serve is a reader of the logits' own
+    gradient -- ``torch.autograd.grad(loss, logits)``, ``logits.retain_grad()``, a tensor hook on the logits: those see the
+    zero stand-in.  ``dsnt_nll(..., dense_grad=True)`` (or ``slot.enabled = False``) selects the dense NCHW float32
+    gradient for such uses."""
+    __slots__ = ("dtype", "dl", "enabled")
 
     def __init__(self, dtype):
         self.dtype = dtype
         self.dl: Optional[Tensor] = None
+        self.enabled = True
+
+    def put(self, dl: Tensor):
+        self.dl = dl if self.dl is None else self.dl + dl
 
     def take(self) -> Optional[Tensor]:
         dl, self.dl = self.dl, None
@@ -39,7 +49,7 @@ class _DsntNllFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits: Tensor, y: Tensor, alpha: Optional[Tensor], covar: bool, w_mse: float, w_log: float,
                 slot: Optional[GradSlot] = None):
-        ctx.slot = slot if logits.is_contiguous() else None
+        ctx.slot = slot if (slot is not None and slot.enabled and logits.is_contiguous()) else None
         logits = logits.contiguous()
         need_grad = logits.requires_grad or (alpha is not None and alpha.requires_grad)
         with ops.L.device_guard(logits):
@@ -59,8 +69,8 @@ class _DsntNllFn(torch.autograd.Function):
         scale = gloss.reshape(1)
         with ops.L.device_guard(logits):
             if ctx.slot is not None:
-                ctx.slot.dl = ops.dsnt_head_bwd_nhwc(logits, aux, (gmu * scale).contiguous(), (gsigma * scale).contiguous(),
-                                                     ctx.covar, ctx.slot.dtype)
+                ctx.slot.put(ops.dsnt_head_bwd_nhwc(logits, aux, (gmu * scale).contiguous(), (gsigma * scale).contiguous(),
+                                                    ctx.covar, ctx.slot.dtype))
                 dl = torch.zeros((), dtype=logits.dtype, device=logits.device).expand(logits.shape)
             else:
                 dl = ops.dsnt_head_bwd(logits, aux, (gmu * scale).contiguous(), (gsigma * scale).contiguous(), ctx.covar)
@@ -69,11 +79,13 @@ class _DsntNllFn(torch.autograd.Function):
 
 
 def dsnt_nll(logits: Tensor, y: Tensor, alpha: Optional[Tensor] = None, covar: bool = True, mse_weight: float = 1.0,
-             log_penalty_weight: float = 1.0):
+             log_penalty_weight: float = 1.0, dense_grad: bool = False):
     """logits (N,K,H,W) f32, y (N,K,2) pixel (x,y), alpha (N,K,2) or None ->
-    (logs dict of 0-dim tensors with a differentiable ``loss``, mu (N,K,2), Sigma (N,K,2,2))."""
+    (logs dict of 0-dim tensors with a differentiable ``loss``, mu (N,K,2), Sigma (N,K,2,2)).
+    ``dense_grad``: give autograd the real NCHW float32 dL/dlogits instead of the :class:`GradSlot` hand-over."""
+    slot = None if dense_grad else getattr(logits, "_cu_grad_slot", None)
     loss, logs, mu, sigma3 = _DsntNllFn.apply(logits, y, alpha, bool(covar), float(mse_weight),
-                                              float(log_penalty_weight), getattr(logits, "_cu_grad_slot", None))
+                                              float(log_penalty_weight), slot)
     out: Dict[str, Tensor] = {"loss": loss, "distance_loss": logs[1], "loss_term1": logs[2], "loss_term2": logs[3]}
     if alpha is not None:
         out["loss_term3"] = logs[4]

@@ -135,6 +135,17 @@ int cu_conv_wgrad(const cu_wgrad_desc* d,
                   const void* src1, const float* scale1, const float* shift1,
                   const void* z, float* dw /* [wtaps][CO][C0+C1] f32 */, void* stream);
 
+/* The same without atomics ("partial tiles"): every adder of a dW block -- one per pixel split, times the k-parts of the
+ * register-staged kernel -- STORES its partial [wtaps][CO][C0+C1] tile into a slab of its own, parts[s], s < *nparts
+ * (host int, written before the call returns); d->splits is capped so that the slabs fit parts_floats.  Contents of
+ * `parts` are irrelevant on entry; cu_grad_unprep_parts sums the slabs in slab order, so the gradient is bit-identical run
+ * to run at ANY split count (round 3: the production form; the atomics form runs at the chip's ~1.3 TB/s float-atomic
+ * rate, 37.7 MB per launch = 29 us whatever the layer). */
+int cu_conv_wgrad_parts(const cu_wgrad_desc* d,
+                        const void* src0, const float* scale0, const float* shift0,
+                        const void* src1, const float* scale1, const float* shift1,
+                        const void* z, float* parts, size_t parts_floats, int* nparts, void* stream);
+
 /* First layer, Cin = 1 (input_block.conv1.conv, unet2.py:113-119): direct 3x3 conv of the f32 image. */
 int cu_conv_c1_fwd(int dtype, int N, int H, int W, int CO, const float* img /* [N][H][W] */,
                    const float* w /* [9][CO] f32 */, const float* bias, void* dst /* NHWC */, void* stream);
@@ -173,7 +184,9 @@ int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, const void* 
  * ws: f32 workspace of cu_instnorm_resident_ws_floats(N, C) elements, zero-filled by the call as needed -- unless
  * CU_NORM_WS_CLEAN is or-ed into mode: the caller then hands over a workspace that is already zero (one memset for
  * all layers of a step instead of one launch per layer); the call leaves it dirty.  After the
- * stream has drained, ((unsigned*)ws)[1] != 0 after a mode-1 call reports that its bounded arrival wait gave up. */
+ * stream has drained, ((unsigned*)ws)[1] != 0 after a mode-1 call reports that its bounded arrival wait gave up; a
+ * workgroup whose wait gave up also POISONS its totals with NaN (statistics, outputs and the step's loss turn NaN): the
+ * training path does not have to poll the flag to notice. */
 #define CU_NORM_WS_CLEAN 16
 /* + CU_NORM_DETERMINISTIC: two-pass kernels with one workgroup per image (fixed summation order, every sum has a single
  * adder) and, in the backward, dgamma / dbeta summed over the images by a finish pass: bit-identical results run to run. */
@@ -257,6 +270,12 @@ int cu_weight_prep(int dtype, int T, int CO, int CI, int COP, long s_co, long s_
  * clean for the next layer: one persistent workspace, no per-layer memset). */
 int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_ci, float* dwk, float* grad, int accumulate,
                    void* stream);
+
+/* Sum of the nparts slabs cu_conv_wgrad_parts wrote (parts [nparts][T][COP][CI] f32; more than 16 slabs are first summed
+ * in groups, IN PLACE: `parts` is scratch) -> logical-layout gradient; accumulate bit 0 as above.  Taps innermost in the
+ * logical layout (Conv2d / ConvTranspose2d weights), T = 9, 4 or 1. */
+int cu_grad_unprep_parts(int T, int CO, int CI, int COP, long s_co, long s_ci, float* parts, int nparts, float* grad,
+                         int accumulate, void* stream);
 
 /* Batched form: one launch for every conv layer of the network.  `items` is a DEVICE array (blk0 ascending, blk0 of
  * item i = number of 256-thread blocks of items 0..i-1; an item has tiles_co * tiles_ci blocks of 32 x 32 x T weights,

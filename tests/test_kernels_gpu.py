@@ -144,6 +144,20 @@ def test_conv_dgrad_wgrad(dtype, case):
     gw = torch.zeros_like(w)
     ops.grad_unprep(dwk, gw, "conv", accumulate=True)
     assert rel_err(gw, wq.grad) < (2e-4 if dtype == torch.float32 else 1e-2)
+    # ---- the same through partial tiles (cu_conv_wgrad_parts + cu_grad_unprep_parts): poisoned scratch, no atomics,
+    #      bit-identical run to run; once with the plain (materialised) operand the engine feeds (LDS-DMA kernel)
+    for srcs in ([a0, a1], [ops.Act(nhwc(r0, dtype), None, 1.0), ops.Act(nhwc(r1, dtype), None, 1.0)]):
+        outs = []
+        for _ in range(2):
+            ws = torch.full((6 << 20,), float("nan"), device=DEV)
+            nparts = ops.conv_wgrad(srcs, gz.z, ws, grid=(os_, os_), in_stride=stride, z_stride=1, taps=TAPS3_W, n_cols=co,
+                                    parts=True)
+            assert nparts >= 1
+            gp = torch.zeros_like(w)
+            ops.grad_unprep_parts(ws, nparts, co, gp, "conv", accumulate=True)
+            outs.append(gp)
+        assert rel_err(outs[0], wq.grad) < (2e-4 if dtype == torch.float32 else 1e-2)
+        assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -179,6 +193,12 @@ def test_conv_transpose(dtype, case):
     gw = torch.zeros_like(w)
     ops.grad_unprep(dwk, gw, "convT", accumulate=True)
     assert rel_err(gw, wq.grad) < (2e-4 if dtype == torch.float32 else 1e-2)
+    ws = torch.full((4 << 20,), float("nan"), device=DEV)           # partial-tile form
+    nparts = ops.conv_wgrad([a_plain], dun, ws, grid=(size, size), in_stride=1, z_stride=2,
+                            taps=[(0, 0, dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)], n_cols=co, parts=True)
+    gp = torch.zeros_like(w)
+    ops.grad_unprep_parts(ws, nparts, co, gp, "convT", accumulate=True)
+    assert rel_err(gp, wq.grad) < (2e-4 if dtype == torch.float32 else 1e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

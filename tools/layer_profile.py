@@ -42,7 +42,7 @@ ops.PROFILE_ON[0] = False
 n = len(ops.PROFILE) // REP
 rows = []
 for k in range(n):
-    fam, flops, _, _, note, nbytes = ops.PROFILE[k]
+    fam, flops, _, _, note, nbytes, *_ = ops.PROFILE[k]
     ms = sum(ops.PROFILE[k + r * n][2].elapsed_time(ops.PROFILE[k + r * n][3]) for r in range(REP)) / REP
     rows.append((k, fam, note, ms, flops, nbytes))
 tot = sum(r[3] for r in rows)

@@ -25,6 +25,12 @@ struct WgKArgs {
     int twl, thl, iml, tiles_x, tiles_y, igroups, ntiles, splits;
     int ctiles;                                // number of channel tiles (grid.x = ntile_n * ctiles)
     int tile_px;                               // loop pixels per tile (128, or 64 for stride-2 gathers)
+    int wtaps;                                 // weight taps (max tap_w + 1): slab layout of the partial-tile mode
+    // LDS-DMA kernel, stride-2 3x3 gathers (s_deint): the source tile is staged as its four PARITY planes
+    // S_ab[y][x] = S[2y + a][2x + b], each (th + 1) x (tw + 1) pixels from (py0 - 1, px0 - 1), so that tap (dy, dx) is a
+    // plain row offset into plane (dy & 1, dx & 1) and the k-loop walks dense rows (ISL = 1) exactly like a stride-1 layer
+    int s_deint, ISL, s_hpi, s_plane;
+    unsigned mg_spl;
     unsigned mg_shpi, mg_shw, mg_zhpi, mg_zhw; // ceil(2^32/d) magics for the halo index decode
     float slope0, slope1;
     int zsame;                                 // all taps read the same Z pixel
@@ -34,12 +40,28 @@ struct WgKArgs {
     int pc_early;                              // ... and rounds the computing waves issue before their k-loop
     int dbg;                                   // CU_CONV_DBG bits (timing experiments): 1 no atomics, 2 no MFMA, 4 no commit, 8 no loads
     // partial-tile mode (cu_conv_wgrad_parts): part_stride != 0 -> every adder of a dW block STORES its partial tile into
-    // its own slab dw + part * part_stride (plain stores, no atomics); the slabs are summed in a fixed order by
-    // cu_grad_unprep_parts.  max_parts / nparts are host-side only (slab capacity in, slabs written out).
+    // its own slab dw + part * part_stride (no atomics); the slabs are summed in a fixed order by cu_grad_unprep_parts.
+    // Slab layout = the accumulators as they stand ("native"): [block = nt * ctiles + ct][wave block][weight tap][q]
+    // [lane][4] floats, register 4q + e of a lane at [q][lane][e] -- every store instruction writes 1 KiB contiguous.
+    // parts_floats / nparts_out / layout_out are host-side only.
     size_t part_stride;
-    int max_parts, nparts;
+    size_t parts_floats;
     int* nparts_out;
+    int* layout_out;
 };
+
+// partial-tile mode: one wave's accumulators -> its region of the slab (16-byte stores, 1 KiB per instruction)
+template <int NTAPS>
+__device__ __forceinline__ void store_native(float* slab, int block, int nwb, int blk, int wtaps, const int* tap_w,
+                                             const f32x16 (&acc)[NTAPS], int lane) {
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+        float* o = slab + ((size_t)((block * nwb + blk) * wtaps + tap_w[t]) * 4) * 256 + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(o + q * 256) = f32x4{acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+    }
+}
 
 template <typename T> struct WCfg;
 template <> struct WCfg<bf16_t> { static constexpr int PIECE = 8; static constexpr int KPIX = 16; };
@@ -305,22 +327,21 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
     const int c = c_base + cblk * 32 + r;
     auto flush = [&]() {
         if (!wave_active || c >= CI) return;
-        // partial-tile mode: slab of (pixel split, k-part) -- each (tap, n, c) of a slab has exactly one writer
-        float* dwp = p.dw + (size_t)(blockIdx.y * KSPLIT + kpart) * p.part_stride;
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int n = n_base + nblk * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                if (n < p.CO) {
-                    float* o = dwp + ((size_t)p.tap_w[t] * p.CO + n) * CI + c;
-                    if (p.part_stride) *o = acc[t][i];
-                    else unsafeAtomicAdd(o, acc[t][i]);
-                }
+                if (n < p.CO) unsafeAtomicAdd(p.dw + ((size_t)p.tap_w[t] * p.CO + n) * CI + c, acc[t][i]);
             }
         }
     };
-    if (p.part_stride) { flush(); return; }
+    if (p.part_stride) {      // partial-tile mode: the slab of (pixel split, k-part)
+        if (wave_active)
+            store_native<NTAPS>(p.dw + (size_t)(blockIdx.y * KSPLIT + kpart) * p.part_stride, blockIdx.x, NWB, blk, p.wtaps,
+                                p.tap_w, acc, lane);
+        return;
+    }
     if constexpr (KSPLIT > 1) {
         // one pixel split (cu_wgrad_desc.splits == 1, the deterministic mode): this workgroup is the only adder of its dW
         // block, and its KSPLIT k-parts add one after the other -- a fixed summation order
@@ -387,7 +408,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     }
     const int ct = bxi % p.ctiles, nt = bxi / p.ctiles;
     const int c_base = ct * TC, n_base = nt * TN;
-    const int s_hpi = p.SHH * p.SHW, z_hpi = p.ZHH * p.ZHW;
+    const int s_hpi = p.s_hpi, z_hpi = p.ZHH * p.ZHW;
     const bool wave_active = !producer && (n_base + nblk * 32 < p.CO) && (c_base + cblk * 32 < CI);
     const int s_img_bytes = p.s_iters * BLK_B;
 
@@ -427,10 +448,21 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
             const int pl = (CBLK == 2 && i >= p.s_halo) ? 1 : 0;
             const int hp = i - pl * p.s_halo;
             const int im = __umulhi((unsigned)hp, p.mg_shpi), rem = hp - im * s_hpi;
-            const int hy = __umulhi((unsigned)rem, p.mg_shw), hx = rem - hy * p.SHW;
+            int hy, hx, sy, sx;
+            bool used = true;
+            if (p.s_deint) {          // parity plane a*2+b, then (hy, hx) inside it; row / column 0 of an even plane is no tap's
+                const int par = __umulhi((unsigned)rem, p.mg_spl), r2 = rem - par * p.s_plane;
+                hy = __umulhi((unsigned)r2, p.mg_shw); hx = r2 - hy * p.SHW;
+                const int pa = par >> 1, pb = par & 1;
+                sy = g_sy0 + 2 * hy + pa; sx = g_sx0 + 2 * hx + pb;
+                used = hy + pa > 0 && hx + pb > 0;
+            } else {
+                hy = __umulhi((unsigned)rem, p.mg_shw); hx = rem - hy * p.SHW;
+                sy = g_sy0 + hy; sx = g_sx0 + hx;
+            }
             const int c = c_base + pl * 32 + slot * 8;
-            const int n = g_img0 + im, sy = g_sy0 + hy, sx = g_sx0 + hx;
-            const bool ok = hp < p.s_halo && c < CI && n < p.N && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;
+            const int n = g_img0 + im;
+            const bool ok = used && hp < p.s_halo && c < CI && n < p.N && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;
             const bool s1 = c >= p.C0;
             const unsigned pix = (unsigned)((n * p.SH + sy) * p.SW + sx);
             const unsigned off = ok ? (pix * (unsigned)(s1 ? p.C1 : p.C0) + (unsigned)(s1 ? c - p.C0 : c)) * 2u : OOB;
@@ -465,7 +497,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     int s_lane[2], z_lane[2];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        s_lane[half] = (8 * hh + 4 * half + q) * p.IS * ROW_B + s_col;
+        s_lane[half] = (8 * hh + 4 * half + q) * p.ISL * ROW_B + s_col;
         z_lane[half] = (8 * hh + 4 * half + q) * p.ZS * ROW_B + z_colb;
     }
     const int NK = p.tile_px / 16;
@@ -514,7 +546,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
             if constexpr (ROWK) {   // tile rows of >= 16 pixels: a k-step lies in one row -> scalar row base + per-lane offset
                 const int m0 = ks * 16;
                 const int tx0 = m0 & (TW - 1), ty = (m0 >> p.twl) & (TH - 1), im = m0 >> (p.twl + p.thl);
-                const int srow = (im * s_hpi + ty * p.IS * p.SHW + tx0 * p.IS) * ROW_B;
+                const int srow = (im * s_hpi + ty * p.ISL * p.SHW + tx0 * p.ISL) * ROW_B;
                 const int zrow = (im * z_hpi + ty * p.ZS * p.ZHW + tx0 * p.ZS) * ROW_B;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
@@ -526,7 +558,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
             for (int half = 0; half < 2; ++half) {
                 const int m = ks * 16 + 8 * hh + 4 * half + q;
                 const int tx = m & (TW - 1), ty = (m >> p.twl) & (TH - 1), im = m >> (p.twl + p.thl);
-                sbase[half] = (im * s_hpi + ty * p.IS * p.SHW + tx * p.IS) * ROW_B + s_col;
+                sbase[half] = (im * s_hpi + ty * p.ISL * p.SHW + tx * p.ISL) * ROW_B + s_col;
                 zbase[half] = (im * z_hpi + ty * p.ZS * p.ZHW + tx * p.ZS) * ROW_B + z_colb;
             }
             }
@@ -626,22 +658,37 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
         }
     }
     if (!wave_active || kpart != 0 || CU_DBG(p, 1)) return;
+    if (p.part_stride) {      // partial-tile mode: the slab of this pixel split
+        store_native<NTAPS>(p.dw + (size_t)byi * p.part_stride, bxi, NWB, blk, p.wtaps, p.tap_w, acc, lane);
+        return;
+    }
     const int r = lane & 31, h2 = lane >> 5;
     const int c = c_base + cblk * 32 + r;
     if (c >= CI) return;
-    float* dwp = p.dw + (size_t)byi * p.part_stride;      // partial-tile mode: the slab of this pixel split
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int n = n_base + nblk * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
-            if (n < p.CO) {
-                float* o = dwp + ((size_t)p.tap_w[t] * p.CO + n) * CI + c;
-                if (p.part_stride) *o = acc[t][i];
-                else unsafeAtomicAdd(o, acc[t][i]);
-            }
+            if (n < p.CO) unsafeAtomicAdd(p.dw + ((size_t)p.tap_w[t] * p.CO + n) * CI + c, acc[t][i]);
         }
     }
+}
+
+// partial-tile mode: slab size of this block shape, split cap from the workspace size, results for the caller.
+// The workspace must also hold the plain [wtaps][CO][CI] sum cu_grad_unprep_parts forms behind the slabs.
+static int parts_setup(WgKArgs& a, int nblk, int cblk, int ntn, int kparts) {
+    a.part_stride = (size_t)ntn * a.ctiles * nblk * cblk * a.wtaps * 1024;
+    const size_t plain = (size_t)a.wtaps * a.CO * (a.C0 + a.C1);
+    CU_CHECK_ARG(a.parts_floats >= plain + (size_t)kparts * a.part_stride,
+                 "cu_conv_wgrad_parts: workspace of %zu floats; this shape needs >= %zu", a.parts_floats,
+                 plain + (size_t)kparts * a.part_stride);
+    size_t cap = (a.parts_floats - plain) / a.part_stride / kparts;
+    if (cap > 1024) cap = 1024;
+    if ((size_t)a.splits > cap) a.splits = (int)cap;
+    *a.nparts_out = a.splits * kparts;
+    *a.layout_out = (nblk << 8) | cblk;
+    return 0;
 }
 
 template <int NBLK, int CBLK, int NTAPS, int NW, bool PC = false, bool ROWK = false>
@@ -657,10 +704,9 @@ int launch_dma(WgKArgs& a, hipStream_t st) {
         a.splits = want < 1 ? 1 : want;
     }
     if (a.splits > a.ntiles) a.splits = a.ntiles;
-    if (a.part_stride) {
-        if (a.splits > a.max_parts) a.splits = a.max_parts;
-        a.nparts = a.splits;
-        *a.nparts_out = a.nparts;
+    if (a.nparts_out) {
+        const int rc = parts_setup(a, NBLK, CBLK, ntn, 1);
+        if (rc) return rc;
     }
     hipLaunchKernelGGL(k, dim3(a.ctiles * ntn, a.splits), dim3(64 * NW), 0, st, a);
     CU_LAUNCH_CHECK();
@@ -689,12 +735,9 @@ int launch_k(WgKArgs& a, hipStream_t st) {
         a.splits = want < 1 ? 1 : want;
     }
     if (a.splits > a.ntiles) a.splits = a.ntiles;
-    if (a.part_stride) {
-        constexpr int KS = 4 / (NBLK * CBLK);          // k-parts of a block: one slab each
-        if (a.splits * KS > a.max_parts) a.splits = a.max_parts / KS;
-        CU_CHECK_ARG(a.splits >= 1, "cu_conv_wgrad_parts: workspace holds %d slabs, this shape needs >= %d", a.max_parts, KS);
-        a.nparts = a.splits * KS;
-        *a.nparts_out = a.nparts;
+    if (a.nparts_out) {
+        const int rc = parts_setup(a, NBLK, CBLK, ntn, 4 / (NBLK * CBLK));      // k-parts of a block: one slab each
+        if (rc) return rc;
     }
     dim3 grid(a.ctiles * ntn, a.splits);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
@@ -706,7 +749,7 @@ int launch_k(WgKArgs& a, hipStream_t st) {
 
 static int wgrad_impl(const cu_wgrad_desc* d, const void* src0, const float* scale0, const float* shift0,
                       const void* src1, const float* scale1, const float* shift1, const void* z, float* dw,
-                      size_t parts_floats, int* nparts, void* stream) {
+                      size_t parts_floats, int* nparts, int* layout, void* stream) {
     CU_CHECK_ARG(d != nullptr, "cu_conv_wgrad: null descriptor");
     CU_CHECK_ARG(d->dtype == CU_F32 || d->dtype == CU_BF16, "cu_conv_wgrad: bad dtype %d", d->dtype);
     CU_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= CU_MAX_TAPS, "cu_conv_wgrad: ntaps %d", d->ntaps);
@@ -725,14 +768,12 @@ static int wgrad_impl(const cu_wgrad_desc* d, const void* src0, const float* sca
     a.ZH = d->ZH; a.ZW = d->ZW; a.ZC = d->ZC; a.ZS = d->ZS; a.CO = d->CO; a.ntaps = d->ntaps;
     a.slope0 = d->slope0; a.slope1 = d->slope1; a.splits = d->splits;
     a.dbg = cu_env_int("CU_CONV_DBG", 0);
-    if (nparts) {         // partial-tile mode: slabs of [wtaps][CO][C0+C1] floats
-        size_t wt = 0;
-        for (int t = 0; t < d->ntaps; ++t) wt = (size_t)d->tap_w[t] + 1 > wt ? (size_t)d->tap_w[t] + 1 : wt;
-        a.part_stride = wt * (size_t)d->CO * (size_t)(d->C0 + d->C1);
-        const size_t cap = parts_floats / a.part_stride;
-        CU_CHECK_ARG(cap >= 1, "cu_conv_wgrad_parts: workspace of %zu floats holds no slab of %zu", parts_floats, a.part_stride);
-        a.max_parts = cap > 4096 ? 4096 : (int)cap;
+    for (int t = 0; t < d->ntaps; ++t) a.wtaps = d->tap_w[t] + 1 > a.wtaps ? d->tap_w[t] + 1 : a.wtaps;
+    if (nparts) {         // partial-tile mode (the launch function sizes the slabs for its block shape)
+        a.parts_floats = parts_floats;
         a.nparts_out = nparts;
+        a.layout_out = layout;
+        a.part_stride = 1;      // != 0: the kernels store; launch_* sets the real stride
     }
 
     const int CI_all = d->C0 + d->C1;
@@ -774,17 +815,28 @@ static int wgrad_impl(const cu_wgrad_desc* d, const void* src0, const float* sca
         }
         a.sdymin = ymin; a.sdxmin = xmin;
         a.SHH = (th - 1) * d->IS + (ymax - ymin) + 1; a.SHW = (tw - 1) * d->IS + (xmax - xmin) + 1;
-        a.s_halo = imgs * a.SHH * a.SHW;
+        a.ISL = d->IS;
+        if (a.s_deint) {          // four parity planes of (th + 1) x (tw + 1) pixels from (2 py0 - 2, 2 px0 - 2)
+            a.SHH = th + 1; a.SHW = tw + 1; a.s_plane = a.SHH * a.SHW; a.ISL = 1;
+            a.sdymin = -2; a.sdxmin = -2;
+            a.mg_spl = (unsigned)((0x100000000ull + (unsigned)a.s_plane - 1) / (unsigned)a.s_plane);
+        }
+        a.s_hpi = (a.s_deint ? 4 : 1) * a.SHH * a.SHW;
+        a.s_halo = imgs * a.s_hpi;
         a.zdymin = zymin; a.zdxmin = zxmin;
         a.ZHH = (th - 1) * d->ZS + (zymax - zymin) + 1; a.ZHW = (tw - 1) * d->ZS + (zxmax - zxmin) + 1;
         a.z_halo = imgs * a.ZHH * a.ZHW;
-        a.mg_shpi = (unsigned)((0x100000000ull + (unsigned)(a.SHH * a.SHW) - 1) / (unsigned)(a.SHH * a.SHW));
+        a.mg_shpi = (unsigned)((0x100000000ull + (unsigned)a.s_hpi - 1) / (unsigned)a.s_hpi);
         a.mg_shw = (unsigned)((0x100000000ull + (unsigned)a.SHW - 1) / (unsigned)a.SHW);
         a.mg_zhpi = (unsigned)((0x100000000ull + (unsigned)(a.ZHH * a.ZHW) - 1) / (unsigned)(a.ZHH * a.ZHW));
         a.mg_zhw = (unsigned)((0x100000000ull + (unsigned)a.ZHW - 1) / (unsigned)a.ZHW);
         a.zsame = 1;
         for (int t = 0; t < d->ntaps; ++t) {
             a.s_off[t] = (d->tap_dy[t] - ymin) * a.SHW + (d->tap_dx[t] - xmin);
+            if (a.s_deint) {
+                const int pa = d->tap_dy[t] & 1, pb = d->tap_dx[t] & 1;
+                a.s_off[t] = (pa * 2 + pb) * a.s_plane + ((d->tap_dy[t] - pa) / 2 + 1) * a.SHW + ((d->tap_dx[t] - pb) / 2 + 1);
+            }
             a.z_off[t] = (d->tap_zy[t] - zymin) * a.ZHW + (d->tap_zx[t] - zxmin);
             a.tap_w[t] = d->tap_w[t];
             if (a.z_off[t] != a.z_off[0]) a.zsame = 0;
@@ -812,6 +864,33 @@ static int wgrad_impl(const cu_wgrad_desc* d, const void* src0, const float* sca
             const int nwb = (wn ? 2 : 1) * (wc ? 2 : 1);
             const int min_nk = ((d->IS > 1 || d->ZS > 1) ? 64 : 256) / 16 / 4;      // the tile loop may halve BM twice
             if (!pc && dma_nw / nwb > min_nk) dma_nw = 4;
+        }
+        // ---- stride-2 3x3 layers: parity-deinterleaved source planes, dense k-loop (see WgKArgs::s_deint).  The source has
+        //      4x the pixels of Z, so the block is wide in n (Z is cheap) and 32 channels narrow: 128 (n) x 32 (c) x 9 taps
+        //      = 9 accumulators per computing wave, producer / consumer waves as on the stride-1 layers.
+        bool std3 = d->ntaps == 9 && d->IS == 2 && d->ZS == 1 && d->C1 == 0 && d->PW >= 8 && d->CO > 32 &&
+                    !cu_env_set("CU_WGRAD_NODEINT");
+        for (int t = 0; std3 && t < 9; ++t)
+            std3 = d->tap_dy[t] >= -1 && d->tap_dy[t] <= 1 && d->tap_dx[t] >= -1 && d->tap_dx[t] <= 1 && d->tap_zy[t] == 0 &&
+                   d->tap_zx[t] == 0;
+        if (std3) {
+            a.s_deint = 1;
+            const int nb = d->CO > 64 ? 4 : 2;
+            for (int BM = 128;; BM >>= 1) {
+                CU_CHECK_ARG(BM >= 32, "cu_conv_wgrad: patches do not fit in LDS");
+                const int rc = geometry(BM);
+                if (rc) return rc;
+                a.s_iters = cdiv(a.s_halo * 4, 256);
+                a.z_iters = cdiv(a.z_halo * 4 * nb, 256);
+                if ((size_t)(a.s_iters + a.z_iters) * 4096 <= (size_t)DMA_IMG_BYTES) break;
+            }
+            a.src0_bytes = (unsigned)b0; a.src1_bytes = (unsigned)b1; a.z_bytes = (unsigned)bz;
+            const int n = a.s_iters + a.z_iters;
+            a.pc_early = 0;
+            a.pc_items = (n * 70 + 99) / 100;
+            const bool rowk = a.twl >= 4;
+            if (nb == 4) return rowk ? launch_dma<4, 1, 9, 8, true, true>(a, st) : launch_dma<4, 1, 9, 8, true, false>(a, st);
+            return rowk ? launch_dma<2, 1, 9, 8, true, true>(a, st) : launch_dma<2, 1, 9, 8, true, false>(a, st);
         }
         const int issue_w = pc ? 4 : dma_nw;
         for (int BM = (d->IS > 1 || d->ZS > 1) ? 64 : 256;; BM >>= 1) {
@@ -914,13 +993,14 @@ static int wgrad_impl(const cu_wgrad_desc* d, const void* src0, const float* sca
 extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const float* scale0, const float* shift0,
                              const void* src1, const float* scale1, const float* shift1, const void* z, float* dw,
                              void* stream) {
-    return wgrad_impl(d, src0, scale0, shift0, src1, scale1, shift1, z, dw, 0, nullptr, stream);
+    return wgrad_impl(d, src0, scale0, shift0, src1, scale1, shift1, z, dw, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int cu_conv_wgrad_parts(const cu_wgrad_desc* d, const void* src0, const float* scale0, const float* shift0,
                                    const void* src1, const float* scale1, const float* shift1, const void* z, float* parts,
-                                   size_t parts_floats, int* nparts, void* stream) {
-    CU_CHECK_ARG(nparts != nullptr && parts != nullptr, "cu_conv_wgrad_parts: null pointer");
+                                   size_t parts_floats, int* nparts, int* layout, void* stream) {
+    CU_CHECK_ARG(nparts != nullptr && layout != nullptr && parts != nullptr, "cu_conv_wgrad_parts: null pointer");
     *nparts = 0;
-    return wgrad_impl(d, src0, scale0, shift0, src1, scale1, shift1, z, parts, parts_floats, nparts, stream);
+    *layout = 0;
+    return wgrad_impl(d, src0, scale0, shift0, src1, scale1, shift1, z, parts, parts_floats, nparts, layout, stream);
 }

@@ -254,8 +254,7 @@ constexpr int UNPREP_MAXT = 9;
 // every load in turn: 10 us per launch on average, 41 launches per step) or 0 = run-time count NTr.
 template <int NT>
 __global__ __launch_bounds__(256) void grad_unprep_rows_kernel(float* __restrict__ dwk, float* __restrict__ g, int NTr,
-                                                               int CO, int CI, int COP, long s_co, long s_ci, int accumulate,
-                                                               int nparts = 1, size_t pstride = 0) {
+                                                               int CO, int CI, int COP, long s_co, long s_ci, int accumulate) {
     __shared__ float tile[8 * (32 * UNPREP_MAXT + 1)];
     const int nt = NT ? NT : NTr;
     const bool co_rows = s_co > s_ci;                  // conv: rows = co, columns = ci; transposed conv: the other way
@@ -273,13 +272,6 @@ __global__ __launch_bounds__(256) void grad_unprep_rows_kernel(float* __restrict
             float v[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) v[t] = ok ? src[t * tstride] : 0.f;
-            // partial-tile form (cu_grad_unprep_parts): slabs 1 .. nparts-1 added in slab order (a fixed summation order)
-#pragma unroll 4
-            for (int s = 1; s < nparts; ++s) {
-                const float* sp = src + (size_t)s * pstride;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] += ok ? sp[t * tstride] : 0.f;
-            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 tile[ty * pitch + tx * NT + t] = v[t];
@@ -287,9 +279,7 @@ __global__ __launch_bounds__(256) void grad_unprep_rows_kernel(float* __restrict
             }
         } else {
             for (int t = 0; t < nt; ++t) {
-                float v = ok ? src[t * tstride] : 0.f;
-                for (int s = 1; s < nparts; ++s) v += ok ? src[(size_t)s * pstride + t * tstride] : 0.f;
-                tile[ty * pitch + tx * nt + t] = v;
+                tile[ty * pitch + tx * nt + t] = ok ? src[t * tstride] : 0.f;
                 if (ok && (accumulate & 2)) src[t * tstride] = 0.f;
             }
         }
@@ -321,10 +311,13 @@ __global__ __launch_bounds__(256) void grad_unprep_rows_kernel(float* __restrict
     }
 }
 
-// Partial tiles of the weight gradient (cu_conv_wgrad_parts): parts[s][e], s < S slabs of E floats.  Workgroups of
-// grid.y = group j sum the G consecutive slabs j*G .. j*G+G-1 INTO slab j*G, in slab order (fixed summation order, no
-// atomics): the thin layers have up to 256 slabs of a small tile, which the un-preparation's few workgroups would walk
-// one L2 round trip at a time.
+// Partial tiles of the weight gradient (cu_conv_wgrad_parts): S slabs of E4 16-byte pieces in the accumulators' own
+// ("native") layout [block][wave block][weight tap][q][lane][4].  Two element-wise kernels sum them in slab order (a fixed
+// summation order, no atomics):
+//   parts_reduce_kernel  group j (grid.y) adds the G consecutive slabs j*G .. j*G+G-1 INTO slab j*G -- first level for the
+//                        thin layers, whose up to 256 slabs of a small tile would otherwise be walked by a few workgroups;
+//   parts_finish_kernel  adds `S` slabs `stride4` pieces apart and writes the plain [T][CO][CI] tile: piece (block, wave
+//                        block, t, q, lane) = rows n0 .. n0+3 (n0 = nt*TN + nblk*32 + 8q + 4h), column ct*TC + cblk*32 + r.
 __global__ __launch_bounds__(256) void parts_reduce_kernel(float* __restrict__ parts, size_t E4, int S, int G) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= E4) return;
@@ -337,6 +330,35 @@ __global__ __launch_bounds__(256) void parts_reduce_kernel(float* __restrict__ p
         acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
     }
     base[0] = acc;
+}
+
+__global__ __launch_bounds__(256) void parts_finish_kernel(const float* __restrict__ parts, size_t E4, size_t stride4, int S,
+                                                           float* __restrict__ out, int T, int CO, int CI, int NBLK,
+                                                           int CBLK, int ctiles) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= E4) return;
+    const int lane = (int)(i & 63), q = (int)((i >> 6) & 3);
+    size_t rest = i >> 8;
+    const int t = (int)(rest % T); rest /= T;
+    const int nwb = NBLK * CBLK;
+    const int blk = (int)(rest % nwb);
+    const int block = (int)(rest / nwb);
+    const int nt = block / ctiles, ct = block - nt * ctiles;
+    const int nblk = blk / CBLK, cblk = blk - nblk * CBLK;
+    const int n0 = (nt * NBLK + nblk) * 32 + 8 * q + 4 * (lane >> 5);
+    const int c = (ct * CBLK + cblk) * 32 + (lane & 31);
+    if (n0 >= CO || c >= CI) return;              // regions of inactive waves are never written: never read either
+    const f32x4* base = reinterpret_cast<const f32x4*>(parts) + i;
+    f32x4 acc = base[0];
+#pragma unroll 8
+    for (int s = 1; s < S; ++s) {
+        const f32x4 v = base[(size_t)s * stride4];
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    float* o = out + ((size_t)t * CO + n0) * CI + c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (n0 + e < CO) o[(size_t)e * CI] = acc[e];
 }
 
 // ---- batched form: the operand copies of every conv layer of the network in ONE launch ---------------------------------
@@ -663,31 +685,30 @@ extern "C" int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_
     return 0;
 }
 
-extern "C" int cu_grad_unprep_parts(int T, int CO, int CI, int COP, long s_co, long s_ci, float* parts, int nparts,
-                                    float* grad, int accumulate, void* stream) {
+extern "C" int cu_grad_unprep_parts(int T, int CO, int CI, int COP, long s_co, long s_ci, float* parts, size_t parts_floats,
+                                    int nparts, int layout, float* grad, int accumulate, void* stream) {
     CU_CHECK_ARG(T > 0 && CO > 0 && CI > 0 && COP >= CO && parts && grad && nparts >= 1, "cu_grad_unprep_parts: bad argument");
-    const bool co_rows = s_co > s_ci;
-    CU_CHECK_ARG((T == 9 || T == 4 || T == 1) && ((co_rows && s_ci == T) || (!co_rows && s_co == T)),
-                 "cu_grad_unprep_parts: taps must be innermost in the logical layout (T = 9, 4 or 1)");
+    const int NBLK = layout >> 8, CBLK = layout & 255;
+    CU_CHECK_ARG(NBLK >= 1 && NBLK <= 4 && CBLK >= 1 && CBLK <= 2, "cu_grad_unprep_parts: layout %d is not one cu_conv_wgrad_parts returns", layout);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const size_t E = (size_t)T * COP * CI;
-    CU_CHECK_ARG(E % 4 == 0, "cu_grad_unprep_parts: slab size must be a multiple of 4 floats");
-    size_t pstride = E;
+    const int ctiles = cdiv(CI, 32 * CBLK), ntn = cdiv(COP, 32 * NBLK);
+    const size_t E = (size_t)ntn * ctiles * NBLK * CBLK * T * 1024, plain = (size_t)T * COP * CI;
+    CU_CHECK_ARG(parts_floats >= (size_t)nparts * E + plain, "cu_grad_unprep_parts: workspace of %zu floats < %d slabs of %zu + %zu",
+                 parts_floats, nparts, E, plain);
+    size_t stride4 = E / 4;
+    const unsigned gx = (unsigned)((E / 4 + 255) / 256);
     if (nparts > 16) {          // first level: <= 16 group sums, by the whole chip
         const int G = cdiv(nparts, 16), groups = cdiv(nparts, G);
-        hipLaunchKernelGGL(parts_reduce_kernel, dim3((unsigned)((E / 4 + 255) / 256), groups), dim3(256), 0, st, parts, E / 4,
-                           nparts, G);
+        hipLaunchKernelGGL(parts_reduce_kernel, dim3(gx, groups), dim3(256), 0, st, parts, E / 4, nparts, G);
         CU_LAUNCH_CHECK();
         nparts = groups;
-        pstride = (size_t)G * E;
+        stride4 = (size_t)G * (E / 4);
     }
-    dim3 grid(cdiv(co_rows ? CI : CO, 32), cdiv(co_rows ? CO : CI, 8));
-    const int acc = accumulate & 1;
-    if (T == 9) hipLaunchKernelGGL(grad_unprep_rows_kernel<9>, grid, dim3(256), 0, st, parts, grad, T, CO, CI, COP, s_co, s_ci, acc, nparts, pstride);
-    else if (T == 4) hipLaunchKernelGGL(grad_unprep_rows_kernel<4>, grid, dim3(256), 0, st, parts, grad, T, CO, CI, COP, s_co, s_ci, acc, nparts, pstride);
-    else hipLaunchKernelGGL(grad_unprep_rows_kernel<1>, grid, dim3(256), 0, st, parts, grad, T, CO, CI, COP, s_co, s_ci, acc, nparts, pstride);
+    float* sum = parts + parts_floats - plain;         // the plain tile lives at the END of the workspace
+    hipLaunchKernelGGL(parts_finish_kernel, dim3(gx), dim3(256), 0, st, (const float*)parts, E / 4, stride4, nparts, sum, T, COP,
+                       CI, NBLK, CBLK, ctiles);
     CU_LAUNCH_CHECK();
-    return 0;
+    return cu_grad_unprep(T, CO, CI, COP, s_co, s_ci, sum, grad, accumulate & 1, stream);
 }
 
 extern "C" int cu_adam_step(size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,

@@ -377,8 +377,8 @@ class UNetEngine:
     def _wgrad(self, srcs, z: Tensor, shape, grad: Tensor, kind: str, prefix: str, **kw):
         """weight gradient of one layer -> ``grad`` (+=): partial tiles + ordered sum."""
         ws = self._parts_ws(z.device)
-        nparts = ops.conv_wgrad(srcs, z, ws, parts=True, **kw)
-        ops.grad_unprep_parts(ws, nparts, shape[1], grad, kind, accumulate=True)
+        slabs = ops.conv_wgrad(srcs, z, ws, parts=True, **kw)
+        ops.grad_unprep_parts(ws, slabs, shape[1], grad, kind, accumulate=True)
         self._ready(prefix)
 
     def _unprep(self, dwk: Tensor, grad: Tensor, kind: str, prefix: str):
@@ -609,9 +609,9 @@ class ConfidenceEngine:
             ops.act_bwd(g, out.z, 0.0, G[f"model.{i}.bias"], deterministic=self.deterministic)
             if self._parts is None or self._parts.device != g.device:
                 self._parts = torch.empty(4 << 20, dtype=torch.float32, device=g.device)
-            nparts = ops.conv_wgrad([src], g, self._parts, grid=(h, w_), in_stride=1, z_stride=1, taps=TAPS3_W, n_cols=co,
+            slabs = ops.conv_wgrad([src], g, self._parts, grid=(h, w_), in_stride=1, z_stride=1, taps=TAPS3_W, n_cols=co,
                                     parts=True)
-            ops.grad_unprep_parts(self._parts, nparts, co, G[f"model.{i}.weight"], "conv", accumulate=True)
+            ops.grad_unprep_parts(self._parts, slabs, co, G[f"model.{i}.weight"], "conv", accumulate=True)
             if li == 0 and not need_input_grad:
                 return None
             _, wd = self._operands(f"model.{i}.weight", w)

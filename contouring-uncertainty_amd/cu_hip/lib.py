@@ -56,7 +56,7 @@ _SIGS = {
     "cu_conv_gemm_stats": (C.c_int, [C.POINTER(ConvDesc)] + [_P] * 11 + [C.c_size_t, _P, C.POINTER(C.c_int), _P]),
     "cu_conv_gemm_ex": (C.c_int, [C.POINTER(ConvDesc)] + [_P] * 11 + [C.c_size_t, C.POINTER(ConvEpilogue), C.POINTER(C.c_int), _P]),
     "cu_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc)] + [_P] * 9),
-    "cu_conv_wgrad_parts": (C.c_int, [C.POINTER(WgradDesc)] + [_P] * 8 + [C.c_size_t, C.POINTER(C.c_int), _P]),
+    "cu_conv_wgrad_parts": (C.c_int, [C.POINTER(WgradDesc)] + [_P] * 8 + [C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
     "cu_conv_c1_fwd": (C.c_int, [C.c_int] * 5 + [_P] * 5),
     "cu_conv_c1_wgrad": (C.c_int, [C.c_int] * 5 + [_P] * 4),
     "cu_conv_c1_wgrad_det": (C.c_int, [C.c_int] * 5 + [_P] * 4 + [C.c_size_t, _P]),
@@ -84,7 +84,7 @@ _SIGS = {
     "cu_linear_bwd": (C.c_int, [C.c_int] * 3 + [_P] * 7),
     "cu_weight_prep": (C.c_int, [C.c_int] * 5 + [C.c_long, C.c_long] + [_P] * 4),
     "cu_grad_unprep": (C.c_int, [C.c_int] * 4 + [C.c_long, C.c_long] + [_P] * 2 + [C.c_int, _P]),
-    "cu_grad_unprep_parts": (C.c_int, [C.c_int] * 4 + [C.c_long, C.c_long, _P, C.c_int, _P, C.c_int, _P]),
+    "cu_grad_unprep_parts": (C.c_int, [C.c_int] * 4 + [C.c_long, C.c_long, _P, C.c_size_t, C.c_int, C.c_int, _P, C.c_int, _P]),
     "cu_psm_sample_gauss": (C.c_int, [C.c_int] * 3 + [_P] * 6 + [C.c_int, _P, C.c_int] + [_P] * 4 + [C.c_uint64, _P, _P]),
     "cu_weight_prep_batch": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P]),
     "cu_psm_record_floats": (C.c_int, [C.c_int, _P, _P]),

@@ -173,7 +173,7 @@ def conv_wgrad(srcs: Sequence[Act], z: Tensor, dwk: Tensor, *, grid: Tuple[int, 
                alg_cols: Optional[int] = None) -> int:
     """dWk[tap_w][n][c] += sum_p Z[p*ZS + zoff, n] * act(S[p*IS + off, c])  (cu_conv_wgrad); taps = (dy,dx,zy,zx,w).
     ``parts=True`` (cu_conv_wgrad_parts): ``dwk`` is a flat f32 scratch; every adder stores its partial tile into a slab
-    of its own (no atomics) and the number of slabs is returned for :func:`grad_unprep_parts`."""
+    of its own (no atomics); returns (number of slabs, their layout code) for :func:`grad_unprep_parts`."""
     lib = L.load()
     s0 = srcs[0]
     s1 = srcs[1] if len(srcs) > 1 else None
@@ -200,16 +200,16 @@ def conv_wgrad(srcs: Sequence[Act], z: Tensor, dwk: Tensor, *, grid: Tuple[int, 
     nbytes = d.N * d.SH * d.SW * (d.C0 + d.C1) * esz + d.N * d.ZH * d.ZW * d.ZC * esz
     note = f"N{d.N} {d.PH}x{d.PW} IS{d.IS} ZS{d.ZS} C{d.C0}+{d.C1}->{d.CO} t{d.ntaps}"
     import ctypes as _C
-    nparts = _C.c_int(0)
+    nparts, layout = _C.c_int(0), _C.c_int(0)
     with _Prof("igemm_wgrad", flops, note, nbytes, exec_flops):
         if parts:
             rc = lib.cu_conv_wgrad_parts(d, L.ptr(t0), L.ptr(sc0), L.ptr(sh0), L.ptr(t1), L.ptr(sc1), L.ptr(sh1), L.ptr(z),
-                                         L.ptr(dwk), dwk.numel(), _C.byref(nparts), L.stream_ptr())
+                                         L.ptr(dwk), dwk.numel(), _C.byref(nparts), _C.byref(layout), L.stream_ptr())
         else:
             rc = lib.cu_conv_wgrad(d, L.ptr(t0), L.ptr(sc0), L.ptr(sh0), L.ptr(t1), L.ptr(sc1), L.ptr(sh1), L.ptr(z),
                                    L.ptr(dwk), L.stream_ptr())
     L.check(rc, "cu_conv_wgrad_parts" if parts else "cu_conv_wgrad")
-    return nparts.value
+    return (nparts.value, layout.value) if parts else 0
 
 
 def conv_c1_fwd(img: Tensor, w9: Tensor, bias: Optional[Tensor], dst: Tensor):
@@ -501,9 +501,9 @@ def grad_unprep(dwk: Tensor, grad: Tensor, kind: str, accumulate: bool = False, 
                                         int(accumulate) | (int(clear) << 1), L.stream_ptr()), "cu_grad_unprep")
 
 
-def grad_unprep_parts(parts: Tensor, nparts: int, cop: int, grad: Tensor, kind: str, accumulate: bool = True):
-    """sum of the ``nparts`` slabs [T][cop][CI] that ``conv_wgrad(parts=True)`` wrote into ``parts`` -> logical gradient
-    (cu_grad_unprep_parts; fixed summation order; ``parts`` is scratch)."""
+def grad_unprep_parts(parts: Tensor, slabs: Tuple[int, int], cop: int, grad: Tensor, kind: str, accumulate: bool = True):
+    """sum of the slabs that ``conv_wgrad(parts=True)`` wrote into ``parts`` (``slabs`` = what it returned; ``cop`` = its
+    ``n_cols``) -> logical gradient (cu_grad_unprep_parts; fixed summation order; ``parts`` is scratch)."""
     if kind == "conv":
         co, ci, kh, kw = grad.shape
         t = kh * kw
@@ -512,10 +512,10 @@ def grad_unprep_parts(parts: Tensor, nparts: int, cop: int, grad: Tensor, kind: 
         ci, co, kh, kw = grad.shape
         t = kh * kw
         s_co, s_ci = t, co * t
-    assert parts.dtype == torch.float32 and nparts * t * cop * ci <= parts.numel()
+    assert parts.dtype == torch.float32
     with _Prof("weight_prep"):
-        L.check(L.load().cu_grad_unprep_parts(t, co, ci, cop, s_co, s_ci, L.ptr(parts), nparts, L.ptr(grad),
-                                              int(accumulate), L.stream_ptr()), "cu_grad_unprep_parts")
+        L.check(L.load().cu_grad_unprep_parts(t, co, ci, cop, s_co, s_ci, L.ptr(parts), parts.numel(), slabs[0], slabs[1],
+                                              L.ptr(grad), int(accumulate), L.stream_ptr()), "cu_grad_unprep_parts")
 
 
 _PREP_ITEM = None

@@ -136,15 +136,17 @@ int cu_conv_wgrad(const cu_wgrad_desc* d,
                   const void* z, float* dw /* [wtaps][CO][C0+C1] f32 */, void* stream);
 
 /* The same without atomics ("partial tiles"): every adder of a dW block -- one per pixel split, times the k-parts of the
- * register-staged kernel -- STORES its partial [wtaps][CO][C0+C1] tile into a slab of its own, parts[s], s < *nparts
- * (host int, written before the call returns); d->splits is capped so that the slabs fit parts_floats.  Contents of
- * `parts` are irrelevant on entry; cu_grad_unprep_parts sums the slabs in slab order, so the gradient is bit-identical run
- * to run at ANY split count (round 3: the production form; the atomics form runs at the chip's ~1.3 TB/s float-atomic
- * rate, 37.7 MB per launch = 29 us whatever the layer). */
+ * register-staged kernel -- STORES its partial tile into a slab of its own in `parts` (f32 scratch of parts_floats
+ * elements, contents irrelevant on entry), in the accumulators' own layout (16-byte stores, 1 KiB per instruction).
+ * *nparts = slabs written, *layout = their block shape: both host ints, written before the call returns, to be handed to
+ * cu_grad_unprep_parts, which adds the slabs in slab order -- the gradient is bit-identical run to run at ANY split count.
+ * d->splits is capped so that the slabs plus one plain [wtaps][CO][C0+C1] tile fit parts_floats.
+ * (Round 3, the production form: the atomics of cu_conv_wgrad run at the chip's ~1.3 TB/s float-atomic rate, 37.7 MB per
+ * launch = 29 us whatever the layer.) */
 int cu_conv_wgrad_parts(const cu_wgrad_desc* d,
                         const void* src0, const float* scale0, const float* shift0,
                         const void* src1, const float* scale1, const float* shift1,
-                        const void* z, float* parts, size_t parts_floats, int* nparts, void* stream);
+                        const void* z, float* parts, size_t parts_floats, int* nparts, int* layout, void* stream);
 
 /* First layer, Cin = 1 (input_block.conv1.conv, unet2.py:113-119): direct 3x3 conv of the f32 image. */
 int cu_conv_c1_fwd(int dtype, int N, int H, int W, int CO, const float* img /* [N][H][W] */,
@@ -271,11 +273,11 @@ int cu_weight_prep(int dtype, int T, int CO, int CI, int COP, long s_co, long s_
 int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_ci, float* dwk, float* grad, int accumulate,
                    void* stream);
 
-/* Sum of the nparts slabs cu_conv_wgrad_parts wrote (parts [nparts][T][COP][CI] f32; more than 16 slabs are first summed
- * in groups, IN PLACE: `parts` is scratch) -> logical-layout gradient; accumulate bit 0 as above.  Taps innermost in the
- * logical layout (Conv2d / ConvTranspose2d weights), T = 9, 4 or 1. */
-int cu_grad_unprep_parts(int T, int CO, int CI, int COP, long s_co, long s_ci, float* parts, int nparts, float* grad,
-                         int accumulate, void* stream);
+/* Sum of the nparts slabs cu_conv_wgrad_parts wrote into `parts` (same parts_floats, nparts and layout; T = its weight-tap
+ * count, COP / CI = its CO and C0+C1, CO <= COP = rows of the logical gradient; `parts` is scratch: more than 16 slabs are first summed in groups in place, the plain
+ * [T][CO][CI] sum is formed at its end) -> logical-layout gradient as cu_grad_unprep; accumulate bit 0 as there. */
+int cu_grad_unprep_parts(int T, int CO, int CI, int COP, long s_co, long s_ci, float* parts, size_t parts_floats,
+                         int nparts, int layout, float* grad, int accumulate, void* stream);
 
 /* Batched form: one launch for every conv layer of the network.  `items` is a DEVICE array (blk0 ascending, blk0 of
  * item i = number of 256-thread blocks of items 0..i-1; an item has tiles_co * tiles_ci blocks of 32 x 32 x T weights,

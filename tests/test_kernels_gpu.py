@@ -150,11 +150,11 @@ def test_conv_dgrad_wgrad(dtype, case):
         outs = []
         for _ in range(2):
             ws = torch.full((6 << 20,), float("nan"), device=DEV)
-            nparts = ops.conv_wgrad(srcs, gz.z, ws, grid=(os_, os_), in_stride=stride, z_stride=1, taps=TAPS3_W, n_cols=co,
+            slabs = ops.conv_wgrad(srcs, gz.z, ws, grid=(os_, os_), in_stride=stride, z_stride=1, taps=TAPS3_W, n_cols=co,
                                     parts=True)
-            assert nparts >= 1
+            assert slabs[0] >= 1
             gp = torch.zeros_like(w)
-            ops.grad_unprep_parts(ws, nparts, co, gp, "conv", accumulate=True)
+            ops.grad_unprep_parts(ws, slabs, co, gp, "conv", accumulate=True)
             outs.append(gp)
         assert rel_err(outs[0], wq.grad) < (2e-4 if dtype == torch.float32 else 1e-2)
         assert torch.equal(outs[0], outs[1])
@@ -194,10 +194,10 @@ def test_conv_transpose(dtype, case):
     ops.grad_unprep(dwk, gw, "convT", accumulate=True)
     assert rel_err(gw, wq.grad) < (2e-4 if dtype == torch.float32 else 1e-2)
     ws = torch.full((4 << 20,), float("nan"), device=DEV)           # partial-tile form
-    nparts = ops.conv_wgrad([a_plain], dun, ws, grid=(size, size), in_stride=1, z_stride=2,
+    slabs = ops.conv_wgrad([a_plain], dun, ws, grid=(size, size), in_stride=1, z_stride=2,
                             taps=[(0, 0, dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)], n_cols=co, parts=True)
     gp = torch.zeros_like(w)
-    ops.grad_unprep_parts(ws, nparts, co, gp, "convT", accumulate=True)
+    ops.grad_unprep_parts(ws, slabs, co, gp, "convT", accumulate=True)
     assert rel_err(gp, wq.grad) < (2e-4 if dtype == torch.float32 else 1e-2)
 
 

@@ -143,7 +143,10 @@ class UNetEngine:
         self.drop_mask_fn: Optional[Callable[[str, int, int, torch.device], Tensor]] = None   # tests inject masks
         self.debug: Optional[Dict[str, Tensor]] = None    # tests/tools: set to {} to capture per-layer gradients (NHWC)
         self._prep_state = None     # (pointer key, item table, blocks, names) of the batched operand preparation
-        self._dwk_ws: Optional[Tensor] = None       # partial-tile scratch of the weight gradients
+        self._dwk_ws = None                         # partial-tile scratch of the weight gradients (two buffers)
+        self._red: Optional[torch.cuda.Stream] = None      # stream of the partial tiles' sums / un-preparations
+        self._red_done = [None, None]
+        self._wg_count = 0
         self._dw9_ws: Optional[Tensor] = None       # first layer's 9 x CO accumulator (zero between uses)
         # InstanceNorm workspaces (atomics targets) of all layers of one pass: slices of ONE arena per direction that
         # is zeroed by one fill at the start of the pass (instead of one memset launch per layer)
@@ -359,27 +362,52 @@ class UNetEngine:
     def _join_wgrad(self, device):
         if self._side is not None and self._side_keep:
             torch.cuda.current_stream(device).wait_stream(self._side)
+            if self._red is not None:
+                torch.cuda.current_stream(device).wait_stream(self._red)
         self._side_keep.clear()
 
     PARTS_FLOATS = 24 << 20       # 96 MiB: 256 slabs of a 64 x 64 x 9 block are 9.4 M floats; the library caps the splits
 
-    def _parts_ws(self, device) -> Tensor:
+    def _parts_ws(self, device, k: int = 0) -> Tensor:
         """Scratch of the weight gradients' partial tiles (cu_conv_wgrad_parts): every pixel split of a launch stores its
         tile into a slab of its own and cu_grad_unprep_parts adds the slabs in a fixed order -- no f32 atomics (they ran
         at the chip-wide ~1.3 TB/s atomic rate: 29 us per launch whatever the layer), no zeroing, no read-and-clear
-        invariant, and bit-identical weight gradients run to run.  One buffer per engine: its users are stream-ordered
-        (wgrad -> un-preparation pairs, all on the weight-gradient stream)."""
+        invariant, and bit-identical weight gradients run to run.  Two buffers per engine, used alternately: layer L's sum
+        (on the reduction stream) overlaps layer L+1's weight-gradient launch (on the weight-gradient stream)."""
         ws = self._dwk_ws
-        if ws is None or ws.device != device or ws.numel() < self.PARTS_FLOATS:
-            ws = self._dwk_ws = torch.empty(self.PARTS_FLOATS, dtype=torch.float32, device=device)
-        return ws
+        if ws is None or ws[0].device != device or ws[0].numel() < self.PARTS_FLOATS:
+            ws = self._dwk_ws = [torch.empty(self.PARTS_FLOATS, dtype=torch.float32, device=device) for _ in range(2)]
+            self._red_done = [None, None]
+        return ws[k]
 
     def _wgrad(self, srcs, z: Tensor, shape, grad: Tensor, kind: str, prefix: str, **kw):
-        """weight gradient of one layer -> ``grad`` (+=): partial tiles + ordered sum."""
-        ws = self._parts_ws(z.device)
+        """weight gradient of one layer -> ``grad`` (+=): partial tiles (on the current = weight-gradient stream) + their
+        ordered sum and un-preparation (light, LDS-free kernels: on a THIRD stream, so that they run beside the next
+        layer's weight-gradient launch, which owns every CU's LDS, instead of in front of it)."""
+        k = self._wg_count & 1
+        self._wg_count += 1
+        ws = self._parts_ws(z.device, k)
+        cur = torch.cuda.current_stream(z.device)
+        third = self.side_wgrad and self._side is not None and cur == self._side
+        if third:
+            if self._red is None or self._red.device != z.device:
+                self._red = torch.cuda.Stream(z.device)
+            if self._red_done[k] is not None:
+                cur.wait_event(self._red_done[k])              # buffer k's previous sum has been read
         slabs = ops.conv_wgrad(srcs, z, ws, parts=True, **kw)
-        ops.grad_unprep_parts(ws, slabs, shape[1], grad, kind, accumulate=True)
-        self._ready(prefix)
+        if not third:
+            ops.grad_unprep_parts(ws, slabs, shape[1], grad, kind, accumulate=True)
+            self._ready(prefix)
+            return
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        with torch.cuda.stream(self._red):
+            self._red.wait_event(ev)
+            ops.grad_unprep_parts(ws, slabs, shape[1], grad, kind, accumulate=True)
+            self._ready(prefix)
+            done = torch.cuda.Event()
+            done.record(self._red)
+        self._red_done[k] = done
 
     def _unprep(self, dwk: Tensor, grad: Tensor, kind: str, prefix: str):
         """kernel-layout dWk -> logical gradient, layer by layer (measured in round 1: one batched launch at the end of the
@@ -491,7 +519,10 @@ class UNetEngine:
             try:
                 if self._side is not None:
                     torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+                if self._red is not None:
+                    torch.cuda.current_stream(self._red.device).wait_stream(self._red)
             finally:
+                self._red_done = [None, None]
                 self._side_keep.clear()
                 self._given_sums.clear()
                 self._dw9_ws = None
@@ -506,6 +537,9 @@ class UNetEngine:
         n, h, w_, c_last = last.z.shape
         self._arena["bwd"].begin(last.z.device)
         self._given_sums.clear()
+        # the previous backward joined the reduction stream into this one: its "buffer read" events are history (and must not
+        # be waited for inside a hipGraph capture, which they precede)
+        self._red_done = [None, None]
         # ---- 1x1 output conv
         if dl_nhwc is not None:
             assert dl_nhwc.dtype == dt and dl_nhwc.shape == (n, h, w_, 32)

@@ -149,7 +149,7 @@ def test_conv_dgrad_wgrad(dtype, case):
     for srcs in ([a0, a1], [ops.Act(nhwc(r0, dtype), None, 1.0), ops.Act(nhwc(r1, dtype), None, 1.0)]):
         outs = []
         for _ in range(2):
-            ws = torch.full((6 << 20,), float("nan"), device=DEV)
+            ws = torch.full((24 << 20,), float("nan"), device=DEV)
             slabs = ops.conv_wgrad(srcs, gz.z, ws, grid=(os_, os_), in_stride=stride, z_stride=1, taps=TAPS3_W, n_cols=co,
                                     parts=True)
             assert slabs[0] >= 1
@@ -193,7 +193,7 @@ def test_conv_transpose(dtype, case):
     gw = torch.zeros_like(w)
     ops.grad_unprep(dwk, gw, "convT", accumulate=True)
     assert rel_err(gw, wq.grad) < (2e-4 if dtype == torch.float32 else 1e-2)
-    ws = torch.full((4 << 20,), float("nan"), device=DEV)           # partial-tile form
+    ws = torch.full((24 << 20,), float("nan"), device=DEV)          # partial-tile form
     slabs = ops.conv_wgrad([a_plain], dun, ws, grid=(size, size), in_stride=1, z_stride=2,
                             taps=[(0, 0, dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)], n_cols=co, parts=True)
     gp = torch.zeros_like(w)
@@ -724,3 +724,33 @@ def test_thin_streaming_conv(case):
         db = torch.empty(n, size, size, 32, device=DEV, dtype=dtype)
         ops.conv_gemm([gz], wd, None, grid=(size, size), in_stride=1, taps=TAPS3_D, dsts=[da, db], dst_cols=[32, 32])
         assert rel_err(nchw(da), gx[:, :32]) < tol(dtype) and rel_err(nchw(db), gx[:, 32:]) < tol(dtype)
+
+
+@pytest.mark.parametrize("case", [(3, 64, 128, 32), (2, 32, 64, 64), (4, 256, 480, 16), (2, 128, 256, 64), (5, 480, 480, 16),
+                                  (2, 64, 128, 8)])
+def test_stride2_wgrad_parity_planes(case):
+    """Weight gradient of a stride-2 3x3 conv from ONE plain bf16 source (what the engine launches for every downsampling
+    block): the LDS-DMA kernel stages the four parity planes of the source (dense k-loop).  Ragged image counts, 16- and
+    32-pixel rows, 8-pixel rows (the general k-step addressing), the 480-channel tail; atomics and partial-tile forms."""
+    ops = _ops()
+    from cu_hip.engine import TAPS3_W
+    n, ci, co, size = case
+    dtype = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(21)
+    x = rq(torch.randn(n, ci, size, size, device=DEV, generator=g), dtype).requires_grad_(True)
+    w = (torch.randn(co, ci, 3, 3, device=DEV, generator=g) / math.sqrt(9 * ci)).requires_grad_(True)
+    dz = rq(torch.randn(n, co, size // 2, size // 2, device=DEV, generator=g), dtype)
+    F.conv2d(x, w, None, stride=2, padding=1).backward(dz)
+    src = ops.Act(nhwc(x.detach(), dtype), None, 1.0)
+    zt = nhwc(dz, dtype)
+    os_ = size // 2
+    dwk = torch.zeros(9, co, ci, device=DEV)
+    ops.conv_wgrad([src], zt, dwk, grid=(os_, os_), in_stride=2, z_stride=1, taps=TAPS3_W, n_cols=co)
+    gw = torch.zeros_like(w)
+    ops.grad_unprep(dwk, gw, "conv", accumulate=True)
+    assert rel_err(gw, w.grad) < 2e-3
+    ws = torch.full((24 << 20,), float("nan"), device=DEV)
+    slabs = ops.conv_wgrad([src], zt, ws, grid=(os_, os_), in_stride=2, z_stride=1, taps=TAPS3_W, n_cols=co, parts=True)
+    gp = torch.zeros_like(w)
+    ops.grad_unprep_parts(ws, slabs, co, gp, "conv", accumulate=True)
+    assert rel_err(gp, w.grad) < 2e-3

@@ -388,7 +388,10 @@ class UNetEngine:
         self._wg_count += 1
         ws = self._parts_ws(z.device, k)
         cur = torch.cuda.current_stream(z.device)
-        third = self.side_wgrad and self._side is not None and cur == self._side
+        # (inside a hipGraph capture the sums stay on the weight-gradient stream: ROCm 7.2's capture_end crashed on the
+        # stream forked from a forked stream; CONTOUR_GRAPH_THIRD=1 re-enables it for experiments)
+        third = self.side_wgrad and self._side is not None and cur == self._side and \
+            (not torch.cuda.is_current_stream_capturing() or os.environ.get("CONTOUR_GRAPH_THIRD") == "1")
         if third:
             if self._red is None or self._red.device != z.device:
                 self._red = torch.cuda.Stream(z.device)

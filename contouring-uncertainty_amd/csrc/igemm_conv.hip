@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256) void ksplit_finish_kernel(const float* __restr
 
 int cu_pconv_try(const cu_conv_desc* d, const void* src0, const void* w, const float* bias, void* dst0, void* stream);
 int cu_tconv_try(const cu_conv_desc* d, const void* src0, const void* src1, const void* w, const float* bias, void* dst0,
-                 void* dst1, const cu_conv_epilogue* ep, void* stream);
+                 void* dst1, const cu_conv_epilogue* ep, const float* scale0, const float* shift0, void* stream);
 
 extern "C" int cu_conv_gemm(const cu_conv_desc* d, const void* src0, const float* scale0, const float* shift0,
                             const void* src1, const float* scale1, const float* shift1, const void* w, const float* bias,
@@ -1096,8 +1096,9 @@ extern "C" int cu_conv_gemm_ex(const cu_conv_desc* d, const void* src0, const fl
     }
 
     // ---- thin, large bf16 3x3 stride-1 layers (256^2 x 32, 128^2 x 64 channels): the streaming kernel (tconv.hip)
-    if (bf && !scale0 && !scale1 && !cu_env_set("CU_CONV_NOTCONV")) {
-        const int rc = cu_tconv_try(d, src0, src1, w, bias, dst0, dst1, stats_done ? ep : nullptr, stream);
+    // (a raw source 0 -- scale0 / shift0 given -- is normalised + activated in LDS by the kernel's XF instances)
+    if (bf && !scale1 && (!scale0 || shift0) && !cu_env_set("CU_CONV_NOTCONV")) {
+        const int rc = cu_tconv_try(d, src0, src1, w, bias, dst0, dst1, stats_done ? ep : nullptr, scale0, shift0, stream);
         if (rc == 2) *stats_done = 1;
         if (rc != 0) return rc < 0 ? rc : 0;
     }

@@ -38,6 +38,7 @@ struct WgKArgs {
     int s_iters, z_iters;                      // LDS-DMA kernel: 4-KiB staging blocks per tile for S / Z
     int pc_items;                              // producer/consumer kernel: staging rounds issued by the producer waves
     int pc_early;                              // ... and rounds the computing waves issue before their k-loop
+    unsigned xstat_bytes;                      // XF: bytes of the scale + shift planes behind sc0
     int dbg;                                   // CU_CONV_DBG bits (timing experiments): 1 no atomics, 2 no MFMA, 4 no commit, 8 no loads
     // partial-tile mode (cu_conv_wgrad_parts): part_stride != 0 -> every adder of a dW block STORES its partial tile into
     // its own slab dw + part * part_stride (no atomics); the slabs are summed in a fixed order by cu_grad_unprep_parts.
@@ -376,7 +377,11 @@ constexpr int DMA_IMG_BYTES = 78 * 1024;      // per image; two of them per work
 // waves 4..7 only issue the LDS-DMA of the next tile into the other image.  The DMA queue drains at L2 speed and blocks
 // the wave that issues into it; in this split that wave has nothing else to do, and its SIMD keeps issuing the other
 // wave's MFMAs, so staging and k-loop overlap instead of adding up.
-template <int NBLK, int CBLK, int NTAPS, int NW, bool PC = false, bool ROWK = false>
+// XF (round 3): source 0 is the RAW output z of the producing layer; its InstanceNorm + LeakyReLU (sc0 / sh0 = the scale and
+// shift planes [N][C0], slope0) is applied to the staged source image IN PLACE in LDS, once per staged element, between the
+// barrier that publishes the tile and a second one that hands it to the k-loop.  The image's scale / shift rows arrive by one
+// more LDS-DMA instruction per tile (1-KiB table beside each image); out-of-image halo pixels stay zero.  One image per tile.
+template <int NBLK, int CBLK, int NTAPS, int NW, bool PC = false, bool ROWK = false, bool XF = false>
 __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs p) {
     constexpr int TN = 32 * NBLK, TC = 32 * CBLK;
     constexpr int NWC = PC ? NW / 2 : NW;              // waves that compute
@@ -384,9 +389,10 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     constexpr int NWB = NBLK * CBLK, KSPLIT = NWC / NWB;
     constexpr int NTHR = 64 * NWI, BLK_B = NTHR * 16;  // issuing threads; bytes of one staging round
     constexpr int ROW_B = 64;                          // one pixel of one 32-channel plane
-    __shared__ __attribute__((aligned(16))) unsigned char img2[2 * DMA_IMG_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char img2[2 * DMA_IMG_BYTES + (XF ? 3072 : 0)];
     unsigned char* imgA = img2;
     unsigned char* imgB = img2 + DMA_IMG_BYTES;
+    unsigned char* xtab = img2 + 2 * DMA_IMG_BYTES;     // XF: table of image A, table of image B, dump kilobyte
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool producer = PC && wave >= NWC, issuer = !PC || producer;
     const int tid = PC ? (threadIdx.x & (NTHR - 1)) : threadIdx.x;      // index among the issuing threads
@@ -415,6 +421,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     const i32x4 rs0 = make_rsrc(p.src0, p.src0_bytes);
     const i32x4 rs1 = make_rsrc(p.src1 ? p.src1 : p.src0, p.src1 ? p.src1_bytes : 0u);
     const i32x4 rz = make_rsrc(p.z, p.z_bytes);
+    const i32x4 rx = make_rsrc(XF ? (const void*)p.sc0 : p.src0, XF ? p.xstat_bytes : 0u);
     constexpr unsigned OOB = 0x7ffffff0u;
 
     f32x16 acc[NTAPS];
@@ -424,6 +431,14 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
     const int slot = tid & 3;       // NTHR % 4 == 0: a thread always stages the same 16-byte piece of a pixel
+    // XF: scale / shift rows of image g_img0 (channels [c_base, c_base + TC)) -> the table of image `which` (0 = A, 1 = B).
+    // One wave-instruction: lanes [0, TC/4) fetch 16-byte pieces of the scales, lanes [TC/4, TC/2) of the shifts.
+    auto issue_table = [&](int img0, int which) {
+        const bool sh = lane >= TC / 4;
+        const int c = c_base + 4 * (lane - (sh ? TC / 4 : 0));
+        const unsigned off = (lane < TC / 2 && c < p.C0) ? (unsigned)(((sh ? p.N : 0) + img0) * p.C0 + c) * 4u : OOB;
+        dma16(rx, off, lds_addr(xtab) + which * 1024);
+    };
 
     // staging of one tile = s_iters + z_iters wave-level DMA instructions per wave, issued back to back right after the
     // barrier (measured: spreading them over the k-steps stalls the MFMA pipeline far more than it hides, 157 -> 191 us)
@@ -506,14 +521,46 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
 
     // one tile: wait for its image, start the DMA of the next tile into the other image, run the k-loop
     long long t_wait = 0, t_bar = 0, t_issue = 0, t_loop = 0;     // CU_CONV_DBG bit 16: phase stamps of one workgroup
-    auto run_tile = [&](int tile, const unsigned char* cur, unsigned char* other) {
+    auto run_tile = [&](int tile, unsigned char* cur, unsigned char* other) {
         const long long c0 = CU_DBG(p, 16) ? wall_clock64() : 0;
         dma_wait();           // this wave's share of the tile has landed ...
         const long long c1 = CU_DBG(p, 16) ? wall_clock64() : 0;
         __syncthreads();      // ... everybody's has, and the other image is no longer being read
+        if constexpr (XF) {   // normalise + activate the source image in place (g_* still describe THIS tile)
+            const float* tab = reinterpret_cast<const float*>(xtab + (cur == imgA ? 0 : 1024));      // scale[TC], shift[TC]
+            const int n_pieces = p.s_halo * 4 * CBLK;
+            for (int i = threadIdx.x; i < n_pieces; i += 64 * NW) {
+                const int pl = (CBLK == 2 && i >= p.s_halo * 4) ? 1 : 0;
+                const int rem = i - pl * p.s_halo * 4;
+                const int hp = rem >> 2, cc = pl * 32 + (rem & 3) * 8;
+                const int hy = __umulhi((unsigned)hp, p.mg_shw), hx = hp - hy * p.SHW;
+                const int sy = g_sy0 + hy, sx = g_sx0 + hx;
+                if (sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW && c_base + cc < p.C0) {
+                    u32x4* pp = reinterpret_cast<u32x4*>(cur + (size_t)i * 16);
+                    u32x4 v = *pp;
+                    const f32x4 sa = *reinterpret_cast<const f32x4*>(tab + cc), sb = *reinterpret_cast<const f32x4*>(tab + cc + 4);
+                    const f32x4 ha = *reinterpret_cast<const f32x4*>(tab + TC + cc), hb = *reinterpret_cast<const f32x4*>(tab + TC + cc + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float z0 = __uint_as_float(v[e] << 16), z1 = __uint_as_float(v[e] & 0xffff0000u);
+                        const float s0 = e < 2 ? sa[2 * e] : sb[2 * e - 4], s1 = e < 2 ? sa[2 * e + 1] : sb[2 * e - 3];
+                        const float h0 = e < 2 ? ha[2 * e] : hb[2 * e - 4], h1 = e < 2 ? ha[2 * e + 1] : hb[2 * e - 3];
+                        float a0 = z0 * s0 + h0, a1 = z1 * s1 + h1;
+                        a0 = a0 > 0.f ? a0 : a0 * p.slope0;
+                        a1 = a1 > 0.f ? a1 : a1 * p.slope0;
+                        v[e] = (unsigned)f32_to_bf16(a0) | ((unsigned)f32_to_bf16(a1) << 16);
+                    }
+                    *pp = v;
+                }
+            }
+            __syncthreads();
+        }
         const long long c2 = CU_DBG(p, 16) ? wall_clock64() : 0;
         const bool more = tile + p.splits < p.ntiles && !CU_DBG(p, 8);
         if (more) tile_geo(tile + p.splits);
+        if constexpr (XF) {
+            if (more && wave == (PC ? NWC : 0)) issue_table(g_img0, other == imgA ? 0 : 1);
+        }
         if (more && issuer) {
             // all DMA instructions now: spreading them over the k-steps was slower with one wave per SIMD (it stalls
             // the software pipeline, 157 -> 191 us) and with two (157 -> 181 us).  PC: the producers take the first
@@ -616,6 +663,9 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     const long long k0 = CU_DBG(p, 16) ? wall_clock64() : 0;
     if (tile < p.ntiles) {
         tile_geo(tile);
+        if constexpr (XF) {
+            if (wave == 0) issue_table(g_img0, 0);
+        }
         if constexpr (PC) {       // first image: both wave groups issue half of the rounds
             const int half = n_items / 2;
             for (int j = producer ? 0 : half; j < (producer ? half : n_items); ++j) issue_item(j, imgA);
@@ -691,10 +741,10 @@ static int parts_setup(WgKArgs& a, int nblk, int cblk, int ntn, int kparts) {
     return 0;
 }
 
-template <int NBLK, int CBLK, int NTAPS, int NW, bool PC = false, bool ROWK = false>
+template <int NBLK, int CBLK, int NTAPS, int NW, bool PC = false, bool ROWK = false, bool XF = false>
 int launch_dma(WgKArgs& a, hipStream_t st) {
     CU_CHECK_ARG((size_t)(a.s_iters + a.z_iters) * 1024 * (PC ? NW / 2 : NW) <= (size_t)DMA_IMG_BYTES, "cu_conv_wgrad: tile image exceeds %d bytes", DMA_IMG_BYTES);
-    auto k = igemm_wgrad_dma_kernel<NBLK, CBLK, NTAPS, NW, PC, ROWK>;
+    auto k = igemm_wgrad_dma_kernel<NBLK, CBLK, NTAPS, NW, PC, ROWK, XF>;
     const int CI = a.C0 + a.C1;
     a.ctiles = cdiv(CI, 32 * CBLK);
     const int ntn = cdiv(a.CO, 32 * NBLK);
@@ -846,13 +896,19 @@ static int wgrad_impl(const cu_wgrad_desc* d, const void* src0, const float* sca
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool plain = !scale0 && d->slope0 == 1.0f && (d->C1 == 0 || (!scale1 && d->slope1 == 1.0f));
     CU_CHECK_ARG(d->ntaps == 9 || d->ntaps == 4 || d->ntaps == 1, "cu_conv_wgrad: ntaps must be 9, 4 or 1 (got %d)", d->ntaps);
-    CU_CHECK_ARG(plain || d->ntaps == 9, "cu_conv_wgrad: fused-activation sources are only built for 3x3 taps");
+    // raw source 0 (scale0 / shift0 = the statistics planes of the producing layer) normalised + activated in LDS by the
+    // LDS-DMA kernel's XF instances: one source, stride 1, the planes adjacent, bf16, large maps (one image per tile)
+    const bool xf_ok = d->dtype == CU_BF16 && scale0 && shift0 == scale0 + (size_t)d->N * d->C0 && d->C1 == 0 && d->IS == 1 &&
+                       d->ZS == 1 && (d->ntaps == 9 || d->ntaps == 1) && (long)d->PH * d->PW >= 256 && d->PW >= 16 &&
+                       ((d->C0 == 32 && d->CO == 32) || (d->C0 == 64 && d->CO == 64 && d->ntaps == 9)) &&
+                       !cu_env_set("CU_WGRAD_NOXF");
+    CU_CHECK_ARG(plain || xf_ok || d->ntaps == 9, "cu_conv_wgrad: fused-activation sources are only built for 3x3 taps");
 
     // ---- bf16 production path: LDS-DMA staging, two LDS images (see igemm_wgrad_dma_kernel)
     const size_t b0 = (size_t)d->N * d->SH * d->SW * d->C0 * 2, b1 = (size_t)d->N * d->SH * d->SW * d->C1 * 2;
     const size_t bz = (size_t)d->N * d->ZH * d->ZW * d->ZC * 2;
     const size_t lim = 0x7fff0000ull;
-    if (d->dtype == CU_BF16 && plain && b0 < lim && b1 < lim && bz < lim && !cu_env_set("CU_WGRAD_NODMA")) {
+    if (d->dtype == CU_BF16 && (plain || xf_ok) && b0 < lim && b1 < lim && bz < lim && !cu_env_set("CU_WGRAD_NODMA")) {
         const int spp = wc ? 8 : 4, zpp = wn ? 8 : 4;
         int dma_nw = cu_env_int("CU_WGRAD_NW", 8);
         CU_CHECK_ARG(dma_nw == 4 || dma_nw == 8, "CU_WGRAD_NW must be 4 or 8");
@@ -903,6 +959,7 @@ static int wgrad_impl(const cu_wgrad_desc* d, const void* src0, const float* sca
         }
         CU_CHECK_ARG(d->ntaps == 4 || a.zsame, "cu_conv_wgrad: per-tap Z shifts are only built for 4 taps");
         a.src0_bytes = (unsigned)b0; a.src1_bytes = (unsigned)b1; a.z_bytes = (unsigned)bz;
+        a.xstat_bytes = (unsigned)((size_t)2 * d->N * d->C0 * 4);
         {
             static const int pcf = cu_env_int("CU_WGRAD_PCF", 70);      // percent of the rounds (measured optimum 65-75)
             const int n = a.s_iters + a.z_iters;
@@ -937,6 +994,15 @@ static int wgrad_impl(const cu_wgrad_desc* d, const void* src0, const float* sca
             }
             if (a.twl >= 4) return launch_dma<4, 2, 9, 8, false, true>(a, st);
             return launch_dma<4, 2, 9, 8, false, false>(a, st);
+        }
+        if (!plain) {       // XF instances (xf_ok): 32 -> 32 and 64 -> 64 channels, one image per tile
+            CU_CHECK_ARG(a.iml == 0 && a.twl >= 4, "cu_conv_wgrad: the normalise-on-load source needs one image per tile");
+            if (d->ntaps == 9) {
+                CU_CHECK_ARG(pc, "cu_conv_wgrad: normalise-on-load is built for the producer / consumer form");
+                if (wn && wc) return launch_dma<2, 2, 9, 8, true, true, true>(a, st);
+                return launch_dma<1, 1, 9, 8, true, true, true>(a, st);
+            }
+            return launch_dma<1, 1, 1, 4, false, false, true>(a, st);
         }
         if (wn && wc) CU_WD(2, 2);
         if (wn) CU_WD(2, 1);

@@ -1150,7 +1150,7 @@ static void launch_bwd_resident(int N, int HW, int C, const RowMap& rm, int nch,
 extern "C" int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* z, const float* gamma, const float* beta,
                                      float eps, float slope, float* stats, void* out, float* ws, int mode, void* stream) {
     NORM_COMMON_CHECKS("cu_instnorm_fwd_fused");
-    CU_CHECK_ARG(z && stats && out && ws, "cu_instnorm_fwd_fused: null pointer");
+    CU_CHECK_ARG(z && stats && ws, "cu_instnorm_fwd_fused: null pointer");      // out == NULL: statistics only (two-pass form)
     const bool clean = (mode & CU_NORM_WS_CLEAN) != 0;       // the caller hands over a zeroed workspace: no memset launch
     const bool det = (mode & CU_NORM_DETERMINISTIC) != 0;    // two-pass kernels, one workgroup per image: fixed summation order
     mode &= ~(CU_NORM_WS_CLEAN | CU_NORM_DETERMINISTIC);
@@ -1158,8 +1158,9 @@ extern "C" int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void
     if (det) mode = 2;
     const int np = rc_pick_np(HW, rm.rows);
     const int nch = cdiv(HW, rm.rows * np);
-    if (mode == 0) mode = (HW <= 256 && nch <= RC_MAX_CHUNKS) ? 1 : 2;      // measured crossover (see the kernels' header)
+    if (mode == 0) mode = (HW <= 256 && nch <= RC_MAX_CHUNKS && out) ? 1 : 2;      // measured crossover (see the kernels' header)
     if (mode == 1) {
+        CU_CHECK_ARG(out != nullptr, "cu_instnorm_fwd_fused: the resident kernel always writes the activated tensor");
         CU_CHECK_ARG(nch <= RC_MAX_CHUNKS, "cu_instnorm_fwd_fused: %d chunks per image exceed %d", nch, RC_MAX_CHUNKS);
         if (!clean) {
             hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * ((size_t)RC_HDR + (size_t)N * rc_block_words(C)), st);
@@ -1180,6 +1181,7 @@ extern "C" int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void
         int rc = dtype == CU_BF16 ? launch_stats<bf16_t>(ni, N, HW, C, zp, gamma, beta, eps, sp, ws + (size_t)n0 * C * 2, st, clean, det)
                                   : launch_stats<float>(ni, N, HW, C, zp, gamma, beta, eps, sp, ws + (size_t)n0 * C * 2, st, clean, det);
         if (rc) return rc;
+        if (!out) continue;       // the consumers normalise + activate on load (cu_conv_gemm / cu_conv_wgrad with scale / shift)
         rc = dtype == CU_BF16 ? launch_apply<bf16_t>(ni, N, HW, C, zp, sp, slope, op, st)
                               : launch_apply<float>(ni, N, HW, C, zp, sp, slope, op, st);
         if (rc) return rc;
@@ -1191,9 +1193,13 @@ extern "C" int cu_instnorm_fwd_given(int dtype, int N, int HW, int C, const void
                                      float eps, float slope, const float* sums, const float* shift, float* stats, void* out,
                                      void* stream) {
     NORM_COMMON_CHECKS("cu_instnorm_fwd_given");
-    CU_CHECK_ARG(z && stats && out && sums, "cu_instnorm_fwd_given: null pointer");
+    CU_CHECK_ARG(z && stats && sums, "cu_instnorm_fwd_given: null pointer");      // out == NULL: statistics only
     hipLaunchKernelGGL(stats_finalize_given_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, st, sums, shift, gamma, beta, eps,
                        stats, N, HW, C);
+    if (!out) {
+        CU_LAUNCH_CHECK();
+        return 0;
+    }
     return dtype == CU_BF16 ? launch_apply<bf16_t>(N, N, HW, C, z, stats, slope, out, st)
                             : launch_apply<float>(N, N, HW, C, z, stats, slope, out, st);
 }

@@ -34,6 +34,12 @@ struct TcArgs {
     int run;                        // MODE 1, 2: consecutive tiles per workgroup (all of one image)
     const void* nz; const float* nstats; float nslope;      // MODE 2: raw output z, statistics planes, LeakyReLU slope of
                                                             // the layer whose output gradient this launch produces
+    // XF (round 3): the source is the RAW output z of the producing layer and its InstanceNorm +
+    // LeakyReLU (a = LeakyReLU(scale z + shift), reference layers.py:193-194) is applied to every halo tile IN PLACE in
+    // LDS, once per staged element, before the MFMAs read it -- the materialised activation and its apply pass are gone.
+    const float* xscale;            // [N][C0] f32; the shifts follow N * C0 floats later (planes 2 and 3 of cu_instnorm_stats)
+    unsigned xstat_bytes;           // bytes of the two planes
+    float xslope;
 };
 
 __device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
@@ -49,8 +55,13 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // pass of that layer's InstanceNorm backward happens here -- the lane reads its pixel's z (8-byte loads issued by hand
 // right after the barrier, so that they are OLDER than this iteration's LDS-DMA and waiting for them does not wait for
 // the prefetch), forms gl = g * LeakyReLU'(y) and keeps running sums of gl and gl * zhat; same flush as MODE 1.
-template <int CIP, int NB, int TH, int R, int MODE>
-__global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
+// XF: normalise + activate the staged source in LDS (see TcArgs).  One more LDS-DMA instruction per wave and tile brings the
+// image's scale / shift rows into a 1-KiB table beside the ring slot (waves 1..7 issue theirs out of range into a shared dump
+// kilobyte, so every wave's counted waits stay equal); after the barrier that publishes the tile every thread rewrites the
+// pieces it staged itself -- skipping out-of-image halo pixels, which must stay zero (the zero padding of the conv) -- and a
+// second barrier hands the tile to the MFMAs.  Rounding: bf16(LeakyReLU(z * scale + shift)), the apply pass's own arithmetic.
+template <int CIP, int NB, int TH, int R, int MODE, bool XF = false>
+__global__ __launch_bounds__(512, (XF && CIP == 1 && NB == 1 && R == 2) ? 4 : 1) void tconv_kernel(const TcArgs p) {
     constexpr bool STATS = MODE != 0;
     constexpr int CI = 32 * CIP, CO = 32 * NB;
     constexpr int HW34 = 34, HALO = (TH + 2) * HW34, HPAD = (HALO + 15) / 16 * 16;     // plane stride: whole DMA instructions
@@ -60,13 +71,17 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
     constexpr int NBW = NB * TH / 8;            // 32-column blocks per wave
     constexpr int S = 2 * NBW;                  // 16-byte stores per thread and tile
     constexpr int ZL = MODE == 2 ? 4 * NBW : 0; // hand-issued 8-byte loads of z per thread and tile
-    static_assert(NBW >= 1 && W_B + R * SLOT_B + 1024 <= 160 * 1024, "tconv: bad instance");
+    constexpr int XT = XF ? 1 : 0;              // table DMA instructions per wave and tile
+    constexpr int TAB0 = W_B + R * SLOT_B + 1024;        // XF: R tables of 1 KiB, then the dump kilobyte
+    static_assert(NBW >= 1 && W_B + R * SLOT_B + 1024 + (XF ? (R + 1) * 1024 : 0) <= 160 * 1024, "tconv: bad instance");
+    static_assert(!XF || (MODE != 2 && CI <= 128), "tconv: XF serves the forward instances");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const unsigned w_base = lds_addr(smem), x_base = w_base + W_B;
     const i32x4 rs0 = make_rsrc(p.src0, p.src0_bytes);
     const i32x4 rs1 = make_rsrc(p.src1 ? p.src1 : p.src0, p.src1 ? p.src1_bytes : 0u);
     const i32x4 rw = make_rsrc(p.w, p.w_bytes);
+    const i32x4 rx = make_rsrc(XF ? (const void*)p.xscale : p.src0, XF ? p.xstat_bytes : 0u);
     constexpr unsigned OOB = 0x7ffffff0u;
 
     // ---- weights, once: LDS row (t * CO + n) of plane pl = channels [32 pl, 32 pl + 32) of weight row (tap_w[t], n);
@@ -126,6 +141,12 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
             if (s1) dma16(rs1, off, dst);
             else dma16(rs0, off, dst);
         }
+        if constexpr (XF) {        // lanes [0, CI/4): 16-byte pieces of scale[n][:], lanes [CI/4, CI/2): of shift[n][:]
+            const bool sh = lane >= CI / 4;
+            const unsigned off = (live && wave == 0 && lane < CI / 2)
+                ? (unsigned)(((sh ? p.N : 0) + n) * CI + 4 * (lane - (sh ? CI / 4 : 0))) * 4u : OOB;
+            dma16(rx, off, w_base + (unsigned)(TAB0 + (wave == 0 ? slot : R) * 1024));
+        }
     };
 
     // ---- this wave's output: row `row` of the tile, column blocks b0 .. b0 + NBW - 1
@@ -163,9 +184,9 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
         // DMA(it) must have landed; younger operations, in issue order: [R == 3: stores(it-2), DMA(it+1)], stores(it-1)
         // (MODE 2 adds ZL hand-issued loads per iteration, issued BEFORE that iteration's DMA)
         if (R == 3) {
-            if (it == 0) wait_vm<D>();
-            else if (it == 1) wait_vm<ZL + D + S>();
-            else wait_vm<ZL + D + 2 * S>();
+            if (it == 0) wait_vm<D + XT>();
+            else if (it == 1) wait_vm<ZL + D + XT + S>();
+            else wait_vm<ZL + D + XT + 2 * S>();
         } else {
             if (it == 0) wait_vm<0>();
             else wait_vm<S>();
@@ -186,6 +207,33 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
         }
         issue(l + (R - 1) * l_step, (it + R - 1) % R);
         const bf16_t* X16 = reinterpret_cast<const bf16_t*>(smem + W_B + (it % R) * SLOT_B);
+        if constexpr (XF) {
+            const float* tab = reinterpret_cast<const float*>(smem + TAB0 + (it % R) * 1024);     // scale[CI], shift[CI]
+            const int y0 = ty * TH - 1, x0 = tx * 32 - 1;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const int sy = y0 + hy[j], sx = x0 + hx[j];
+                if (coff[j] != 0xffffffffu && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) {
+                    const int c0 = (int)(coff[j] >> 1) + (cat ? 0 : 0);      // first channel of the piece (single source)
+                    u32x4* pp = reinterpret_cast<u32x4*>(smem + W_B + (it % R) * SLOT_B + j * 8192 + tid * 16);
+                    u32x4 v = *pp;
+                    const f32x4 sa = *reinterpret_cast<const f32x4*>(tab + c0), sb = *reinterpret_cast<const f32x4*>(tab + c0 + 4);
+                    const f32x4 ha = *reinterpret_cast<const f32x4*>(tab + CI + c0), hb = *reinterpret_cast<const f32x4*>(tab + CI + c0 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float z0 = __uint_as_float(v[e] << 16), z1 = __uint_as_float(v[e] & 0xffff0000u);
+                        const float sc0 = e < 2 ? sa[2 * e] : sb[2 * e - 4], sc1 = e < 2 ? sa[2 * e + 1] : sb[2 * e - 3];
+                        const float sh0 = e < 2 ? ha[2 * e] : hb[2 * e - 4], sh1 = e < 2 ? ha[2 * e + 1] : hb[2 * e - 3];
+                        float a0 = z0 * sc0 + sh0, a1 = z1 * sc1 + sh1;
+                        a0 = a0 > 0.f ? a0 : a0 * p.xslope;
+                        a1 = a1 > 0.f ? a1 : a1 * p.xslope;
+                        v[e] = (unsigned)f32_to_bf16(a0) | ((unsigned)f32_to_bf16(a1) << 16);
+                    }
+                    *pp = v;
+                }
+            }
+            __syncthreads();      // the rewritten tile is complete for every wave
+        }
 
         f32x16 acc[NBW];
 #pragma unroll
@@ -291,11 +339,13 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
     }
 }
 
-template <int CIP, int NB, int TH, int R>
+template <int CIP, int NB, int TH, int R, bool XFI = false>
 int launch_tc(TcArgs& a, hipStream_t st) {
     constexpr int HPAD = ((TH + 2) * 34 + 15) / 16 * 16;
     constexpr int D = (CIP * HPAD * 4 + 511) / 512, WD = (CIP * 9 * 32 * NB * 4 + 511) / 512;
-    const size_t lds = (size_t)WD * 8192 + (size_t)R * D * 8192 + 1024;      // + the MODE 2 parameter table
+    const bool xf = XFI && a.xscale != nullptr;
+    const size_t lds = (size_t)WD * 8192 + (size_t)R * D * 8192 + 1024 +     // + the MODE 2 parameter table
+                       (xf ? (size_t)(R + 1) * 1024 : 0);                    // + XF: scale / shift tables and the dump
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;       // workgroups that fit a CU (LDS; <= 128 VGPRs in every instance)
     int grid = a.ntiles < 256 * per_cu ? a.ntiles : 256 * per_cu;
     // statistics: every workgroup needs a run of consecutive tiles inside ONE image
@@ -304,6 +354,12 @@ int launch_tc(TcArgs& a, hipStream_t st) {
     if (!stats) a.stat_sums = nullptr;
     a.run = stats ? a.ntiles / grid : 0;
     auto k = !stats ? tconv_kernel<CIP, NB, TH, R, 0> : (a.nz ? tconv_kernel<CIP, NB, TH, R, 2> : tconv_kernel<CIP, NB, TH, R, 1>);
+    if constexpr (XFI) {
+        if (xf) {
+            CU_CHECK_ARG(!a.nz, "cu_conv_gemm: the normalise-on-load source is a forward form");
+            k = stats ? tconv_kernel<CIP, NB, TH, R, 1, true> : tconv_kernel<CIP, NB, TH, R, 0, true>;
+        }
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     CU_CHECK_ARG(e == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
@@ -315,11 +371,15 @@ int launch_tc(TcArgs& a, hipStream_t st) {
 
 // 2 = launched and the sums were gathered, 1 = launched, 0 = not this kernel's shape, < 0 = error.  Called by cu_conv_gemm
 // for plain bf16 operands.  ep (or NULL): the epilogue extension of cu_conv_gemm_ex.
+// scale0 / shift0 (or NULL): source 0 is a RAW conv output whose InstanceNorm + LeakyReLU (slope0) this launch applies in
+// LDS (XF); served for one source, with the shift plane N * C0 floats behind the scale plane (cu_instnorm_stats' layout).
 int cu_tconv_try(const cu_conv_desc* d, const void* src0, const void* src1, const void* w, const float* bias, void* dst0,
-                 void* dst1, const cu_conv_epilogue* ep, void* stream) {
+                 void* dst1, const cu_conv_epilogue* ep, const float* scale0, const float* shift0, void* stream) {
+    const bool xf = scale0 != nullptr;
     if (d->dtype != CU_BF16 || d->ntaps != 9 || d->IS != 1 || d->OS != 1 || d->OY0 || d->OX0 || d->out_nchw_f32 ||
-        d->par_co || d->accum0 || d->accum1 || d->slope0 != 1.0f || (d->C1 && d->slope1 != 1.0f))
+        d->par_co || d->accum0 || d->accum1 || (!xf && d->slope0 != 1.0f) || (d->C1 && d->slope1 != 1.0f))
         return 0;
+    if (xf && (d->C1 || shift0 != scale0 + (size_t)d->N * d->C0 || (ep && ep->mode == 2))) return 0;
     if (d->PH != d->SH || d->PW != d->SW || d->OH != d->PH || d->OW != d->PW || d->PW % 32 || d->PH % 8) return 0;
     const int CI = d->C0 + d->C1;
     if (!((CI == 32 && d->C1 == 0) || (CI == 64 && (d->C1 == 0 || d->C0 == 32)))) return 0;
@@ -336,6 +396,10 @@ int cu_tconv_try(const cu_conv_desc* d, const void* src0, const void* src1, cons
     a.src0_bytes = (unsigned)b0; a.src1_bytes = (unsigned)b1; a.w_bytes = (unsigned)((size_t)9 * d->CO * CI * 2);
     a.N = d->N; a.H = d->PH; a.W = d->PW; a.C0 = d->C0; a.C1 = d->C1;
     a.D0 = d->D0; a.DC0 = d->DC0; a.DC1 = d->DC1;
+    if (xf) {
+        if (two || !((CI == 32 && d->CO == 32) || (CI == 64 && d->CO == 64))) return 0;      // instances built with XF
+        a.xscale = scale0; a.xstat_bytes = (unsigned)((size_t)2 * d->N * d->C0 * 4); a.xslope = d->slope0;
+    }
     if (ep && !two && ep->sums && (ep->mode == 1 || (ep->mode == 2 && ep->z && ep->stats && !bias))) {
         a.stat_sums = ep->sums;
         if (ep->mode == 2) { a.nz = ep->z; a.nstats = ep->stats; a.nslope = ep->slope; }
@@ -354,8 +418,8 @@ int cu_tconv_try(const cu_conv_desc* d, const void* src0, const void* src1, cons
     // two-destination input gradient the 4-row tile that would fit two workgroups loses to 8 rows x 3 slots (248 vs 237)
     const int var = cu_env_int("CU_TCONV_VAR", 1);      // tuning knob: 0 = three slots, one workgroup per CU
     // (the norm-backward epilogue needs 146 registers: one workgroup per CU either way, so it takes the three-slot ring)
-    if (CI == 32 && d->CO == 32) return (var == 1 && !a.nz) ? launch_tc<1, 1, 8, 2>(a, st) : launch_tc<1, 1, 8, 3>(a, st);
+    if (CI == 32 && d->CO == 32) return (var == 1 && !a.nz) ? launch_tc<1, 1, 8, 2, true>(a, st) : launch_tc<1, 1, 8, 3>(a, st);
     if (CI == 32 && d->CO == 64) return launch_tc<1, 2, 8, 3>(a, st);
     if (CI == 64 && d->CO == 32) return launch_tc<2, 1, 8, 2>(a, st);
-    return launch_tc<2, 2, 4, 2>(a, st);
+    return launch_tc<2, 2, 4, 2, true>(a, st);
 }

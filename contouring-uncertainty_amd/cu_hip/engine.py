@@ -124,6 +124,8 @@ class UNetEngine:
         # True: one streaming pass materialises LeakyReLU(InstanceNorm(z)) per layer and every consumer stages a plain
         # operand; False: consumers recompute it in their operand load (less HBM traffic, but VALU-bound thin layers)
         self.materialize = True
+        # True: the thin, large layers keep only their raw output + statistics; consumers normalise on load (see _lazy)
+        self.lazy_act = os.environ.get("CONTOUR_LAZY_ACT", "1") != "0"
         # True: InstanceNorm + LeakyReLU forward (statistics + materialise) and backward (reduce + apply) each run as ONE
         # resident-chunk launch that reads every tensor once (norm.hip); False: the two-pass kernels
         self.fused_norm = True
@@ -206,6 +208,8 @@ class UNetEngine:
         n, sh, sw, _ = srcs[0].z.shape
         oh, ow = sh // stride, sw // stride
         co = w.shape[0]
+        if not (stride == 1 and len(srcs) == 1 and self._raw_ok(srcs[0], w.shape[1], co)):
+            srcs = [ops.materialized(s_) for s_ in srcs]       # kernels without the normalise-on-load path
         z = torch.empty((n, oh, ow, co), dtype=self.dtype, device=w.device)
         # thin, large layers: the streaming kernel gathers the InstanceNorm statistics in its epilogue (no statistics pass)
         sums = None
@@ -217,7 +221,7 @@ class UNetEngine:
                             dst_cols=[co], stat_sums=sums)
         if got:
             out = ops.instnorm_fwd_given(z, P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"], self.slope, sums,
-                                         P[f"{prefix}.conv.bias"], self.eps)
+                                         P[f"{prefix}.conv.bias"], self.eps, materialize=not self._lazy(ctx, z))
             if not ctx.keep and out.a is not None:
                 return Act(out.a, None, 1.0)
             ctx.convs[prefix] = _ConvRec(prefix, srcs, out, stride, drop_mask=None)
@@ -231,18 +235,34 @@ class UNetEngine:
                 keep = torch.rand((n, co), device=z.device) >= self.drop_p
                 mask = keep.float() / (1.0 - self.drop_p)
             ops.channel_scale(z, mask)
-        out = self._norm_act_fwd(P, prefix, z)
+        out = self._norm_act_fwd(P, prefix, z, ctx)
         if not ctx.keep and out.a is not None:
             return Act(out.a, None, 1.0)      # inference: z, the statistics and the layer record die here
         ctx.convs[prefix] = _ConvRec(prefix, srcs, out, stride, drop_mask=mask)
         self._producer[id(out)] = prefix
         return out
 
-    def _norm_act_fwd(self, P, prefix: str, z: Tensor) -> Act:
+    def _lazy(self, ctx: "UNetCtx", z: Tensor) -> bool:
+        """True: do NOT materialise LeakyReLU(InstanceNorm(z)) of this layer at production.  The thin,
+        large layers (256^2 x 32, 128^2 x 64 channels) are HBM-bound, and the consumers that dominate there -- the streaming
+        3x3 kernel, the weight-gradient kernel, the 1x1 head -- normalise + activate the raw tensor in LDS while staging it;
+        any other consumer materialises it on first need (``ops.materialized``), so this is a pure speed decision."""
+        n, h, w_, c = z.shape
+        return (self.lazy_act and ctx.keep and self.debug is None and self.dtype == torch.bfloat16 and self.fused_norm and
+                self.materialize and not self.deterministic and c in (32, 64) and n * h * w_ >= (1 << 20))
+
+    def _raw_ok(self, src: Act, ci: int, co: int) -> bool:
+        """the 3x3 stride-1 kernels (forward + weight gradient) take this source raw"""
+        n, h, w_, _ = src.z.shape
+        return src.a is None and src.stats is not None and (ci, co) in ((32, 32), (64, 64)) and n * h * w_ >= (1 << 20) \
+            and h % 8 == 0 and w_ % 32 == 0
+
+    def _norm_act_fwd(self, P, prefix: str, z: Tensor, ctx: Optional["UNetCtx"] = None) -> Act:
         gamma, beta = P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"]
         if self.fused_norm and self.materialize:
             ws = self._arena["fwd"].take(ops.resident_ws_floats(z.shape[0], z.shape[3]), z.device)
-            return ops.instnorm_fwd_fused(z, gamma, beta, self.slope, self.eps, ws=ws, mode=self._norm_mode())
+            return ops.instnorm_fwd_fused(z, gamma, beta, self.slope, self.eps, ws=ws, mode=self._norm_mode(),
+                                          materialize=not (ctx is not None and self._lazy(ctx, z)))
         out = Act(z, ops.instnorm_stats(z, gamma, beta, self.eps), self.slope)
         if self.materialize:
             ops.instnorm_apply(out)
@@ -260,7 +280,7 @@ class UNetEngine:
         n, _, h, w_ = img.shape
         z = torch.empty((n, h, w_, co), dtype=self.dtype, device=img.device)
         ops.conv_c1_fwd(img, w9, P[f"{prefix}.conv.bias"], z)
-        out = self._norm_act_fwd(P, prefix, z)
+        out = self._norm_act_fwd(P, prefix, z, ctx)
         if not ctx.keep and out.a is not None:
             return Act(out.a, None, 1.0)
         ctx.convs[prefix] = _ConvRec(prefix, [], out, 1, first=True)
@@ -273,6 +293,7 @@ class UNetEngine:
 
     def _convT_fwd(self, P, ctx: UNetCtx, prefix: str, src: Act) -> Act:
         w = P[f"{prefix}.weight"]                             # (CI, CO, 2, 2)
+        src = ops.materialized(src)
         wf, _ = self._operands(f"{prefix}.weight", w, "convT")
         n, h, w_, _ = src.z.shape
         co = w.shape[1]
@@ -455,6 +476,8 @@ class UNetEngine:
                 self._unprep(dw9.view(9, co, 1), G[f"{prefix}.conv.weight"], "conv", prefix)
             return
         ci = w.shape[1]
+        if not (rec.stride == 1 and len(rec.srcs) == 1 and self._raw_ok(rec.srcs[0], ci, co)):
+            rec.srcs = [ops.materialized(s_) for s_ in rec.srcs]
         with self._wgrad_stream(g, *[s_.z for s_ in rec.srcs]):
             self._wgrad(rec.srcs, g, (9, co, ci), G[f"{prefix}.conv.weight"], "conv", prefix, grid=(oh, ow),
                         in_stride=rec.stride, z_stride=1, taps=TAPS3_W, n_cols=co)

@@ -241,6 +241,14 @@ def instnorm_stats(z: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], e
     return stats
 
 
+def materialized(act: Act) -> Act:
+    """``act`` with its activated tensor present (runs the apply pass once, on first need: a consumer whose kernel cannot
+    normalise + activate the raw tensor while staging it)."""
+    if act.a is None and act.stats is not None:
+        instnorm_apply(act)
+    return act
+
+
 def instnorm_apply(act: Act) -> Tensor:
     """Materialise LeakyReLU(z*scale + shift) and attach it to the Act."""
     n, h, w_, c = act.z.shape
@@ -275,13 +283,13 @@ def resident_ws_floats(n: int, c: int) -> int:
 
 
 def instnorm_fwd_fused(z: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], slope: float, eps: float = 1e-5,
-                       ws: Optional[Tensor] = None, mode: int = 0) -> Act:
+                       ws: Optional[Tensor] = None, mode: int = 0, materialize: bool = True) -> Act:
     """statistics + LeakyReLU(z*scale + shift) in one call (cu_instnorm_fwd_fused; mode 0 auto, 1 resident-chunk
     kernel, 2 two-pass kernels on cache-sized image groups; + NORM_WS_CLEAN: ``ws`` is handed over zeroed)
     -> Act(z, stats, a)."""
     n, h, w_, c = z.shape
     stats = torch.empty((4, n, c), dtype=torch.float32, device=z.device)
-    out = torch.empty_like(z)
+    out = torch.empty_like(z) if materialize else None     # None: statistics only, the consumers normalise on load
     ws = _resident_ws(n, c, z.device) if ws is None else ws
     with _Prof("instnorm_fwd", 0.0, f"N{n} {h}x{w_} C{c}", 2 * z.numel() * z.element_size()):
         L.check(L.load().cu_instnorm_fwd_fused(L.dtype_code(z.dtype), n, h * w_, c, L.ptr(z), L.ptr(gamma), L.ptr(beta), eps,
@@ -291,12 +299,12 @@ def instnorm_fwd_fused(z: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor
 
 
 def instnorm_fwd_given(z: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], slope: float, sums: Tensor,
-                       shift: Optional[Tensor], eps: float = 1e-5) -> Act:
+                       shift: Optional[Tensor], eps: float = 1e-5, materialize: bool = True) -> Act:
     """statistics from sums the producing convolution gathered (``conv_gemm(stat_sums=...)``) + the apply pass
     (cu_instnorm_fwd_given) -> Act(z, stats, a)."""
     n, h, w_, c = z.shape
     stats = torch.empty((4, n, c), dtype=torch.float32, device=z.device)
-    out = torch.empty_like(z)
+    out = torch.empty_like(z) if materialize else None
     with _Prof("instnorm_fwd", 0.0, f"N{n} {h}x{w_} C{c}", 2 * z.numel() * z.element_size()):
         L.check(L.load().cu_instnorm_fwd_given(L.dtype_code(z.dtype), n, h * w_, c, L.ptr(z), L.ptr(gamma), L.ptr(beta), eps,
                                                slope, L.ptr(sums), L.ptr(shift), L.ptr(stats), L.ptr(out), L.stream_ptr()),

@@ -193,6 +193,8 @@ int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, const void* 
 /* + CU_NORM_DETERMINISTIC: two-pass kernels with one workgroup per image (fixed summation order, every sum has a single
  * adder) and, in the backward, dgamma / dbeta summed over the images by a finish pass: bit-identical results run to run. */
 #define CU_NORM_DETERMINISTIC 32
+/* out == NULL (cu_instnorm_fwd_fused with the two-pass kernels, cu_instnorm_fwd_given): statistics only -- the layer's
+ * consumers then normalise + activate while they stage the raw tensor (scale / shift of cu_conv_gemm / cu_conv_wgrad). */
 size_t cu_instnorm_resident_ws_floats(int N, int C);
 int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* z, const float* gamma, const float* beta,
                           float eps, float slope, float* stats, void* out, float* ws, int mode, void* stream);

@@ -754,3 +754,69 @@ def test_stride2_wgrad_parity_planes(case):
     gp = torch.zeros_like(w)
     ops.grad_unprep_parts(ws, slabs, co, gp, "conv", accumulate=True)
     assert rel_err(gp, w.grad) < 2e-3
+
+
+@pytest.mark.parametrize("case", [(16, 32, 256), (64, 64, 128)])
+def test_normalise_on_load_equals_the_materialised_operand(case):
+    """Round 3: the streaming 3x3 kernel and the weight-gradient kernel take the RAW conv output of the
+    producing layer and apply its InstanceNorm + LeakyReLU in LDS while staging it.  Same bf16 operand values, same MFMA
+    order: the results must equal the path through the materialised activation bit for bit (forward, forward with the
+    statistics epilogue, 3x3 weight gradient; 32 channels also the 1x1 head's forward and weight gradient)."""
+    ops = _ops()
+    from cu_hip.engine import TAPS3, TAPS3_W
+    n, c, size = case
+    dtype = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(31)
+    z = torch.randn(n, size, size, c, device=DEV, generator=g).to(dtype)
+    gamma = torch.rand(c, device=DEV, generator=g) + 0.5
+    beta = torch.randn(c, device=DEV, generator=g) * 0.3
+    raw = ops.instnorm_fwd_fused(z, gamma, beta, 0.01, materialize=False)
+    assert raw.a is None and raw.stats is not None
+    mat = ops.Act(raw.z, raw.stats, raw.slope)
+    ops.instnorm_apply(mat)
+    plain = ops.Act(mat.a, None, 1.0)
+    w = torch.randn(c, c, 3, 3, device=DEV, generator=g) / math.sqrt(9 * c)
+    b = torch.randn(c, device=DEV, generator=g) * 0.1
+    wf, _ = ops.weight_prep(w, "conv", dtype)
+    outs = []
+    for src in (raw, plain):
+        o = torch.empty(n, size, size, c, device=DEV, dtype=dtype)
+        sums = torch.zeros(n, c, 2, device=DEV)
+        got = ops.conv_gemm([src], wf, b, grid=(size, size), in_stride=1, taps=TAPS3, dsts=[o], dst_cols=[c], stat_sums=sums)
+        assert got
+        o2 = torch.empty_like(o)
+        ops.conv_gemm([src], wf, b, grid=(size, size), in_stride=1, taps=TAPS3, dsts=[o2], dst_cols=[c])
+        outs.append((o, sums, o2))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
+    assert rel_err(outs[0][1], outs[1][1]) < 1e-5           # f32 atomics: order noise only
+    ref = F.conv2d(nchw(mat.a), rq(w, dtype), b, padding=1)
+    assert rel_err(nchw(outs[0][0]), ref) < tol(dtype)
+    dz = torch.randn(n, size, size, c, device=DEV, generator=g).to(dtype)
+    grads = []
+    for src in (raw, plain):
+        ws = torch.full((24 << 20,), float("nan"), device=DEV)
+        slabs = ops.conv_wgrad([src], dz, ws, grid=(size, size), in_stride=1, z_stride=1, taps=TAPS3_W, n_cols=c, parts=True)
+        gw = torch.zeros_like(w)
+        ops.grad_unprep_parts(ws, slabs, c, gw, "conv", accumulate=True)
+        grads.append(gw)
+    assert torch.equal(grads[0], grads[1])
+    if c == 32:       # the 1x1 head: forward through the generic kernel's fused load, weight gradient through the XF instance
+        w1 = torch.randn(21, c, 1, 1, device=DEV, generator=g) / math.sqrt(c)
+        wf1, _ = ops.weight_prep(w1, "conv", dtype, cop=32)
+        lo = []
+        for src in (raw, plain):
+            logits = torch.empty(n, 21, size, size, device=DEV)
+            ops.conv_gemm([src], wf1, None, grid=(size, size), in_stride=1, taps=[(0, 0, 0)], dsts=[logits], dst_cols=[32],
+                          out_nchw=True, n_cols=32)
+            lo.append(logits)
+        assert rel_err(lo[0], lo[1]) < 1e-5
+        dl = torch.randn(n, size, size, 32, device=DEV, generator=g).to(dtype)
+        gs = []
+        for src in (raw, plain):
+            ws = torch.full((8 << 20,), float("nan"), device=DEV)
+            slabs = ops.conv_wgrad([src], dl, ws, grid=(size, size), in_stride=1, z_stride=1, taps=[(0, 0, 0, 0, 0)], n_cols=32,
+                                   parts=True)
+            gw = torch.zeros_like(w1)
+            ops.grad_unprep_parts(ws, slabs, 32, gw, "conv", accumulate=True)
+            gs.append(gw)
+        assert torch.equal(gs[0], gs[1])

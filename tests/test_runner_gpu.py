@@ -101,4 +101,8 @@ def test_frame_sharded_predict_equals_single_rank(golden_dir, tmp_path):
         for g, s in zip(got, single):
             assert np.allclose(g[1], s.mu, rtol=1e-4, atol=1e-3)
             assert np.allclose(g[2], s.contour_samples, atol=2e-2)
-            assert np.abs(g[3] - s.entropy_map).max() < 0.2 and (np.abs(g[3] - s.entropy_map) > 1e-3).mean() < 0.02
+            # the two runs' contours agree to 2e-2 px (InstanceNorm sums are f32 atomics: last-bit noise), so a sampled contour
+            # may round a boundary pixel of its mask differently: with 16 samples one flipped mask moves that pixel's entropy
+            # by up to H(1/16) = 0.34 and a few flips at one pixel by more -- bound HOW MANY pixels move, not the largest move
+            diff = np.abs(g[3] - s.entropy_map)
+            assert (diff > 1e-3).mean() < 0.02 and diff.mean() < 5e-3

@@ -421,7 +421,6 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     const i32x4 rs0 = make_rsrc(p.src0, p.src0_bytes);
     const i32x4 rs1 = make_rsrc(p.src1 ? p.src1 : p.src0, p.src1 ? p.src1_bytes : 0u);
     const i32x4 rz = make_rsrc(p.z, p.z_bytes);
-    const i32x4 rx = make_rsrc(XF ? (const void*)p.sc0 : p.src0, XF ? p.xstat_bytes : 0u);
     constexpr unsigned OOB = 0x7ffffff0u;
 
     f32x16 acc[NTAPS];
@@ -431,13 +430,23 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
     const int slot = tid & 3;       // NTHR % 4 == 0: a thread always stages the same 16-byte piece of a pixel
-    // XF: scale / shift rows of image g_img0 (channels [c_base, c_base + TC)) -> the table of image `which` (0 = A, 1 = B).
-    // One wave-instruction: lanes [0, TC/4) fetch 16-byte pieces of the scales, lanes [TC/4, TC/2) of the shifts.
-    auto issue_table = [&](int img0, int which) {
-        const bool sh = lane >= TC / 4;
-        const int c = c_base + 4 * (lane - (sh ? TC / 4 : 0));
-        const unsigned off = (lane < TC / 2 && c < p.C0) ? (unsigned)(((sh ? p.N : 0) + img0) * p.C0 + c) * 4u : OOB;
-        dma16(rx, off, lds_addr(xtab) + which * 1024);
+    // XF: table ring of 3 slots (512 B each: scale[TC], shift[TC] of a tile's image, channels [c_base, c_base + TC)).
+    // Wave 0 writes the table of logical tile L into slot (L / splits) % 3 two tiles ahead of its use, so the barrier at the
+    // top of the tile in between publishes it: no synchronisation of its own.
+    auto tile_img = [&](int ltile) {
+        const int bx = ((p.ntiles & 7) == 0 && !CU_DBG(p, 64)) ? (ltile & 7) * (p.ntiles >> 3) + (ltile >> 3) : ltile;
+        return (bx / (p.tiles_x * p.tiles_y)) << p.iml;
+    };
+    auto write_table = [&](int ltile) {
+        const int n = tile_img(ltile);
+        float* tab = reinterpret_cast<float*>(xtab) + ((ltile / p.splits) % 3) * 128;
+#pragma unroll
+        for (int k = 0; k < 2 * TC / 64; ++k) {
+            const int i = lane + 64 * k;                     // [0, TC): scale, [TC, 2 TC): shift
+            const bool sh = i >= TC;
+            const int c = c_base + i - (sh ? TC : 0);
+            tab[i] = c < p.C0 ? p.sc0[(size_t)((sh ? p.N : 0) + n) * p.C0 + c] : 0.f;
+        }
     };
 
     // staging of one tile = s_iters + z_iters wave-level DMA instructions per wave, issued back to back right after the
@@ -502,6 +511,56 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
         }
     };
     const int n_items = p.s_iters + p.z_iters;
+    // XF: rewrite source item j of image `img` (the 16-byte piece THIS thread staged) as LeakyReLU(scale z + shift); g_*
+    // describe the tile of `img`; out-of-image halo pixels stay zero
+    auto xf_item = [&](int j, unsigned char* img, const float* tab) {
+        if (j >= p.s_iters) return;
+        const int i = (tid + j * NTHR) >> 2;
+        const int pl = (CBLK == 2 && i >= p.s_halo) ? 1 : 0;
+        const int hp = i - pl * p.s_halo;
+        const int hy = __umulhi((unsigned)hp, p.mg_shw), hx = hp - hy * p.SHW;
+        const int sy = g_sy0 + hy, sx = g_sx0 + hx, cc = pl * 32 + slot * 8;
+        if (hp < p.s_halo && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW && c_base + cc < p.C0) {
+            u32x4* pp = reinterpret_cast<u32x4*>(img + (size_t)(tid + j * NTHR) * 16);
+            u32x4 v = *pp;
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(tab + cc), sb = *reinterpret_cast<const f32x4*>(tab + cc + 4);
+            const f32x4 ha = *reinterpret_cast<const f32x4*>(tab + TC + cc), hb = *reinterpret_cast<const f32x4*>(tab + TC + cc + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z0 = __uint_as_float(v[e] << 16), z1 = __uint_as_float(v[e] & 0xffff0000u);
+                const float s0 = e < 2 ? sa[2 * e] : sb[2 * e - 4], s1 = e < 2 ? sa[2 * e + 1] : sb[2 * e - 3];
+                const float h0 = e < 2 ? ha[2 * e] : hb[2 * e - 4], h1 = e < 2 ? ha[2 * e + 1] : hb[2 * e - 3];
+                float a0 = z0 * s0 + h0, a1 = z1 * s1 + h1;
+                a0 = a0 > 0.f ? a0 : a0 * p.slope0;
+                a1 = a1 > 0.f ? a1 : a1 * p.slope0;
+                v[e] = (unsigned)f32_to_bf16(a0) | ((unsigned)f32_to_bf16(a1) << 16);
+            }
+            *pp = v;
+        }
+    };
+    // the items this wave issued for logical tile `ltile` (same loops as the issue sites below)
+    auto xf_own = [&](int ltile, unsigned char* img) {
+        const float* tab = reinterpret_cast<const float*>(xtab) + ((ltile / p.splits) % 3) * 128;
+        if (ltile == byi) {                       // first image
+            if constexpr (PC) {
+                const int half = n_items / 2;
+                for (int j = producer ? 0 : half; j < (producer ? half : n_items); ++j) xf_item(j, img, tab);
+            } else {
+                for (int j = 0; j < n_items; ++j) xf_item(j, img, tab);
+            }
+            return;
+        }
+        if constexpr (PC) {
+            if (producer) {
+                for (int j = p.pc_early; j < p.pc_items; ++j) xf_item(j, img, tab);
+            } else {
+                for (int j = 0; j < p.pc_early; ++j) xf_item(j, img, tab);
+                for (int j = p.pc_items; j < n_items; ++j) xf_item(j, img, tab);
+            }
+        } else {
+            for (int j = 0; j < n_items; ++j) xf_item(j, img, tab);
+        }
+    };
     if (PC && producer && CU_DBG(p, 128)) __builtin_amdgcn_s_setprio(3);
 
     // lane l = 16g + 4q + pp supplies row q of its group's 4x16 transpose block
@@ -524,43 +583,15 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     auto run_tile = [&](int tile, unsigned char* cur, unsigned char* other) {
         const long long c0 = CU_DBG(p, 16) ? wall_clock64() : 0;
         dma_wait();           // this wave's share of the tile has landed ...
+        if constexpr (XF) xf_own(tile, cur);      // ... and is normalised + activated in place by the wave that staged it
         const long long c1 = CU_DBG(p, 16) ? wall_clock64() : 0;
         __syncthreads();      // ... everybody's has, and the other image is no longer being read
-        if constexpr (XF) {   // normalise + activate the source image in place (g_* still describe THIS tile)
-            const float* tab = reinterpret_cast<const float*>(xtab + (cur == imgA ? 0 : 1024));      // scale[TC], shift[TC]
-            const int n_pieces = p.s_halo * 4 * CBLK;
-            for (int i = threadIdx.x; i < n_pieces; i += 64 * NW) {
-                const int pl = (CBLK == 2 && i >= p.s_halo * 4) ? 1 : 0;
-                const int rem = i - pl * p.s_halo * 4;
-                const int hp = rem >> 2, cc = pl * 32 + (rem & 3) * 8;
-                const int hy = __umulhi((unsigned)hp, p.mg_shw), hx = hp - hy * p.SHW;
-                const int sy = g_sy0 + hy, sx = g_sx0 + hx;
-                if (sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW && c_base + cc < p.C0) {
-                    u32x4* pp = reinterpret_cast<u32x4*>(cur + (size_t)i * 16);
-                    u32x4 v = *pp;
-                    const f32x4 sa = *reinterpret_cast<const f32x4*>(tab + cc), sb = *reinterpret_cast<const f32x4*>(tab + cc + 4);
-                    const f32x4 ha = *reinterpret_cast<const f32x4*>(tab + TC + cc), hb = *reinterpret_cast<const f32x4*>(tab + TC + cc + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float z0 = __uint_as_float(v[e] << 16), z1 = __uint_as_float(v[e] & 0xffff0000u);
-                        const float s0 = e < 2 ? sa[2 * e] : sb[2 * e - 4], s1 = e < 2 ? sa[2 * e + 1] : sb[2 * e - 3];
-                        const float h0 = e < 2 ? ha[2 * e] : hb[2 * e - 4], h1 = e < 2 ? ha[2 * e + 1] : hb[2 * e - 3];
-                        float a0 = z0 * s0 + h0, a1 = z1 * s1 + h1;
-                        a0 = a0 > 0.f ? a0 : a0 * p.slope0;
-                        a1 = a1 > 0.f ? a1 : a1 * p.slope0;
-                        v[e] = (unsigned)f32_to_bf16(a0) | ((unsigned)f32_to_bf16(a1) << 16);
-                    }
-                    *pp = v;
-                }
-            }
-            __syncthreads();
-        }
         const long long c2 = CU_DBG(p, 16) ? wall_clock64() : 0;
         const bool more = tile + p.splits < p.ntiles && !CU_DBG(p, 8);
-        if (more) tile_geo(tile + p.splits);
-        if constexpr (XF) {
-            if (more && wave == (PC ? NWC : 0)) issue_table(g_img0, other == imgA ? 0 : 1);
+        if constexpr (XF) {   // wave 0: scale / shift rows of the tile after next -> table ring (published by the next barrier)
+            if (wave == 0 && tile + 2 * p.splits < p.ntiles) write_table(tile + 2 * p.splits);
         }
+        if (more) tile_geo(tile + p.splits);
         if (more && issuer) {
             // all DMA instructions now: spreading them over the k-steps was slower with one wave per SIMD (it stalls
             // the software pipeline, 157 -> 191 us) and with two (157 -> 181 us).  PC: the producers take the first
@@ -663,15 +694,19 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     const long long k0 = CU_DBG(p, 16) ? wall_clock64() : 0;
     if (tile < p.ntiles) {
         tile_geo(tile);
-        if constexpr (XF) {
-            if (wave == 0) issue_table(g_img0, 0);
-        }
         if constexpr (PC) {       // first image: both wave groups issue half of the rounds
             const int half = n_items / 2;
             for (int j = producer ? 0 : half; j < (producer ? half : n_items); ++j) issue_item(j, imgA);
         } else {
             for (int j = 0; j < n_items; ++j) issue_item(j, imgA);
         }
+    }
+    if constexpr (XF) {           // tables of this workgroup's first two tiles (the later ones: run_tile, two tiles ahead)
+        if (wave == 0) {
+            if (tile < p.ntiles) write_table(tile);
+            if (tile + p.splits < p.ntiles) write_table(tile + p.splits);
+        }
+        __syncthreads();
     }
     const long long k1 = CU_DBG(p, 16) ? wall_clock64() : 0;
     for (; tile < p.ntiles; tile += 2 * p.splits) {

@@ -71,7 +71,10 @@ __global__ __launch_bounds__(512, (XF && CIP == 1 && NB == 1 && R == 2) ? 4 : 1)
     constexpr int NBW = NB * TH / 8;            // 32-column blocks per wave
     constexpr int S = 2 * NBW;                  // 16-byte stores per thread and tile
     constexpr int ZL = MODE == 2 ? 4 * NBW : 0; // hand-issued 8-byte loads of z per thread and tile
-    constexpr int XT = XF ? 1 : 0;              // table DMA instructions per wave and tile
+    // MODE 1 (a run of tiles of ONE image per workgroup): the table is loaded once and every thread rewrites the pieces it
+    // staged itself BEFORE the tile's barrier -- no second barrier; MODE 0 (tiles of any image): table by LDS-DMA per tile
+    constexpr bool XF1 = XF && MODE == 1;
+    constexpr int XT = (XF && !XF1) ? 1 : 0;    // table DMA instructions per wave and tile
     constexpr int TAB0 = W_B + R * SLOT_B + 1024;        // XF: R tables of 1 KiB, then the dump kilobyte
     static_assert(NBW >= 1 && W_B + R * SLOT_B + 1024 + (XF ? (R + 1) * 1024 : 0) <= 160 * 1024, "tconv: bad instance");
     static_assert(!XF || (MODE != 2 && CI <= 128), "tconv: XF serves the forward instances");
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(512, (XF && CIP == 1 && NB == 1 && R == 2) ? 4 : 1)
             if (s1) dma16(rs1, off, dst);
             else dma16(rs0, off, dst);
         }
-        if constexpr (XF) {        // lanes [0, CI/4): 16-byte pieces of scale[n][:], lanes [CI/4, CI/2): of shift[n][:]
+        if constexpr (XF && !XF1) {        // lanes [0, CI/4): 16-byte pieces of scale[n][:], lanes [CI/4, CI/2): of shift[n][:]
             const bool sh = lane >= CI / 4;
             const unsigned off = (live && wave == 0 && lane < CI / 2)
                 ? (unsigned)(((sh ? p.N : 0) + n) * CI + 4 * (lane - (sh ? CI / 4 : 0))) * 4u : OOB;
@@ -167,7 +170,15 @@ __global__ __launch_bounds__(512, (XF && CIP == 1 && NB == 1 && R == 2) ? 4 : 1)
             *reinterpret_cast<f32x4*>(s_par + 4 * tid) = f32x4{p.nstats[2 * NC + i], p.nstats[3 * NC + i], rstd, -mean * rstd};
         }
     }
+    if constexpr (XF1) {        // scale[CI], shift[CI] of this workgroup's image -> table 0, once
+        if (tid < 2 * CI) {
+            const int n_img = ((int)blockIdx.x * p.run) / (p.tiles_x * p.tiles_y);
+            const bool sh = tid >= CI;
+            reinterpret_cast<float*>(smem + TAB0)[tid] = p.xscale[(size_t)((sh ? p.N : 0) + n_img) * CI + (tid - (sh ? CI : 0))];
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weights + bias have landed (before any counted wait below)
+    if constexpr (XF1) __syncthreads();                    // ... and the table is visible to every wave
 
     const bf16_t* W16 = reinterpret_cast<const bf16_t*>(smem);
     float ssum[STATS ? NBW : 1][16], ssq[STATS ? NBW : 1][16];
@@ -177,6 +188,32 @@ __global__ __launch_bounds__(512, (XF && CIP == 1 && NB == 1 && R == 2) ? 4 : 1)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { ssum[b][i] = 0.f; ssq[b][i] = 0.f; }
     }
+    // XF: rewrite the pieces THIS thread staged into ring slot `slot` (tile origin y0, x0) with table `tb`
+    auto xform = [&](int slot, int tb, int y0, int x0) {
+        const float* tab = reinterpret_cast<const float*>(smem + TAB0 + tb * 1024);     // scale[CI], shift[CI]
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int sy = y0 + hy[j], sx = x0 + hx[j];
+            if (coff[j] != 0xffffffffu && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) {
+                const int c0 = (int)(coff[j] >> 1);      // first channel of the piece (single source)
+                u32x4* pp = reinterpret_cast<u32x4*>(smem + W_B + slot * SLOT_B + j * 8192 + tid * 16);
+                u32x4 v = *pp;
+                const f32x4 sa = *reinterpret_cast<const f32x4*>(tab + c0), sb = *reinterpret_cast<const f32x4*>(tab + c0 + 4);
+                const f32x4 ha = *reinterpret_cast<const f32x4*>(tab + CI + c0), hb = *reinterpret_cast<const f32x4*>(tab + CI + c0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float z0 = __uint_as_float(v[e] << 16), z1 = __uint_as_float(v[e] & 0xffff0000u);
+                    const float sc0 = e < 2 ? sa[2 * e] : sb[2 * e - 4], sc1 = e < 2 ? sa[2 * e + 1] : sb[2 * e - 3];
+                    const float sh0 = e < 2 ? ha[2 * e] : hb[2 * e - 4], sh1 = e < 2 ? ha[2 * e + 1] : hb[2 * e - 3];
+                    float a0 = z0 * sc0 + sh0, a1 = z1 * sc1 + sh1;
+                    a0 = a0 > 0.f ? a0 : a0 * p.xslope;
+                    a1 = a1 > 0.f ? a1 : a1 * p.xslope;
+                    v[e] = (unsigned)f32_to_bf16(a0) | ((unsigned)f32_to_bf16(a1) << 16);
+                }
+                *pp = v;
+            }
+        }
+    };
     int l = l_begin;
     issue(l, 0);
     if (R == 3) issue(l + l_step, 1);
@@ -191,10 +228,11 @@ __global__ __launch_bounds__(512, (XF && CIP == 1 && NB == 1 && R == 2) ? 4 : 1)
             if (it == 0) wait_vm<0>();
             else wait_vm<S>();
         }
-        __syncthreads();        // tile `it` is complete for every wave, and nobody reads the slot of tile it-1 any more
         const int tile = tile_of(l);
         const int tx = tile % p.tiles_x, rest = tile / p.tiles_x;
         const int ty = rest % p.tiles_y, n = rest / p.tiles_y;
+        if constexpr (XF1) xform(it % R, 0, ty * TH - 1, tx * 32 - 1);      // this thread's own pieces: they have landed
+        __syncthreads();        // tile `it` is complete for every wave, and nobody reads the slot of tile it-1 any more
         const size_t opix = ((size_t)n * p.H + ty * TH + row) * p.W + tx * 32 + r;
         u32x2 zq[MODE == 2 ? NBW : 1][4];
         if constexpr (MODE == 2) {
@@ -207,31 +245,8 @@ __global__ __launch_bounds__(512, (XF && CIP == 1 && NB == 1 && R == 2) ? 4 : 1)
         }
         issue(l + (R - 1) * l_step, (it + R - 1) % R);
         const bf16_t* X16 = reinterpret_cast<const bf16_t*>(smem + W_B + (it % R) * SLOT_B);
-        if constexpr (XF) {
-            const float* tab = reinterpret_cast<const float*>(smem + TAB0 + (it % R) * 1024);     // scale[CI], shift[CI]
-            const int y0 = ty * TH - 1, x0 = tx * 32 - 1;
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                const int sy = y0 + hy[j], sx = x0 + hx[j];
-                if (coff[j] != 0xffffffffu && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) {
-                    const int c0 = (int)(coff[j] >> 1) + (cat ? 0 : 0);      // first channel of the piece (single source)
-                    u32x4* pp = reinterpret_cast<u32x4*>(smem + W_B + (it % R) * SLOT_B + j * 8192 + tid * 16);
-                    u32x4 v = *pp;
-                    const f32x4 sa = *reinterpret_cast<const f32x4*>(tab + c0), sb = *reinterpret_cast<const f32x4*>(tab + c0 + 4);
-                    const f32x4 ha = *reinterpret_cast<const f32x4*>(tab + CI + c0), hb = *reinterpret_cast<const f32x4*>(tab + CI + c0 + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float z0 = __uint_as_float(v[e] << 16), z1 = __uint_as_float(v[e] & 0xffff0000u);
-                        const float sc0 = e < 2 ? sa[2 * e] : sb[2 * e - 4], sc1 = e < 2 ? sa[2 * e + 1] : sb[2 * e - 3];
-                        const float sh0 = e < 2 ? ha[2 * e] : hb[2 * e - 4], sh1 = e < 2 ? ha[2 * e + 1] : hb[2 * e - 3];
-                        float a0 = z0 * sc0 + sh0, a1 = z1 * sc1 + sh1;
-                        a0 = a0 > 0.f ? a0 : a0 * p.xslope;
-                        a1 = a1 > 0.f ? a1 : a1 * p.xslope;
-                        v[e] = (unsigned)f32_to_bf16(a0) | ((unsigned)f32_to_bf16(a1) << 16);
-                    }
-                    *pp = v;
-                }
-            }
+        if constexpr (XF && !XF1) {
+            xform(it % R, it % R, ty * TH - 1, tx * 32 - 1);
             __syncthreads();      // the rewritten tile is complete for every wave
         }
 

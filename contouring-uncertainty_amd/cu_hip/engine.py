@@ -338,6 +338,9 @@ class UNetEngine:
             u = self._convT_fwd(P, ctx, f"upsamples.{i}.transp_conv", a)
             a = self._block_fwd(P, ctx, f"upsamples.{i}.conv_block", [u, skip], 1)
         ctx.n_up = len(ctx.enc)
+        # (the 1x1 head's kernels read the materialised activation: the generic kernel's fused load made the head's forward
+        # 419 instead of 143 us and its weight gradient 231 instead of 165 us at batch 64 -- profiles/r03_lazy_act.txt)
+        a = ops.materialized(a)
         ctx.last = a
         # 1x1 output conv -> NCHW f32 logits (K planes; GEMM columns padded to 32)
         w = P["output_block.conv.weight"]

@@ -61,7 +61,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // pieces it staged itself -- skipping out-of-image halo pixels, which must stay zero (the zero padding of the conv) -- and a
 // second barrier hands the tile to the MFMAs.  Rounding: bf16(LeakyReLU(z * scale + shift)), the apply pass's own arithmetic.
 template <int CIP, int NB, int TH, int R, int MODE, bool XF = false>
-__global__ __launch_bounds__(512, (XF && CIP == 1 && NB == 1 && R == 2) ? 4 : 1) void tconv_kernel(const TcArgs p) {
+__global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
     constexpr bool STATS = MODE != 0;
     constexpr int CI = 32 * CIP, CO = 32 * NB;
     constexpr int HW34 = 34, HALO = (TH + 2) * HW34, HPAD = (HALO + 15) / 16 * 16;     // plane stride: whole DMA instructions

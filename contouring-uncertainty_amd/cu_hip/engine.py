@@ -124,8 +124,10 @@ class UNetEngine:
         # True: one streaming pass materialises LeakyReLU(InstanceNorm(z)) per layer and every consumer stages a plain
         # operand; False: consumers recompute it in their operand load (less HBM traffic, but VALU-bound thin layers)
         self.materialize = True
-        # True: the thin, large layers keep only their raw output + statistics; consumers normalise on load (see _lazy)
-        self.lazy_act = os.environ.get("CONTOUR_LAZY_ACT", "1") != "0"
+        # True: the thin, large layers keep only their raw output + statistics; consumers normalise on load (see _lazy).
+        # OFF by default: measured on MI355X (profiles/r03_lazy_act.txt) the in-LDS rewrite costs the streaming kernel and
+        # the weight-gradient kernel as much as the apply pass it removes (both are latency-bound per tile, not HBM-bound)
+        self.lazy_act = os.environ.get("CONTOUR_LAZY_ACT", "0") == "1"
         # True: InstanceNorm + LeakyReLU forward (statistics + materialise) and backward (reduce + apply) each run as ONE
         # resident-chunk launch that reads every tensor once (norm.hip); False: the two-pass kernels
         self.fused_norm = True

@@ -136,6 +136,9 @@ static inline int cu_env_int(const char*, int dflt) { return dflt; }
 static inline bool cu_env_set(const char*) { return false; }
 #endif
 
+// layout code of cu_conv_wgrad_parts for slabs in the plain [wtaps][CO][CI] layout (else (NBLK << 8) | CBLK: native)
+#define CU_PARTS_PLAIN 0xffff
+
 static inline int ilog2_exact(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

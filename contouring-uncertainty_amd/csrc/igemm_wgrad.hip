@@ -1091,6 +1091,9 @@ static int wgrad_impl(const cu_wgrad_desc* d, const void* src0, const float* sca
 #undef CU_W
 }
 
+int cu_gemm_tn_try(const cu_wgrad_desc* d, const void* src0, const void* z, float* parts, size_t parts_floats, int* nparts,
+                   void* stream);
+
 extern "C" int cu_conv_wgrad(const cu_wgrad_desc* d, const void* src0, const float* scale0, const float* shift0,
                              const void* src1, const float* scale1, const float* shift1, const void* z, float* dw,
                              void* stream) {
@@ -1103,5 +1106,11 @@ extern "C" int cu_conv_wgrad_parts(const cu_wgrad_desc* d, const void* src0, con
     CU_CHECK_ARG(nparts != nullptr && layout != nullptr && parts != nullptr, "cu_conv_wgrad_parts: null pointer");
     *nparts = 0;
     *layout = 0;
+    // 2x2 stride-2 transposed convolution from one plain bf16 source: the pixel-major GEMM of gemm_tn.hip (plain slabs)
+    if (d && src0 && z && !scale0 && !cu_env_set("CU_WGRAD_NOGEMMTN")) {
+        const int rc = cu_gemm_tn_try(d, src0, z, parts, parts_floats, nparts, stream);
+        if (rc < 0) return rc;
+        if (rc > 0) { *layout = CU_PARTS_PLAIN; return 0; }
+    }
     return wgrad_impl(d, src0, scale0, shift0, src1, scale1, shift1, z, parts, parts_floats, nparts, layout, stream);
 }

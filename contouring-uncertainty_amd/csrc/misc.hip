@@ -332,6 +332,20 @@ __global__ __launch_bounds__(256) void parts_reduce_kernel(float* __restrict__ p
     base[0] = acc;
 }
 
+// slab 0 += slabs 1 .. S-1, `stride4` pieces apart, in slab order (plain-layout slabs)
+__global__ __launch_bounds__(256) void parts_reduce_strided_kernel(float* __restrict__ parts, size_t E4, size_t stride4, int S) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= E4) return;
+    f32x4* base = reinterpret_cast<f32x4*>(parts) + i;
+    f32x4 acc = base[0];
+#pragma unroll 8
+    for (int s = 1; s < S; ++s) {
+        const f32x4 v = base[(size_t)s * stride4];
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    base[0] = acc;
+}
+
 __global__ __launch_bounds__(256) void parts_finish_kernel(const float* __restrict__ parts, size_t E4, size_t stride4, int S,
                                                            float* __restrict__ out, int T, int CO, int CI, int NBLK,
                                                            int CBLK, int ctiles) {
@@ -688,9 +702,25 @@ extern "C" int cu_grad_unprep(int T, int CO, int CI, int COP, long s_co, long s_
 extern "C" int cu_grad_unprep_parts(int T, int CO, int CI, int COP, long s_co, long s_ci, float* parts, size_t parts_floats,
                                     int nparts, int layout, float* grad, int accumulate, void* stream) {
     CU_CHECK_ARG(T > 0 && CO > 0 && CI > 0 && COP >= CO && parts && grad && nparts >= 1, "cu_grad_unprep_parts: bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (layout == CU_PARTS_PLAIN) {      // slabs already in the plain [T][COP][CI] layout (gemm_tn.hip): element-wise sums
+        const size_t E = (size_t)T * COP * CI;
+        CU_CHECK_ARG(E % 4 == 0 && parts_floats >= (size_t)nparts * E, "cu_grad_unprep_parts: workspace of %zu floats < %d slabs of %zu", parts_floats, nparts, E);
+        const unsigned gx = (unsigned)((E / 4 + 255) / 256);
+        if (nparts > 16) {
+            const int G = cdiv(nparts, 16), groups = cdiv(nparts, G);
+            hipLaunchKernelGGL(parts_reduce_kernel, dim3(gx, groups), dim3(256), 0, st, parts, E / 4, nparts, G);
+            CU_LAUNCH_CHECK();
+            hipLaunchKernelGGL(parts_reduce_strided_kernel, dim3(gx), dim3(256), 0, st, parts, E / 4, (size_t)G * (E / 4), groups);
+            CU_LAUNCH_CHECK();
+        } else if (nparts > 1) {
+            hipLaunchKernelGGL(parts_reduce_strided_kernel, dim3(gx), dim3(256), 0, st, parts, E / 4, E / 4, nparts);
+            CU_LAUNCH_CHECK();
+        }
+        return cu_grad_unprep(T, CO, CI, COP, s_co, s_ci, parts, grad, accumulate & 1, stream);
+    }
     const int NBLK = layout >> 8, CBLK = layout & 255;
     CU_CHECK_ARG(NBLK >= 1 && NBLK <= 4 && CBLK >= 1 && CBLK <= 2, "cu_grad_unprep_parts: layout %d is not one cu_conv_wgrad_parts returns", layout);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int ctiles = cdiv(CI, 32 * CBLK), ntn = cdiv(COP, 32 * NBLK);
     const size_t E = (size_t)ntn * ctiles * NBLK * CBLK * T * 1024, plain = (size_t)T * COP * CI;
     CU_CHECK_ARG(parts_floats >= (size_t)nparts * E + plain, "cu_grad_unprep_parts: workspace of %zu floats < %d slabs of %zu + %zu",

@@ -161,7 +161,7 @@ def test_conv_dgrad_wgrad(dtype, case):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(2, 64, 32, 16), (3, 480, 480, 2), (2, 480, 256, 8)])
+@pytest.mark.parametrize("case", [(2, 64, 32, 16), (3, 480, 480, 2), (2, 480, 256, 8), (4, 128, 64, 32), (3, 256, 128, 16)])
 def test_conv_transpose(dtype, case):
     ops = _ops()
     n, ci, co, size = case

@@ -23,12 +23,42 @@ import torch
 import torch.distributed as dist
 
 
+def sum_over_ranks(buf: torch.Tensor, group=None, algo: str = "allreduce", async_op: bool = False):
+    """In-place SUM of ``buf`` over the ranks through torch.distributed.  ``algo`` "rs_ag": reduce-scatter + all-gather of
+    equal shards (what the native cu_comm_* path does by default); backends without a tensor reduce-scatter (gloo, the
+    CPU tests) get the same two phases from ``reduce`` to the shard's owner + ``all_gather``."""
+    world = dist.get_world_size(group)
+    per = buf.numel() // world if algo == "rs_ag" else 0
+    if per == 0:
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    head, rank = buf[:per * world], dist.get_rank(group)
+    shards = list(head.view(world, per).unbind(0))
+    try:
+        mine = torch.empty_like(shards[rank])
+        dist.reduce_scatter_tensor(mine, head, op=dist.ReduceOp.SUM, group=group)
+        dist.all_gather_into_tensor(head, mine, group=group)
+    except (RuntimeError, NotImplementedError):
+        for r, sh in enumerate(shards):                   # phase 1: shard r summed on rank r
+            dist.reduce(sh, dst=dist.get_global_rank(group, r) if group is not None else r, op=dist.ReduceOp.SUM, group=group)
+        mine = shards[rank].clone()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine, group=group)      # phase 2: everybody gets every shard
+        for sh, g_ in zip(shards, gathered):
+            sh.copy_(g_)
+    if buf.numel() > per * world:
+        dist.all_reduce(buf[per * world:], op=dist.ReduceOp.SUM, group=group)
+    return None
+
+
 class BucketedAllReduce:
     def __init__(self, total: int, bucket_elems: int = 8 * 1024 * 1024, group=None, native=None):
         self.total = total
         self.bucket = bucket_elems
         self.group = group
         self.native = native            # cu_hip.comm.NativeComm: the cu_comm_* C ABI instead of torch.distributed
+        # torch.distributed path: "allreduce" (asynchronous, overlapped) or "rs_ag" (CONTOUR_COMM_ALGO; the native path's
+        # default algorithm, here for rehearsals and tests -- its torch form is synchronous)
+        self.algo = os.environ.get("CONTOUR_COMM_ALGO", "allreduce") if native is None else native.algo
         self.flat: Optional[torch.Tensor] = None
         self._done: List[Tuple[int, int]] = []
         self._frontier = total          # everything in [frontier, total) has been handed to a collective
@@ -64,8 +94,11 @@ class BucketedAllReduce:
         if self.native is not None:
             self.native.allreduce_async(self.flat[lo:hi])
         elif dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                               async_op=True))
+            if self.algo == "rs_ag":
+                sum_over_ranks(self.flat[lo:hi], self.group, "rs_ag")
+            else:
+                self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                                   async_op=True))
 
     def ready(self, lo: int, hi: int):
         """Mark [lo, hi) final; launch a collective when a bucket's worth is contiguous with the frontier."""
@@ -178,6 +211,13 @@ class GradSync:
             return
         lo, hi = self.ranges[prefix]
         self.bar.ready(lo, hi)
+
+    def close(self):
+        """Release the RCCL communicator of the native path (also released when the object is collected)."""
+        if self.native is not None:
+            self.native.close()
+            self.native = None
+            self.bar.native = None
 
     def abort(self):
         """The backward in flight died (``UNetEngine.backward`` calls this before re-raising): wait for the collectives

@@ -41,9 +41,10 @@ def _completion_order(names):
     return list(reversed(layers))
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, algo="allreduce"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["CONTOUR_COMM_ALGO"] = algo
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from cu_hip.ddp import BucketedAllReduce, prefix_ranges
@@ -58,6 +59,7 @@ def _worker(rank, world, port, ret):
         flat = torch.randn(total, generator=g)
         mine = flat.clone()
         bar = BucketedAllReduce(total, bucket_elems=1 << 20)
+        assert bar.algo == algo
         bar.begin(flat)
         for prefix in _completion_order(names):
             lo, hi = ranges[prefix]
@@ -75,11 +77,17 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_two_ranks_gloo():
+import pytest
+
+
+@pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
+def test_bucketed_allreduce_two_ranks_gloo(algo):
+    """both exchange algorithms: one all-reduce per bucket, and reduce-scatter + all-gather of equal shards (the native
+    cu_comm_* path's default over xGMI; gloo carries its two phases as reduce-to-owner + all_gather)"""
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, ret, algo), nprocs=2, join=True)
     assert len(ret) == 2
     for rank in (0, 1):
         ok, contiguous, several, n = ret[rank]

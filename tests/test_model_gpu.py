@@ -188,11 +188,15 @@ def test_full_size_forward_vs_reference_golden(golden_dir):
         logits, bott = net(x.to(DEV))
         a = head(bott)
         mu, sigma, aux = ops.dsnt_head_fwd(logits, True)
-    # the bottleneck is 16 InstanceNorms deep and normalises over 2x2 = 4 values: ill-conditioned, so it (and the skew
-    # head fed by it) gets an absolute tolerance; the head outputs below are what north_star bounds at 1e-4
-    assert torch.allclose(bott.cpu(), T(g["bottleneck"]), rtol=5e-3, atol=2e-3)
-    assert torch.allclose(a.cpu(), T(g["alpha_raw"]), rtol=5e-3, atol=2e-3)
-    assert torch.allclose(logits[0, :, 128, :].cpu(), T(g["logits_row"]), rtol=5e-3, atol=1e-3)
+    # Tolerances (measured, not guessed).  The reference algorithm itself, run on the CPU in
+    # float32 and in float64 on these weights, differs by 1.0e-4 absolute at the bottleneck (16 InstanceNorms deep, the last
+    # ones over 2x2 = 4 values: ill-conditioned) and by 6.1e-5 in the logits; the HIP f32 path measured against the
+    # reference's float32 golden (tools/full_size_err.py, profiles/r03_full_size_err.txt): bottleneck 4.7e-4 absolute
+    # (|max| 1.73), alpha 5.3e-7 (|max| 0.058), logits 9.3e-5 (|max| 4.6).  The bounds leave 2x for the run-to-run noise of
+    # the f32 atomics in the statistics; the head outputs below are what north_star bounds at 1e-4.
+    assert torch.allclose(bott.cpu(), T(g["bottleneck"]), rtol=1e-3, atol=8e-4)
+    assert torch.allclose(a.cpu(), T(g["alpha_raw"]), rtol=1e-3, atol=5e-6)
+    assert torch.allclose(logits[0, :, 128, :].cpu(), T(g["logits_row"]), rtol=3e-4, atol=2e-4)
     coords_px = 0.5 * ((T(g["coords"]) + 1) * 256 - 1)
     assert float((mu.cpu() - coords_px).abs().max() / coords_px.abs().max()) < 1e-4
     var_px = T(g["var"]) * 128.0 ** 2

@@ -151,6 +151,10 @@ class UNetEngine:
         self._red: Optional[torch.cuda.Stream] = None      # stream of the partial tiles' sums / un-preparations
         self._red_done = [None, None]
         self._wg_count = 0
+        # workgroups of a weight-gradient launch on the second stream: 192 of the 256 CUs' worth, so that the input-gradient
+        # chain beside it finds free CUs (a weight-gradient workgroup owns its CU's whole LDS).  Measured, alternating runs
+        # on one box: 14.10 / 14.17 ms at 192 against 14.40 / 14.34 ms at 256 (0 = the library's choice, 256)
+        self._wgrad_wgs = int(os.environ.get("CONTOUR_WGRAD_WGS", "192"))
         self._dw9_ws: Optional[Tensor] = None       # first layer's 9 x CO accumulator (zero between uses)
         # InstanceNorm workspaces (atomics targets) of all layers of one pass: slices of ONE arena per direction that
         # is zeroed by one fill at the start of the pass (instead of one memset launch per layer)
@@ -423,6 +427,11 @@ class UNetEngine:
                 self._red = torch.cuda.Stream(z.device)
             if self._red_done[k] is not None:
                 cur.wait_event(self._red_done[k])              # buffer k's previous sum has been read
+        if self._wgrad_wgs and third and "splits" not in kw:
+            # experiment knob (CONTOUR_WGRAD_WGS=n): cap the weight-gradient launch at ~n workgroups so that it leaves CUs to
+            # the input-gradient chain running beside it (its workgroups own a CU's whole LDS)
+            co, ci = shape[1], shape[2]
+            kw["splits"] = max(1, self._wgrad_wgs // (-(-co // 64) * -(-ci // 64)))
         slabs = ops.conv_wgrad(srcs, z, ws, parts=True, **kw)
         if not third:
             ops.grad_unprep_parts(ws, slabs, shape[1], grad, kind, accumulate=True)

@@ -353,7 +353,11 @@ class Trainer:
             model.current_epoch = epoch
             model.train()
             for idx, batch in self._mine(datamodule.train_dataloader()):
-                out = model.training_step(_to_device(batch, device), idx)
+                batch = _to_device(batch, device)
+                hook = getattr(datamodule, "on_after_batch_transfer", None)      # Lightning's hook: on-device augmentation
+                if hook is not None:
+                    batch = hook(batch, idx)
+                out = model.training_step(batch, idx)
                 (out["loss"] / self.accumulate_grad_batches).backward()
                 if (idx + 1) % self.accumulate_grad_batches == 0:
                     self._call("on_before_optimizer_step", model, optimizer)

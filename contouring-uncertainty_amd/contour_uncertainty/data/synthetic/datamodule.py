@@ -77,7 +77,7 @@ class SyntheticContourDataModule:
 
     def __init__(self, size: int = 256, points_per_side: int = 11, labels: Optional[Sequence[int]] = (0, 1),
                  batch_size: int = 32, num_workers: int = 0, n_train: int = 64, n_val: int = 8, n_predict: int = 4,
-                 seed: int = 1234, **_unused):
+                 seed: int = 1234, da: bool = False, **_unused):
         nb_points = 2 * points_per_side - 1                       # reference datamodule.py:76-84 (one LV contour)
         # label names -> vital.data.camus.config.Label values, like Label.from_proto_labels does for the CAMUS module
         names = {"bg": 0, "lv": 1, "myo": 2, "atrium": 3}
@@ -87,6 +87,26 @@ class SyntheticContourDataModule:
         self.counts = {"train": n_train, "val": n_val, "predict": n_predict}
         self.datasets = {}
         self._dataset = self.datasets          # the name UncertaintyTask.on_fit_start reads (reference uncertainty.py:78)
+        # the reference's data augmentation and test-time augmentation sets (data/camus/datamodule.py:46-55), here applied to
+        # whole batches ON THE DEVICE after the transfer: the CPU workers only read and collate
+        from contour_uncertainty.augmentations import (Compose, RandomBrightnessContrast, RandomGamma, RandomRotation,
+                                                       RandomTranslation)
+        shape = (size, size)
+        self.tta_transforms = Compose([RandomRotation(3, shape), RandomBrightnessContrast(0.2, 0.2), RandomGamma((0.8, 1.2)),
+                                       RandomTranslation(5, 5)])
+        self.da_transforms = Compose([RandomRotation(3, shape), RandomBrightnessContrast(0.2, 0.2), RandomGamma((0.8, 1.2)),
+                                      RandomTranslation(5, 5)])
+        self.transforms = self.da_transforms if da else None
+
+    def on_after_batch_transfer(self, batch, dataloader_idx: int = 0):
+        """Lightning's post-transfer hook (``_compat.Trainer.fit`` calls it for training batches): image, label map and key
+        points of every item transformed with the item's own random parameters, on the device."""
+        if self.transforms is None or not batch[Tags.img].is_cuda:
+            return batch
+        out = self.transforms(image=batch[Tags.img], mask=batch[Tags.gt], keypoints=batch[ContourTags.contour])
+        batch = dict(batch)
+        batch[Tags.img], batch[Tags.gt], batch[ContourTags.contour] = out["image"], out["mask"], out["keypoints"]
+        return batch
 
     def setup(self, stage: Optional[str] = None):
         stage = str(getattr(stage, "value", stage) or "fit")

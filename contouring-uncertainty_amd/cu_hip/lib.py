@@ -98,6 +98,8 @@ _SIGS = {
     "cu_mask_weighted_entropy": (C.c_int, [C.c_int] * 4 + [_P] * 5),
     "cu_logpdf_grid": (C.c_int, [C.c_int] * 3 + [_P] * 6),
     "cu_skew_rvs": (C.c_int, [C.c_int] * 2 + [_P] * 4 + [C.c_uint64, _P, _P]),
+    "cu_augment_image": (C.c_int, [C.c_int] * 3 + [_P] * 5),
+    "cu_augment_labels": (C.c_int, [C.c_int] * 3 + [_P] * 4),
     "cu_comm_unique_id": (C.c_int, [_P]),
     "cu_comm_init": (C.c_int, [C.c_int, C.c_int, _P, C.POINTER(_P)]),
     "cu_comm_allreduce_bucket": (C.c_int, [_P, _P, C.c_size_t, _P]),

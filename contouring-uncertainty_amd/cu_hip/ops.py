@@ -744,3 +744,30 @@ def skew_rvs(mu: Tensor, sigma3: Tensor, alpha: Tensor, n: int, eps: Optional[Te
         L.check(L.load().cu_skew_rvs(m, n, L.ptr(mu), L.ptr(sigma3), L.ptr(alpha), L.ptr(eps), seed, L.ptr(out),
                                      L.stream_ptr()), "cu_skew_rvs")
     return out
+
+
+def augment_image(img: Tensor, params: Tensor) -> Tensor:
+    """img (N, H, W) or (N, 1, H, W) f32 in [0, 1], params (N, 8) f32 = {angle deg, tx, ty, brightness, contrast, gamma, 0, 0}
+    -> augmented copy (cu_augment_image: rotate -> brightness -> contrast -> gamma -> translate, per image)."""
+    shape = img.shape
+    x = img.reshape(-1, shape[-2], shape[-1]).contiguous().float()
+    n, h, w_ = x.shape
+    assert params.shape == (n, 8) and params.dtype == torch.float32
+    out = torch.empty_like(x)
+    ws = torch.empty(n, dtype=torch.float32, device=x.device)
+    with _Prof("augment"):
+        L.check(L.load().cu_augment_image(n, h, w_, L.ptr(x), L.ptr(params.contiguous()), L.ptr(ws), L.ptr(out), L.stream_ptr()),
+                "cu_augment_image")
+    return out.view(shape)
+
+
+def augment_labels(labels: Tensor, params: Tensor) -> Tensor:
+    """labels (N, H, W) int64 -> rotated + translated copy (nearest; cu_augment_labels)."""
+    x = labels.contiguous()
+    n, h, w_ = x.shape
+    assert x.dtype == torch.int64 and params.shape == (n, 8)
+    out = torch.empty_like(x)
+    with _Prof("augment"):
+        L.check(L.load().cu_augment_labels(n, h, w_, L.ptr(x), L.ptr(params.contiguous()), L.ptr(out), L.stream_ptr()),
+                "cu_augment_labels")
+    return out

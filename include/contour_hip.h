@@ -390,6 +390,21 @@ int cu_mask_weighted_entropy(int F, int S, int H, int W, const uint32_t* packed,
 int cu_mask_last_value(int S, int H, int W, const uint32_t* packed, const float* values, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * On-device training augmentation: the CAMUS data module's Compose([RandomRotation(3),
+ * RandomBrightnessContrast(0.2, 0.2), RandomGamma((0.8, 1.2)), RandomTranslation(5, 5)]) (reference
+ * contour_uncertainty/data/camus/datamodule.py:46-55, augmentations/{affine,brightnesscontrast,gamma}.py), which the
+ * reference runs per item on CPU workers through torchvision.transforms.functional, for a whole batch in two launches.
+ *   img / out [N][H][W] f32 in [0, 1] (distinct buffers); params [N][8] f32 = {angle (degrees), tx, ty (whole pixels),
+ *   brightness factor, contrast factor, gamma, 0, 0} per image; mean_ws [N] f32 scratch.
+ *   Order and semantics of the reference: rotate (nearest, zero fill, about the image centre) -> adjust_brightness ->
+ *   adjust_contrast (blend with the mean of its input, clamp to [0, 1]) -> adjust_gamma -> translate (zero fill).
+ * cu_augment_labels: the geometric half (rotate, translate; nearest) for the int64 label maps [N][H][W].
+ * The key-point half (21 x 2 numbers per item) is host-side tensor arithmetic (contour_uncertainty/augmentations/affine.py).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int cu_augment_image(int N, int H, int W, const float* img, const float* params, float* mean_ws, float* out, void* stream);
+int cu_augment_labels(int N, int H, int W, const long long* labels, const float* params, long long* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Data-parallel gradient exchange: one communicator per process (= per GPU), RCCL over xGMI.
  * The reference is single-device; these are the N-GPU form of the training path, used by cu_hip/comm.py when
  * CONTOUR_COMM=native (default: torch.distributed's "nccl" backend, which is the same RCCL).

@@ -69,6 +69,56 @@ def linear_reconstruction(contour: np.ndarray, shape) -> np.ndarray:
     return binary_fill_holes(mask)
 
 
+def contour_spline(mu: np.ndarray, n: int = 1001, close: bool = False) -> np.ndarray:
+    """interpolating cubic spline through the landmarks at n parameters (reference utils/contour.py:9-25: scipy's
+    ``splprep(k=3, s=0)`` / ``splev``; a contour FITPACK refuses -- duplicate consecutive points, fewer than 4 -- comes
+    back as the raw landmarks, like the reference's bare ``except``).  Host SciPy: the LV + MYO branch of
+    ``USContourToMask`` calls it twice per item; the thousands of sampled contours go through ``reconstruction_batch``."""
+    from scipy import interpolate
+    mu = np.asarray(mu, dtype=float)
+    try:
+        tck, _ = interpolate.splprep([mu[:, 0], mu[:, 1]], k=3, s=0)
+        spline = np.array(interpolate.splev(np.linspace(0, 1.0, n), tck)).transpose()
+    except Exception:      # noqa: BLE001 -- the reference swallows every FITPACK error the same way
+        spline = mu
+    if close:
+        spline = np.concatenate((spline, spline[0][None]))
+    return spline
+
+
+def polygon_mask(vertex_rows, vertex_cols, shape) -> np.ndarray:
+    """``poly2mask`` of the reference (data/camus/utils.py:24-28) = ``skimage.draw.polygon`` + scatter: every pixel centre
+    that lies inside the closed polygon OR on its boundary (vertex / edge), by skimage's point-in-polygon rule (even-odd
+    crossing counts of the ray to the right and of the ray to the left; a point whose two counts disagree in parity sits on
+    an edge; ``skimage/_shared/geometry.pxd``).  scikit-image is absent from this image: the rule is restated (vectorised
+    over pixels x edges with torch, in float64 like skimage); returns an int array (H, W) of 0 / 1."""
+    h, w = shape
+    xp = torch.as_tensor(np.asarray(vertex_cols, dtype=np.float64))
+    yp = torch.as_tensor(np.asarray(vertex_rows, dtype=np.float64))
+    n = xp.numel()
+    out = torch.zeros((h, w), dtype=torch.bool)
+    if n < 3:
+        return out.numpy().astype(int)
+    r0, r1 = max(int(np.floor(yp.min().item())), 0), min(int(np.ceil(yp.max().item())), h - 1)
+    c0, c1 = max(int(np.floor(xp.min().item())), 0), min(int(np.ceil(xp.max().item())), w - 1)
+    if r1 < r0 or c1 < c0:
+        return out.numpy().astype(int)
+    xprev, yprev = torch.roll(xp, 1), torch.roll(yp, 1)          # edge i runs from vertex i-1 to vertex i
+    cols = torch.arange(c0, c1 + 1, dtype=torch.float64)
+    eps = 1e-12
+    for r in range(r0, r1 + 1):                                  # one image row at a time: (columns x edges) work
+        x0 = xp[None, :] - cols[:, None]; y0 = (yp - r)[None, :].expand_as(x0)
+        x1 = xprev[None, :] - cols[:, None]; y1 = (yprev - r)[None, :].expand_as(x0)
+        vertex = ((x0.abs() < eps) & (y0.abs() < eps)).any(1)
+        denom = y1 - y0
+        t = (x0 * y1 - x1 * y0) / torch.where(denom == 0, torch.ones_like(denom), denom)
+        r_cross = (((y0 > 0) != (y1 > 0)) & (t > 0)).sum(1)
+        l_cross = (((y0 < 0) != (y1 < 0)) & (t < 0)).sum(1)
+        edge = (r_cross & 1) != (l_cross & 1)
+        out[r, c0:c1 + 1] = vertex | edge | ((r_cross & 1) == 1)
+    return out.numpy().astype(int)
+
+
 def contour_to_mask(contour: np.ndarray, shape, labels=None, apply_argmax: bool = True,
                     reconstruction_type: str = "linear") -> np.ndarray:
     """Host-only single-structure converter (linear reconstruction), kept for callers without a datamodule."""

@@ -160,10 +160,38 @@ def test_mask_and_umap_paths_have_no_cpu_fallback():
         assert "CUDA" in str(e.value) or "cuda" in str(e.value) or "HIP" in str(e.value) or "GPU" in str(e.value)
     # host-only pieces keep working without a GPU: linear reconstruction (validation Dice), projection
     assert USContourToMask()(c, (256, 256), [0, 1], reconstruction_type="linear").sum() > 1000
-    for fn, args in ((USContourToMask(), (c, (256, 256), [0, 1, 2])), (USUMap(), (c, None, [0, 1, 2])),
-                     (USSkewUmap(), (c, None, None, [0, 1, 2]))):
-        with pytest.raises(NotImplementedError):
-            fn(*args)
+    # the LV + MYO branch (reference data/camus/utils.py:48-82) is host code: with the linear reconstruction it needs no GPU
+    t2 = np.linspace(0, np.pi, 21)
+    epi = np.stack([128 + 70 * np.cos(t2), 170 - 105 * np.sin(t2)], -1).astype(np.float32)
+    seg = USContourToMask()(np.concatenate([c, epi]), (256, 256), [0, 1, 2], reconstruction_type="linear")
+    assert seg.shape == (256, 256) and set(np.unique(seg)) == {0, 1, 2}
+    assert seg[150, 128] == 1 and seg[150, 128 + 60] == 2 and seg[150, 128 - 60] == 2 and seg[20, 20] == 0
+    assert (seg == 2).sum() > 0.5 * (seg == 1).sum()
+    three = USContourToMask()(np.concatenate([c, epi]), (256, 256), [0, 1, 2], apply_argmax=False, reconstruction_type="linear")
+    assert three.shape == (3, 256, 256) and int(three.sum(0).min()) == 1 and int(three.sum(0).max()) == 1
+
+
+def test_polygon_fill_agrees_with_an_independent_point_in_polygon_test():
+    """``polygon_mask`` restates skimage.draw.polygon (absent from this image); matplotlib's Path.contains_points is an
+    independent implementation: the two may differ only on pixels whose centre lies ON the boundary (skimage includes
+    them), i.e. within one pixel of an edge."""
+    from matplotlib.path import Path as MplPath
+    from scipy.ndimage import binary_dilation, binary_erosion
+    from contour_uncertainty.utils.contour import polygon_mask
+    rng = np.random.default_rng(3)
+    for _ in range(3):
+        ang = np.sort(rng.uniform(0, 2 * np.pi, 40))
+        rad = rng.uniform(30, 90, 40)
+        rows, cols = np.rint(128 + rad * np.sin(ang)).astype(int), np.rint(120 + rad * np.cos(ang)).astype(int)
+        got = polygon_mask(rows, cols, (256, 256)).astype(bool)
+        yy, xx = np.mgrid[0:256, 0:256]
+        ref = MplPath(np.stack([cols, rows], 1)).contains_points(np.stack([xx.ravel(), yy.ravel()], 1)).reshape(256, 256)
+        band = binary_dilation(ref, iterations=1) & ~binary_erosion(ref, iterations=1)
+        odd = (got != ref) & ~band                         # only the tips of thin spikes: boundary pixels next to a vertex
+        ys, xs = np.nonzero(odd)
+        assert got[ys, xs].all() and all(np.min(np.hypot(rows - y, cols - x)) <= 1.5 for y, x in zip(ys, xs))
+        assert got.sum() >= ref.sum() and (got != ref).sum() < 0.01 * ref.sum()
+        assert got[rows, cols].all()                       # vertices belong to the polygon
 
 
 def test_train_ensemble_takes_a_random_90_percent_subset():

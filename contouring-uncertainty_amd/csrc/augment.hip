@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void augment_apply_kernel(const T* __restrict_
             float f = (float)v;
             f = fminf(fmaxf(pp[3] * f, 0.f), 1.f);                                        // adjust_brightness
             f = fminf(fmaxf(pp[4] * f + (1.f - pp[4]) * mean[n], 0.f), 1.f);               // adjust_contrast
-            f = fminf(fmaxf(powf(f, pp[5]), 0.f), 1.f);                                    // adjust_gamma (gain 1)
+            if (pp[5] != 1.f) f = fminf(fmaxf(powf(f, pp[5]), 0.f), 1.f);                   // adjust_gamma (gain 1; x ** 1 = x exactly)
             v = (T)f;
         }
     }

@@ -31,7 +31,7 @@ static inline RowMap row_map(int C, int piece) {
 // rows serially, which dominated these HBM-bound kernels.)
 template <int NV, int PIECE>
 __device__ __forceinline__ void reduce_rows(float (&v)[NV][PIECE], float* lds, int piece, int prow, int rows, int tpp,
-                                            bool active, int nwaves = NT / 64) {
+                                            bool active) {
     const int stride = NV * PIECE;
     const bool pow2 = (tpp & (tpp - 1)) == 0 && tpp <= 32;
     if (pow2) {       // uniform; every thread of the block is active when tpp divides 256
@@ -55,7 +55,7 @@ __device__ __forceinline__ void reduce_rows(float (&v)[NV][PIECE], float* lds, i
             for (int a = 0; a < NV; ++a)
 #pragma unroll
                 for (int e = 0; e < PIECE; ++e) v[a][e] = 0.f;
-            for (int w = 0; w < nwaves; ++w) {
+            for (int w = 0; w < NT / 64; ++w) {
                 const float* s = lds + ((size_t)w * tpp + piece) * stride;
 #pragma unroll
                 for (int a = 0; a < NV; ++a)
@@ -446,17 +446,13 @@ __global__ __launch_bounds__(NT) void stats_small_kernel(const T* __restrict__ z
     }
 }
 
-// NTB threads per workgroup (round 3): these launches are latency-bound -- one workgroup per (image, 64 channels) walks its
-// pixels twice with 8 loads in flight per thread -- so up to 16 waves per workgroup (one or two pixels per thread) put 4x
-// the loads in flight per CU: 32^2 x 256 channels 45 -> see profiles/r03_norm_small.txt
-template <typename T, int NTB>
-__global__ __launch_bounds__(NTB) void bwd_small_kernel(T* __restrict__ g, const T* __restrict__ z,
-                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                        float slope, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                        float* __restrict__ dbias, int N, int HW, int C) {
+template <typename T>
+__global__ __launch_bounds__(NT) void bwd_small_kernel(T* __restrict__ g, const T* __restrict__ z,
+                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       float slope, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                       float* __restrict__ dbias, int N, int HW, int C) {
     constexpr int PIECE = Elem<T>::PIECE;
-    constexpr int SR = NTB / SG;      // pixel rows per workgroup (shadows the 256-thread constant)
-    __shared__ float lds[(NTB / 64) * SG * 2 * PIECE];
+    __shared__ float lds[(NT / 64) * SG * 2 * PIECE];
     __shared__ float sums[SG][2 * PIECE];
     const int n = blockIdx.x;
     const int pl = threadIdx.x & (SG - 1), prow = threadIdx.x / SG;
@@ -502,7 +498,7 @@ __global__ __launch_bounds__(NTB) void bwd_small_kernel(T* __restrict__ g, const
             sum1(zv, gv);
         }
     }
-    reduce_rows<2, PIECE>(acc, lds, pl, prow, SR, SG, true, NTB / 64);
+    reduce_rows<2, PIECE>(acc, lds, pl, prow, SR, SG, true);
     if (prow == 0) {
 #pragma unroll
         for (int e = 0; e < PIECE; ++e) {
@@ -560,7 +556,7 @@ __global__ __launch_bounds__(NTB) void bwd_small_kernel(T* __restrict__ g, const
     }
     if (dbias) {
         __syncthreads();
-        reduce_rows<1, PIECE>(db, lds, pl, prow, SR, SG, true, NTB / 64);
+        reduce_rows<1, PIECE>(db, lds, pl, prow, SR, SG, true);
         if (active && prow == 0) {
 #pragma unroll
             for (int e = 0; e < PIECE; ++e) unsafeAtomicAdd(dbias + piece * PIECE + e, db[0][e]);
@@ -1058,16 +1054,8 @@ static int launch_bwd(int nimg, int N, int HW, int C, void* g, const void* z, co
     const RowMap rm = row_map(C, PIECE);
     if (HW <= 1024 && !det) {       // small feature maps: one fused launch
         dim3 sgrid(nimg, cdiv(C / PIECE, SG));
-        // threads: one pixel row per thread row up to 1024 threads (16 waves hide the two dependent passes' latency)
-        if (HW * SG >= 1024)
-            hipLaunchKernelGGL((bwd_small_kernel<T, 1024>), sgrid, dim3(1024), 0, st, (T*)g, (const T*)z, stats, gamma, slope,
-                               dgamma, dbeta, dbias, N, HW, C);
-        else if (HW * SG >= 512)
-            hipLaunchKernelGGL((bwd_small_kernel<T, 512>), sgrid, dim3(512), 0, st, (T*)g, (const T*)z, stats, gamma, slope,
-                               dgamma, dbeta, dbias, N, HW, C);
-        else
-            hipLaunchKernelGGL((bwd_small_kernel<T, 256>), sgrid, dim3(256), 0, st, (T*)g, (const T*)z, stats, gamma, slope,
-                               dgamma, dbeta, dbias, N, HW, C);
+        hipLaunchKernelGGL(bwd_small_kernel<T>, sgrid, dim3(NT), 0, st, (T*)g, (const T*)z, stats, gamma, slope, dgamma, dbeta,
+                           dbias, N, HW, C);
         CU_LAUNCH_CHECK();
         return 0;
     }

@@ -32,12 +32,18 @@ class CapturedStep:
                 self._step(i)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self._capture()
+        self.warmup_steps = warmup
+
+    def _capture(self):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.logs = self._step(0)
         # the capture ran the optimizer's host code (its per-parameter step counters moved) but no kernel
         self.optimizer.note_replayed_steps(-1)
-        self.warmup_steps = warmup
+        # lr, betas, eps, weight decay and the gradient scale are scalar arguments of the captured launches:
+        # an LR scheduler or a param_group edit after the capture must not be ignored by the replays
+        self._hyper = self.optimizer.hyper_key()
 
     def _step(self, i):
         self.optimizer.zero_grad(set_to_none=True)
@@ -49,6 +55,11 @@ class CapturedStep:
         return out
 
     def replay(self):
+        if self.optimizer.hyper_key() != self._hyper:       # hyper-parameters changed since the capture: capture again
+            torch.cuda.synchronize()
+            self.optimizer.note_replayed_steps(self.replays)
+            self.replays = 0
+            self._capture()
         self.graph.replay()
         self.replays += 1
 

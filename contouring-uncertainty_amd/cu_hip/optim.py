@@ -152,6 +152,18 @@ class FusedAdam(torch.optim.Optimizer):
             ops.step_advance(self._steps_dev)
         return loss
 
+    def load_state_dict(self, state_dict):
+        """``torch.optim.Adam`` layout in; the device step counter and the flat moment buffers of an optimizer that has
+        already stepped belong to the OLD state: both are dropped and rebuilt from what was loaded at the next
+        ``step`` (``_moments`` re-packs the per-parameter tensors, the counter restarts from the loaded ``step``)."""
+        super().load_state_dict(state_dict)
+        self._steps_dev = None
+        self._flat.clear()
+
+    def hyper_key(self):
+        """the scalars a captured step bakes into its launches (cu_hip.graph.CapturedStep re-captures when they change)"""
+        return tuple((g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]) for g in self.param_groups) + (self.grad_scale,)
+
     def note_replayed_steps(self, k: int):
         """A captured step was replayed k times: bring the per-parameter host counters (state_dict) up to date."""
         for st in self.state.values():

@@ -91,3 +91,35 @@ def test_captured_step_replays_like_the_eager_step():
         assert ma.shape == mb.shape and float((ma - mb).norm() / ma.norm()) < tol, (key, float((ma - mb).norm() / ma.norm()))
     st = copt.state[next(iter(task.model.parameters()))]
     assert float(st["step"]) == 7.0 and int(copt._steps_dev.item()) == 7
+
+
+def test_changed_hyper_parameters_recapture_and_loaded_state_restarts_the_device_counter():
+    """lr / betas / weight decay / grad_scale are scalar arguments of the captured launches -- a changed value
+    must reach the replays (re-capture); ``load_state_dict`` on an optimizer that has stepped must not keep the old device
+    step counter (the bias correction would be wrong)."""
+    from contour_uncertainty.data.synthetic import synthetic_batch
+    from cu_hip.graph import CapturedStep
+    img, contour = synthetic_batch(2, 64, 21, seed=4)
+    batch = {"img": img.cuda(), "contour": contour.cuda()}
+    task = _build(True)
+    copt = task.configure_optimizers()["optimizer"]
+    step = CapturedStep(task, copt, batch, warmup=2)
+    step.replay()
+    w = task.model.flat_params()[0].clone()
+    copt.param_groups[0]["lr"] = 0.0                 # scheduler / manual edit after the capture
+    step.replay()
+    assert step._hyper == copt.hyper_key() and copt.param_groups[0]["lr"] == 0.0
+    # lr 0 and weight decay folded into the gradient only: the parameters must not move in the re-captured replay
+    assert torch.equal(task.model.flat_params()[0], w)
+    step.finish()
+    sd = copt.state_dict()
+    n_steps = float(next(iter(copt.state.values()))["step"])
+    fresh = _build(True)
+    fopt = fresh.configure_optimizers()["optimizer"]
+    fresh.model.load_state_dict(task.model.state_dict())
+    out = fresh.training_step(batch, 0); out["loss"].backward(); fopt.step()          # the optimizer has stepped once
+    fopt.load_state_dict(sd)
+    assert fopt._steps_dev is None and not fopt._flat
+    fopt.zero_grad(set_to_none=True)
+    out = fresh.training_step(batch, 1); out["loss"].backward(); fopt.step()
+    assert int(fopt._steps_dev.item()) == int(n_steps) + 1

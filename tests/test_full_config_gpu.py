@@ -102,3 +102,28 @@ def test_loss_falls_on_a_fixed_batch(setup):
         losses.append(float(out["loss"].detach()))
     assert all(map(lambda v: v == v and abs(v) < 1e6, losses))
     assert losses[-1] < losses[0]
+
+
+def test_lazy_activation_mode_matches_the_default_step():
+    """``engine.lazy_act`` (normalise-on-load: round 3, off by default -- profiles/r03_lazy_act.txt) keeps only raw conv outputs
+    + statistics at the thin levels and lets the streaming conv / weight-gradient kernels apply InstanceNorm + LeakyReLU in
+    LDS.  Same bf16 operands, same MFMA order: loss and gradients of a full-size step equal the default (materialised) step
+    up to the f32 atomics' order noise of the statistics."""
+    import torch
+    from bench import build_task
+    from contour_uncertainty.data.synthetic import synthetic_batch
+    img, contour = synthetic_batch(16, 256, 21, seed=7)
+    batch = {"img": img.cuda(), "contour": contour.cuda()}
+    res = []
+    for lazy in (False, True):
+        task, _ = build_task(256, "bf16", "dsnt-skew")
+        task = task.cuda()
+        task.model.engine.lazy_act = lazy
+        out = task.training_step(batch, 0)
+        out["loss"].backward()
+        res.append((float(out["loss"]), {n: p.grad.clone() for n, p in task.model.named_parameters() if p.grad is not None}))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[0][0])
+    for n in ("input_block.conv2.conv.weight", "upsamples.6.conv_block.conv2.conv.weight", "downsamples.0.conv2.conv.weight",
+              "output_block.conv.weight", "bottleneck.conv1.conv.weight"):
+        a, b = res[0][1][n], res[1][1][n]
+        assert float((a - b).norm() / a.norm()) < 2e-3, n

@@ -14,8 +14,10 @@ a second HIP stream; up to 16 images per GPU (one GPU) the step is replayed as o
 Prints ONE JSON line on rank 0 with the driver's contract plus:
   roofline     : the dominant kernel family (MFMA implicit-GEMM convolution), algorithmic FLOPs / measured launch time
                  (HIP events on the launch stream, in a separate profiled pass after the timed region, with the step on
-                 ONE stream so that an event pair times one launch) vs 2.5 PFLOP/s; traffic = HBM bytes per launch from
-                 the committed PMC passes (profiles/r02_pmc_hbm_traffic.json).
+                 ONE stream so that an event pair times one launch) vs 2.5 PFLOP/s, from ALGORITHMIC FLOPs; traffic = HBM
+                 bytes per launch from the newest committed PMC passes (profiles/r0N_pmc_hbm_traffic.json; a constant).
+  parity       : f32 mu / Sigma / alpha vs the reference's own outputs and bf16-vs-f32 NLL after 20 steps (smoke size).
+  multi_gpu    : N > 1: world / devices, parameter checksums of all ranks, exposed communication time.
   cpu_baseline : the CPU oracle (PyTorch-CPU restatement of the reference step, kind "port") timed on this box's host
                  cores on a bounded sample of the same workload.
 """
@@ -40,7 +42,7 @@ PEAK_BF16_DENSE = 2.5e15     # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
 PEAK_HBM = 8.0e12
 
 
-def build_task(size: int, dtype: str, task_name: str):
+def build_task(size: int, dtype: str, task_name: str, backbone: str = "unet2"):
     from contour_uncertainty._compat import DataParameters
     from contour_uncertainty.task.regression.dsnt.dsnt_al import DSNTAleatoric
     from contour_uncertainty.task.regression.dsnt.dsnt_skew import DSNTSkew
@@ -48,6 +50,9 @@ def build_task(size: int, dtype: str, task_name: str):
     model_cfg = {"_target_": "contour_uncertainty.models.nnUnet.unet2.UNet", "kernels": [[3, 3]] * n_stages,
                  "strides": [[1, 1]] + [[2, 2]] * (n_stages - 1), "patch_size": [256, 256], "drop_block": False,
                  "deep_supervision": False, "compute_dtype": dtype}
+    if backbone == "vital":     # `task/model=unet`: the `vital` BatchNorm U-Net (north_star's second backbone; secondary number)
+        model_cfg = {"_target_": "contour_uncertainty.models.vital.unet.UNet", "init_channels": 32, "use_batchnorm": True,
+                     "bilinear": False, "dropout": 0.0, "compute_dtype": dtype, "drop_block": False}
     cls = DSNTSkew if task_name == "dsnt-skew" else DSNTAleatoric
     torch.manual_seed(0)
     task = cls(model=model_cfg, optim={"_target_": "torch.optim.Adam", "lr": 1e-3, "weight_decay": 1e-3}, choices={},
@@ -150,6 +155,9 @@ def main():
                          "most 16 images per GPU, where the eager step is bound by its ~320 host launches (from 32 images "
                          "on the eager step is faster: its weight-gradient stream runs beside the main one, which a "
                          "replayed graph serialises -- profiles/r02_small_batch_graph.txt)")
+    ap.add_argument("--backbone", default="unet2", choices=["unet2", "vital"],
+                    help="unet2 = the headline network; vital = `task/model=unet` (BatchNorm U-Net, dsnt-al only): a secondary "
+                         "number, no roofline / CPU baseline / parity legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-comm-probe", action="store_true",
@@ -180,7 +188,10 @@ def main():
     from contour_uncertainty.data.synthetic import synthetic_batch   # SURVEY 8d synthetic inputs
 
     task_name = "dsnt-al" if args.task == "dsnt-al2" else args.task
-    task, n_stages = build_task(args.size, args.dtype, task_name)
+    if args.backbone == "vital":
+        assert task_name == "dsnt-al", "the vital U-Net has no bottleneck output: --task dsnt-al"
+        args.no_roofline = args.no_cpu_baseline = args.no_parity = True
+    task, n_stages = build_task(args.size, args.dtype, task_name, args.backbone)
     task = task.to(dev)
     sync = GradSync(task)
     sync.broadcast_parameters()
@@ -285,13 +296,17 @@ def main():
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"task={args.task} {args.size}x{args.size}x1, K=21, {n_stages}-stage unet2, "
+            "config": {"workload": f"task={args.task} {args.size}x{args.size}x1, K=21, "
+                                   + (f"{n_stages}-stage unet2, " if args.backbone == "unet2" else "vital U-Net (BatchNorm), ") +
                                    f"batch {per_gpu}/GPU, Adam(lr=1e-3, wd=1e-3)",
                        "per_gpu_batch": per_gpu, "global_batch": per_gpu * world,
                        "launch": "hipGraph replay" if captured is not None else "eager",
                        "parallelism": f"dp{world}", "final_loss": round(loss, 4),
                        "mfma_roofline_frac_whole_step": round(value / world * flops_step_img / PEAK_BF16_DENSE, 4)},
         }
+        if args.backbone != "unet2":
+            result["metric"] += " (vital U-Net backbone: secondary)"
+            result["config"].pop("mfma_roofline_frac_whole_step")
         if multi is not None:
             result["multi_gpu"] = multi
 

@@ -193,7 +193,17 @@ def main():
         args.no_roofline = args.no_cpu_baseline = args.no_parity = True
     task, n_stages = build_task(args.size, args.dtype, task_name, args.backbone)
     task = task.to(dev)
-    sync = GradSync(task)
+    if args.backbone == "vital":
+        assert world == 1, "the BatchNorm U-Net has no bucketed exchange: one GPU"
+
+        class _NoSync:      # single rank: nothing to exchange
+            grad_scale, native = 1.0, None
+
+            def broadcast_parameters(self): pass
+            def finish(self): pass
+        sync = _NoSync()
+    else:
+        sync = GradSync(task)
     sync.broadcast_parameters()
     if args.scaling == "strong":
         assert args.batch % world == 0, "strong scaling: --batch (global) must divide by the number of GPUs"

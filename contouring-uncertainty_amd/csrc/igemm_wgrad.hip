@@ -996,9 +996,11 @@ static int wgrad_impl(const cu_wgrad_desc* d, const void* src0, const float* sca
         a.src0_bytes = (unsigned)b0; a.src1_bytes = (unsigned)b1; a.z_bytes = (unsigned)bz;
         a.xstat_bytes = (unsigned)((size_t)2 * d->N * d->C0 * 4);
         {
-            static const int pcf = cu_env_int("CU_WGRAD_PCF", 70);      // percent of the rounds (measured optimum 65-75)
+            // round 3 (profiles/r03_wgrad_pc_sweep.txt; in the step, alternating runs: 13.67 / 13.71 ms against 13.83 / 13.85
+            // at 0 / 70 %): the computing waves issue 4 rounds BEFORE their k-loop, the producer waves all the others
+            static const int pcf = cu_env_int("CU_WGRAD_PCF", 100);     // percent of the remaining rounds issued by the producers
             const int n = a.s_iters + a.z_iters;
-            static const int pce = cu_env_int("CU_WGRAD_PCE", 0);
+            static const int pce = cu_env_int("CU_WGRAD_PCE", 4);
             a.pc_early = pce < n ? pce : n;
             a.pc_items = a.pc_early + ((n - a.pc_early) * pcf + 99) / 100;
             if (a.pc_items > n) a.pc_items = n;

@@ -977,8 +977,10 @@ static int wgrad_impl(const cu_wgrad_desc* d, const void* src0, const float* sca
             }
             a.src0_bytes = (unsigned)b0; a.src1_bytes = (unsigned)b1; a.z_bytes = (unsigned)bz;
             const int n = a.s_iters + a.z_iters;
-            a.pc_early = 0;
-            a.pc_items = (n * 70 + 99) / 100;
+            static const int dpe = cu_env_int("CU_WGRAD_DPCE", 4), dpf = cu_env_int("CU_WGRAD_DPCF", 100);   // as the stride-1 form
+            a.pc_early = dpe < n ? dpe : n;
+            a.pc_items = a.pc_early + ((n - a.pc_early) * dpf + 99) / 100;
+            if (a.pc_items > n) a.pc_items = n;
             const bool rowk = a.twl >= 4;
             if (nb == 4) return rowk ? launch_dma<4, 1, 9, 8, true, true>(a, st) : launch_dma<4, 1, 9, 8, true, false>(a, st);
             return rowk ? launch_dma<2, 1, 9, 8, true, true>(a, st) : launch_dma<2, 1, 9, 8, true, false>(a, st);

@@ -11,17 +11,21 @@ namespace {
 // One thread = one 16-byte piece of channels for C1_PX consecutive pixels of a row: the 9 x PIECE weights are loaded once
 // per thread and the 3 x (C1_PX + 2) image window slides (the first version reloaded 72 weights per output piece).
 constexpr int C1_PX = 8;
-template <typename T>
+// MODE 0: z = conv + bias -> dst.
+// MODE 2 (round 3): z -> dst AND LeakyReLU(z * scale + shift) -> dst2 from finished statistics (stats planes 2 and 3, see
+//         c1_moments_kernel): the layer's conv and apply passes in one, each tensor written once and none re-read.
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                           const float* __restrict__ bias, T* __restrict__ dst, int N,
-                                                          int H, int W, int CO) {
+                                                          int H, int W, int CO, const float* __restrict__ stats,
+                                                          float slope, T* __restrict__ dst2) {
     constexpr int PIECE = Elem<T>::PIECE;
     const int ppp = CO / PIECE;
     const int wgroups = (W + C1_PX - 1) / C1_PX;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t total = (size_t)N * H * wgroups * ppp;
     if (i >= total) return;
-    const int piece = i % ppp;
+    const int piece = (int)(i % ppp);
     size_t r = i / ppp;
     const int x0 = (int)(r % wgroups) * C1_PX; r /= wgroups;
     const int y = (int)(r % H);
@@ -33,6 +37,12 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
         for (int e = 0; e < PIECE; ++e) wr[t][e] = w[t * CO + piece * PIECE + e];
 #pragma unroll
     for (int e = 0; e < PIECE; ++e) b[e] = bias ? bias[piece * PIECE + e] : 0.f;
+    float sc[MODE == 2 ? PIECE : 1], sh[MODE == 2 ? PIECE : 1];
+    if constexpr (MODE == 2) {
+        const size_t NC = (size_t)N * CO, si = (size_t)n * CO + piece * PIECE;
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) { sc[e] = stats[2 * NC + si + e]; sh[e] = stats[3 * NC + si + e]; }
+    }
     float win[3][C1_PX + 2];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
@@ -55,8 +65,115 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
 #pragma unroll
             for (int e = 0; e < PIECE; ++e) acc[e] += v * wr[t][e];
         }
-        store_piece<T>(dst + (((size_t)n * H + y) * W + x0 + k) * CO + piece * PIECE, acc);
+        const size_t o = (((size_t)n * H + y) * W + x0 + k) * CO + piece * PIECE;
+        store_piece<T>(dst + o, acc);
+        if constexpr (MODE == 2) {
+            float a[PIECE];
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) {
+                float zr = acc[e];
+                if constexpr (sizeof(T) == 2) zr = bf16_to_f32(f32_to_bf16(zr));
+                const float yv = zr * sc[e] + sh[e];
+                a[e] = yv > 0.f ? yv : yv * slope;
+            }
+            store_piece<T>(dst2 + o, a);
+        }
     }
+}
+
+// InstanceNorm statistics of the first layer's z = conv3x3(img) + bias WITHOUT computing z: z is linear in the image, so
+//   sum_p (z - bias)[c]   = sum_t w[t][c] S[t],           S[t]     = sum_p x[p + t]
+//   sum_p (z - bias)[c]^2 = sum_{t,u} w[t][c] w[u][c] R[t][u],  R[t][u] = sum_p x[p + t] x[p + u]
+// with x zero outside the image (the conv's padding): 9 + 45 moments per image gathered in one pass over the IMAGE
+// (17 MB at batch 64, against 268 MB for a statistics pass over z).  One thread = C1M_PX pixels of a row; per-workgroup
+// partial moments go to part[n][wg][54] and are summed in workgroup order by c1_stats_kernel: deterministic.  The
+// statistics are those of z BEFORE its rounding to the storage type, as in the streaming kernel's epilogue (tconv.hip).
+constexpr int C1M_PX = 16;
+constexpr int C1M_N = 54;
+__global__ __launch_bounds__(256) void c1_moments_kernel(const float* __restrict__ img, float* __restrict__ part, int H, int W) {
+    __shared__ float red[4][C1M_N];
+    const int n = blockIdx.y;
+    const int segs = (W + C1M_PX - 1) / C1M_PX;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    float m[C1M_N];
+#pragma unroll
+    for (int j = 0; j < C1M_N; ++j) m[j] = 0.f;
+    if (s < H * segs) {
+        const int y = s / segs, x0 = (s % segs) * C1M_PX;
+        float win[3][C1M_PX + 2];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int sy = y + dy - 1;
+#pragma unroll
+            for (int k = 0; k < C1M_PX + 2; ++k) {
+                const int sx = x0 + k - 1;
+                win[dy][k] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? img[((size_t)n * H + sy) * W + sx] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < C1M_PX; ++k) {
+            const float live = x0 + k < W ? 1.f : 0.f;
+            float v[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[t] = win[t / 3][k + t % 3] * live;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                m[t] += v[t];
+#pragma unroll
+                for (int u = t; u < 9; ++u) {
+                    const int j = 9 + t * 9 - t * (t - 1) / 2 + (u - t);        // row t of the upper triangle
+                    m[j] = fmaf(v[t], v[u], m[j]);
+                }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < C1M_N; ++j) {
+        float v = m[j];
+        for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[wave][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < C1M_N)
+        part[((size_t)n * gridDim.x + blockIdx.x) * C1M_N + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// moments -> the four statistics planes (mean, rstd, scale, shift) of cu_instnorm_stats.  One thread per (n, c); the 81-term
+// quadratic form in double (it cancels: mean^2 against the second moment).
+__global__ void c1_stats_kernel(const float* __restrict__ part, int nwg, const float* __restrict__ w,
+                                const float* __restrict__ bias, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float eps, float* __restrict__ stats, int N, int HW, int CO) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * CO) return;
+    const int n = i / CO, c = i % CO;
+    double m[C1M_N];
+    for (int j = 0; j < C1M_N; ++j) {
+        double a = 0.0;
+        for (int g = 0; g < nwg; ++g) a += (double)part[((size_t)n * nwg + g) * C1M_N + j];
+        m[j] = a;
+    }
+    double wt[9];
+    for (int t = 0; t < 9; ++t) wt[t] = (double)w[t * CO + c];
+    double s1 = 0.0, s2 = 0.0;
+    int j = 9;
+    for (int t = 0; t < 9; ++t) {
+        s1 += wt[t] * m[t];
+        for (int u = t; u < 9; ++u) s2 += (u == t ? 1.0 : 2.0) * wt[t] * wt[u] * m[j + u - t];
+        j += 9 - t;
+    }
+    const double inv = 1.0 / (double)HW;
+    const double m1 = s1 * inv, m2 = s2 * inv;
+    const double var = fmax(m2 - m1 * m1, 0.0);
+    const float mean = (float)((bias ? (double)bias[c] : 0.0) + m1);
+    const float rstd = 1.f / sqrtf((float)var + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const size_t NC = (size_t)N * CO;
+    stats[i] = mean;
+    stats[NC + i] = rstd;
+    stats[2 * NC + i] = g * rstd;
+    stats[3 * NC + i] = b - mean * g * rstd;
 }
 
 template <typename T>
@@ -599,9 +716,43 @@ extern "C" int cu_conv_c1_fwd(int dtype, int N, int H, int W, int CO, const floa
     const unsigned blocks = (unsigned)((total + 255) / 256);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == CU_BF16)
-        hipLaunchKernelGGL(conv_c1_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, img, w, bias, (bf16_t*)dst, N, H, W, CO);
+        hipLaunchKernelGGL((conv_c1_fwd_kernel<bf16_t, 0>), dim3(blocks), dim3(256), 0, st, img, w, bias, (bf16_t*)dst, N, H,
+                           W, CO, (const float*)nullptr, 0.f, (bf16_t*)nullptr);
     else
-        hipLaunchKernelGGL(conv_c1_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, img, w, bias, (float*)dst, N, H, W, CO);
+        hipLaunchKernelGGL((conv_c1_fwd_kernel<float, 0>), dim3(blocks), dim3(256), 0, st, img, w, bias, (float*)dst, N, H, W,
+                           CO, (const float*)nullptr, 0.f, (float*)nullptr);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t cu_conv_c1_norm_ws_floats(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t nwg = ((size_t)H * ((W + C1M_PX - 1) / C1M_PX) + 255) / 256;
+    return (size_t)N * nwg * C1M_N;
+}
+
+extern "C" int cu_conv_c1_fwd_norm(int dtype, int N, int H, int W, int CO, const float* img, const float* w,
+                                   const float* bias, const float* gamma, const float* beta, float eps, float slope,
+                                   float* ws, float* stats, void* z, void* a, void* stream) {
+    CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_conv_c1_fwd_norm: bad dtype");
+    const int PIECE = dtype == CU_BF16 ? 8 : 4;
+    CU_CHECK_ARG(N > 0 && N < 65536 && H > 0 && W > 0 && CO > 0 && CO % PIECE == 0 && img && w && ws && stats && z && a,
+                 "cu_conv_c1_fwd_norm: bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const unsigned nwg = (unsigned)(((size_t)H * ((W + C1M_PX - 1) / C1M_PX) + 255) / 256);
+    hipLaunchKernelGGL(c1_moments_kernel, dim3(nwg, N), dim3(256), 0, st, img, ws, H, W);
+    CU_LAUNCH_CHECK();
+    hipLaunchKernelGGL(c1_stats_kernel, dim3(cdiv(N * CO, 64)), dim3(64), 0, st, (const float*)ws, (int)nwg, w, bias, gamma,
+                       beta, eps, stats, N, H * W, CO);
+    CU_LAUNCH_CHECK();
+    const size_t total = (size_t)N * H * ((W + C1_PX - 1) / C1_PX) * (CO / PIECE);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL((conv_c1_fwd_kernel<bf16_t, 2>), dim3(blocks), dim3(256), 0, st, img, w, bias, (bf16_t*)z, N, H, W,
+                           CO, (const float*)stats, slope, (bf16_t*)a);
+    else
+        hipLaunchKernelGGL((conv_c1_fwd_kernel<float, 2>), dim3(blocks), dim3(256), 0, st, img, w, bias, (float*)z, N, H, W, CO,
+                           (const float*)stats, slope, (float*)a);
     CU_LAUNCH_CHECK();
     return 0;
 }

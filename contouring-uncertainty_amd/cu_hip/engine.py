@@ -128,6 +128,9 @@ class UNetEngine:
         # OFF by default: measured on MI355X (profiles/r03_lazy_act.txt) the in-LDS rewrite costs the streaming kernel and
         # the weight-gradient kernel as much as the apply pass it removes (both are latency-bound per tile, not HBM-bound)
         self.lazy_act = os.environ.get("CONTOUR_LAZY_ACT", "0") == "1"
+        # True: the first layer (Cin = 1) derives its InstanceNorm statistics from moments of the image and writes z and a in one pass
+        # (cu_conv_c1_fwd_norm) instead of conv -> statistics pass over z -> apply pass
+        self.first_fused = os.environ.get("CONTOUR_FIRST_FUSED", "1") == "1"
         # True: InstanceNorm + LeakyReLU forward (statistics + materialise) and backward (reduce + apply) each run as ONE
         # resident-chunk launch that reads every tensor once (norm.hip); False: the two-pass kernels
         self.fused_norm = True
@@ -284,9 +287,14 @@ class UNetEngine:
             self._opcache[prefix] = (key, w9, None)
         w9 = self._opcache[prefix][1]
         n, _, h, w_ = img.shape
-        z = torch.empty((n, h, w_, co), dtype=self.dtype, device=img.device)
-        ops.conv_c1_fwd(img, w9, P[f"{prefix}.conv.bias"], z)
-        out = self._norm_act_fwd(P, prefix, z, ctx)
+        if self.first_fused and self.fused_norm and self.materialize and self.debug is None:
+            # statistics from moments of the image, then z and a in one pass (no pass over z between conv and apply)
+            out = ops.conv_c1_fwd_norm(img, w9, P[f"{prefix}.conv.bias"], P[f"{prefix}.norm.weight"],
+                                       P[f"{prefix}.norm.bias"], self.slope, self.eps, self.dtype)
+        else:
+            z = torch.empty((n, h, w_, co), dtype=self.dtype, device=img.device)
+            ops.conv_c1_fwd(img, w9, P[f"{prefix}.conv.bias"], z)
+            out = self._norm_act_fwd(P, prefix, z, ctx)
         if not ctx.keep and out.a is not None:
             return Act(out.a, None, 1.0)
         ctx.convs[prefix] = _ConvRec(prefix, [], out, 1, first=True)

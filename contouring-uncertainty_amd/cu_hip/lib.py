@@ -58,6 +58,8 @@ _SIGS = {
     "cu_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc)] + [_P] * 9),
     "cu_conv_wgrad_parts": (C.c_int, [C.POINTER(WgradDesc)] + [_P] * 8 + [C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
     "cu_conv_c1_fwd": (C.c_int, [C.c_int] * 5 + [_P] * 5),
+    "cu_conv_c1_norm_ws_floats": (C.c_size_t, [C.c_int] * 3),
+    "cu_conv_c1_fwd_norm": (C.c_int, [C.c_int] * 5 + [_P] * 5 + [C.c_float] * 2 + [_P] * 5),
     "cu_conv_c1_wgrad": (C.c_int, [C.c_int] * 5 + [_P] * 4),
     "cu_conv_c1_wgrad_det": (C.c_int, [C.c_int] * 5 + [_P] * 4 + [C.c_size_t, _P]),
     "cu_instnorm_stats": (C.c_int, [C.c_int] * 4 + [_P] * 3 + [C.c_float] + [_P] * 3),

@@ -219,6 +219,23 @@ def conv_c1_fwd(img: Tensor, w9: Tensor, bias: Optional[Tensor], dst: Tensor):
                                         L.ptr(dst), L.stream_ptr()), "cu_conv_c1_fwd")
 
 
+def conv_c1_fwd_norm(img: Tensor, w9: Tensor, bias: Optional[Tensor], gamma: Optional[Tensor], beta: Optional[Tensor],
+                     slope: float, eps: float, dtype) -> Act:
+    """first layer conv -> InstanceNorm -> LeakyReLU with the statistics derived from moments of the image and z, a written
+    by one pass (cu_conv_c1_fwd_norm) -> Act(z, stats, a)."""
+    n, _, h, w_ = img.shape
+    co = w9.shape[1]
+    z = torch.empty((n, h, w_, co), dtype=dtype, device=img.device)
+    a = torch.empty_like(z)
+    stats = torch.empty((4, n, co), dtype=torch.float32, device=img.device)
+    sums = torch.empty((L.load().cu_conv_c1_norm_ws_floats(n, h, w_),), dtype=torch.float32, device=img.device)
+    with _Prof("conv_c1", 0.0, f"N{n} {h}x{w_} C{co} +norm", 2 * z.numel() * z.element_size()):
+        L.check(L.load().cu_conv_c1_fwd_norm(L.dtype_code(dtype), n, h, w_, co, L.ptr(img), L.ptr(w9), L.ptr(bias),
+                                             L.ptr(gamma), L.ptr(beta), eps, slope, L.ptr(sums), L.ptr(stats), L.ptr(z),
+                                             L.ptr(a), L.stream_ptr()), "cu_conv_c1_fwd_norm")
+    return Act(z, stats, slope, a, None)
+
+
 def conv_c1_wgrad(img: Tensor, dz: Tensor, dw9: Tensor, det_ws: Optional[Tensor] = None):
     """``det_ws`` (float32 workspace): per-workgroup partial sums + a fixed-order finish instead of atomics."""
     n, h, w_, co = dz.shape

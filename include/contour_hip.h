@@ -151,6 +151,17 @@ int cu_conv_wgrad_parts(const cu_wgrad_desc* d,
 /* First layer, Cin = 1 (input_block.conv1.conv, unet2.py:113-119): direct 3x3 conv of the f32 image. */
 int cu_conv_c1_fwd(int dtype, int N, int H, int W, int CO, const float* img /* [N][H][W] */,
                    const float* w /* [9][CO] f32 */, const float* bias, void* dst /* NHWC */, void* stream);
+/* The first layer's conv -> InstanceNorm -> LeakyReLU (layers.py:192-194) without a statistics pass over z and without a
+ * separate apply pass.  z is linear in the image, so its per-(image, channel) mean and variance follow from 9 + 45 moments
+ * of the image (sums of shifted pixels and of their pairwise products, zero outside the image like the conv's padding):
+ * (1) one pass over the IMAGE gathers them (per-workgroup partials in ws, summed in a fixed order: deterministic),
+ * (2) the four stats planes of cu_instnorm_stats, (3) one pass writes z AND a = LeakyReLU(z*scale + shift).
+ * z is bit-identical to cu_conv_c1_fwd's; the statistics are those of z before its rounding to the storage type (as in
+ * cu_conv_gemm_stats).  ws: f32 scratch of cu_conv_c1_norm_ws_floats(N, H, W) elements, contents irrelevant on entry. */
+size_t cu_conv_c1_norm_ws_floats(int N, int H, int W);
+int cu_conv_c1_fwd_norm(int dtype, int N, int H, int W, int CO, const float* img, const float* w, const float* bias,
+                        const float* gamma, const float* beta, float eps, float slope, float* ws, float* stats,
+                        void* z, void* a, void* stream);
 int cu_conv_c1_wgrad(int dtype, int N, int H, int W, int CO, const float* img, const void* dz /* NHWC */,
                      float* dw /* [9][CO] f32, += */, void* stream);
 /* The same with the workgroups' partial sums stored in ws (>= (rows chunks x N) x 9 x CO floats; 2^20 covers every shape

@@ -228,6 +228,43 @@ def test_first_conv(dtype, geom):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", [(3, 64, 64, 32), (5, 256, 256, 32), (2, 32, 128, 16), (2, 19, 45, 8), (1, 3, 5, 32)])
+def test_first_conv_with_norm(dtype, geom):
+    """cu_conv_c1_fwd_norm (statistics from 54 moments of the image, z and a written by one pass) against the three-launch
+    form it replaces and against F.instance_norm of the unrounded conv: z bit-identical, statistics to f32 rounding, a to
+    one rounding step of the storage type; bit-identical run to run."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(14)
+    n, hh, ww, co = geom
+    img = torch.rand(n, 1, hh, ww, device=DEV, generator=g) + 0.5          # a mean well above the spread: cancellation
+    w = torch.randn(co, 1, 3, 3, device=DEV, generator=g)
+    w[0] -= w[0].mean()                                                     # an edge filter: output mean ~ 0
+    b = torch.randn(co, device=DEV, generator=g) * 3
+    gamma = torch.rand(co, device=DEV, generator=g) + 0.5
+    beta = torch.randn(co, device=DEV, generator=g)
+    w9, _ = ops.weight_prep(w, "conv", torch.float32, want_dgrad=False)
+    z = torch.empty(n, hh, ww, co, device=DEV, dtype=dtype)
+    ops.conv_c1_fwd(img, w9, b, z)
+    new = ops.conv_c1_fwd_norm(img, w9, b, gamma, beta, 0.01, 1e-5, dtype)
+    again = ops.conv_c1_fwd_norm(img, w9, b, gamma, beta, 0.01, 1e-5, dtype)
+    assert torch.equal(new.z, z)
+    assert torch.equal(new.stats, again.stats) and torch.equal(new.a, again.a)
+    zd = F.conv2d(img.double(), w.double(), b.double(), padding=1)         # the unrounded conv output
+    mean = zd.mean((2, 3))
+    rstd = (zd.var((2, 3), unbiased=False) + 1e-5).rsqrt()
+    assert rel_err(new.stats[0], mean.float()) < 2e-6
+    assert rel_err(new.stats[1], rstd.float()) < 2e-5
+    old = ops.instnorm_fwd_fused(z, gamma, beta, 0.01, 1e-5)               # statistics of the ROUNDED z
+    assert rel_err(new.stats, old.stats) < (1e-4 if dtype == torch.float32 else 2e-3)
+    step = 2.0 ** -7 if dtype == torch.bfloat16 else 0.0
+    d = (new.a.float() - old.a.float()).abs()
+    # (a 15-pixel image does not average the rounding of z away: the two sets of statistics differ by ~1e-3 there)
+    assert (d <= 2 * step * old.a.float().abs() + (5e-3 if dtype == torch.bfloat16 else 1e-4) * old.a.float().abs().max()).all()
+    ref = F.leaky_relu(F.instance_norm(nchw(z).float(), weight=gamma, bias=beta, eps=1e-5), 0.01)
+    assert rel_err(nchw(new.a), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 32, 64), (3, 480, 4), (2, 128, 16), (64, 480, 2)])
 def test_instnorm_fwd_bwd(dtype, shape):
     """statistics + fused backward vs F.instance_norm -> leaky_relu autograd."""

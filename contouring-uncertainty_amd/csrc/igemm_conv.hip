@@ -1010,6 +1010,162 @@ __global__ __launch_bounds__(256) void ksplit_finish_kernel(const float* __restr
     }
 }
 
+// split-K finish of a TINY feature map (HW <= 64 pixels per image) that also carries the layer's InstanceNorm + LeakyReLU
+// (layers.py:193-194), forward (BWD = false) or backward (BWD = true): at 8x8 and below the separate norm launch is pure
+// latency (13-22 us for kilobytes), and a workgroup here holds whole images -- every (image, channel) statistic is a
+// reduction inside the workgroup, no second pass, no cross-workgroup exchange.
+//   workgroup = (image n, 32 channels); thread = (channel quad q, pixel lane pl of 32) with pixels pl, pl + 32 in registers.
+//   forward : z = T(sum of slices + bias) -> dst; mean / variance of the ROUNDED z (two-pass, in registers) -> the four
+//             statistics planes; a = LeakyReLU(z * scale + shift) -> act_out.
+//   backward: g = T(sum of slices [+ dst]) = dL/da; dst = dL/dz = gamma rstd (gl - mean(gl) - zhat mean(gl zhat)),
+//             gl = g * LeakyReLU'(scale z + shift); dbeta += sum gl, dgamma += sum gl zhat (atomics over the images).
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void ksplit_finish_norm_kernel(const float* __restrict__ ws, size_t slice, int ksplit,
+                                                                 T* __restrict__ dst, const float* __restrict__ bias, int N,
+                                                                 int HW, int C, int accum, const cu_conv_epilogue ep) {
+    __shared__ float red[2][4][64];
+    const int n = blockIdx.y, cb = blockIdx.x * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane & 7, pl = wave * 8 + (lane >> 3);
+    const int c = cb + q * 4;
+    const size_t NC = (size_t)N * C, si = (size_t)n * C + c;
+    // sum of K values per channel over the workgroup's 32 pixel lanes, returned to every thread of the channel quad
+    auto reduce = [&](float* x, int K, int buf) {
+        for (int j = 0; j < K; ++j) {
+            float v = x[j];
+            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (lane < 8) red[buf][wave][q * K + j] = v;
+        }
+        __syncthreads();
+        for (int j = 0; j < K; ++j)
+            x[j] = (red[buf][0][q * K + j] + red[buf][1][q * K + j]) + (red[buf][2][q * K + j] + red[buf][3][q * K + j]);
+    };
+    auto round_t = [](float x) {
+        if constexpr (sizeof(T) == 2) return bf16_to_f32(f32_to_bf16(x));
+        else return x;
+    };
+    auto load_t = [](const T* ptr, float (&o)[4]) {
+        if constexpr (sizeof(T) == 2) {
+            const u32x2 r = *reinterpret_cast<const u32x2*>(ptr);
+            o[0] = __uint_as_float(r[0] << 16); o[1] = __uint_as_float(r[0] & 0xffff0000u);
+            o[2] = __uint_as_float(r[1] << 16); o[3] = __uint_as_float(r[1] & 0xffff0000u);
+        } else {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(ptr);
+            o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
+        }
+    };
+    auto store_t = [](T* ptr, const float (&o)[4]) {
+        if constexpr (sizeof(T) == 2) {
+            u32x2 pk;
+            pk[0] = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+            pk[1] = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+            *reinterpret_cast<u32x2*>(ptr) = pk;
+        } else {
+            *reinterpret_cast<f32x4*>(ptr) = f32x4{o[0], o[1], o[2], o[3]};
+        }
+    };
+    float v[2][4];
+    bool live[2];
+    size_t off[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int px = pl + 32 * it;
+        live[it] = px < HW;
+        off[it] = ((size_t)n * HW + (live[it] ? px : 0)) * C + c;
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live[it]) {
+            a = *reinterpret_cast<const f32x4*>(ws + off[it]);
+            for (int k = 1; k < ksplit; ++k) a += *reinterpret_cast<const f32x4*>(ws + (size_t)k * slice + off[it]);
+            if (bias) a += *reinterpret_cast<const f32x4*>(bias + c);
+            if (accum) {
+                float o[4];
+                load_t(dst + off[it], o);
+                a += f32x4{o[0], o[1], o[2], o[3]};
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[it][e] = round_t(a[e]);
+    }
+    const float inv = 1.f / (float)HW;
+    if constexpr (!BWD) {
+        float s[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = (live[0] ? v[0][e] : 0.f) + (live[1] ? v[1][e] : 0.f);
+        reduce(s, 4, 0);
+        float mean[4], ss[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mean[e] = s[e] * inv;
+            const float d0 = live[0] ? v[0][e] - mean[e] : 0.f, d1 = live[1] ? v[1][e] - mean[e] : 0.f;
+            ss[e] = d0 * d0 + d1 * d1;
+        }
+        reduce(ss, 4, 1);
+        float sc[4], sh[4], rstd[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            rstd[e] = 1.f / sqrtf(ss[e] * inv + ep.eps);
+            sc[e] = (ep.gamma ? ep.gamma[c + e] : 1.f) * rstd[e];
+            sh[e] = (ep.beta ? ep.beta[c + e] : 0.f) - mean[e] * sc[e];
+        }
+        if (pl == 0) {
+            *reinterpret_cast<f32x4*>(ep.stats + si) = f32x4{mean[0], mean[1], mean[2], mean[3]};
+            *reinterpret_cast<f32x4*>(ep.stats + NC + si) = f32x4{rstd[0], rstd[1], rstd[2], rstd[3]};
+            *reinterpret_cast<f32x4*>(ep.stats + 2 * NC + si) = f32x4{sc[0], sc[1], sc[2], sc[3]};
+            *reinterpret_cast<f32x4*>(ep.stats + 3 * NC + si) = f32x4{sh[0], sh[1], sh[2], sh[3]};
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            if (!live[it]) continue;
+            store_t(dst + off[it], v[it]);
+            float a[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = v[it][e] * sc[e] + sh[e];
+                a[e] = y > 0.f ? y : y * ep.slope;
+            }
+            store_t(reinterpret_cast<T*>(ep.act_out) + off[it], a);
+        }
+    } else {
+        const f32x4 mean = *reinterpret_cast<const f32x4*>(ep.stats + si);
+        const f32x4 rstd = *reinterpret_cast<const f32x4*>(ep.stats + NC + si);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(ep.stats + 2 * NC + si);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(ep.stats + 3 * NC + si);
+        float gl[2][4], xh[2][4], s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 0.f;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            float zv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (live[it]) load_t(reinterpret_cast<const T*>(ep.z) + off[it], zv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = zv[e] * sc[e] + sh[e];
+                gl[it][e] = live[it] ? (y > 0.f ? v[it][e] : v[it][e] * ep.slope) : 0.f;
+                xh[it][e] = (zv[e] - mean[e]) * rstd[e];
+                s[2 * e] += gl[it][e];
+                s[2 * e + 1] += gl[it][e] * xh[it][e];
+            }
+        }
+        reduce(s, 8, 0);
+        if (pl == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (ep.dbeta) unsafeAtomicAdd(ep.dbeta + c + e, s[2 * e]);
+                if (ep.dgamma) unsafeAtomicAdd(ep.dgamma + c + e, s[2 * e + 1]);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            if (!live[it]) continue;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = (ep.gamma ? ep.gamma[c + e] : 1.f) * rstd[e] * (gl[it][e] - s[2 * e] * inv - xh[it][e] * s[2 * e + 1] * inv);
+            store_t(dst + off[it], o);
+        }
+    }
+}
+
 }  // namespace
 
 int cu_pconv_try(const cu_conv_desc* d, const void* src0, const void* w, const float* bias, void* dst0, void* stream);
@@ -1293,10 +1449,15 @@ extern "C" int cu_conv_gemm_ex(const cu_conv_desc* d, const void* src0, const fl
                            (d->par_co > 0 && d->DC0 == d->par_co && d->OH == 2 * d->PH && d->OW == 2 * d->PW);
         fin0 = (size_t)d->N * d->OH * d->OW * d->DC0;
         fin1 = d->D0 == d->CO ? 0 : (size_t)d->N * d->OH * d->OW * d->DC1;
+        // a fused norm finish (epilogue modes 3 / 4) is worth a two-way split of its own on 8x8 maps (480 workgroups): the
+        // finish pass replaces a norm launch instead of adding one
+        const bool norm_fin = ep && stats_done && (ep->mode == 3 || ep->mode == 4) && d->OH * d->OW <= 64 &&
+                              !cu_env_set("CU_CONV_NO_NORMFIN8");
         const int max_wgs = cu_env_int("CU_CONV_KSPLIT_WGS", 128);
-        if (ws && !wres && whole && !d->out_nchw_f32 && nchunks >= 4 && wgs <= max_wgs && a.ntiles <= grid_x &&
-            !cu_env_set("CU_CONV_NO_KSPLIT")) {
+        if (ws && !wres && whole && !d->out_nchw_f32 && nchunks >= 4 && (wgs <= max_wgs || (norm_fin && wgs <= 512)) &&
+            a.ntiles <= grid_x && !cu_env_set("CU_CONV_NO_KSPLIT")) {
             int want = (int)(512 / wgs);
+            if (norm_fin && want < 2) want = 2;
             if (want > 8) want = 8;
             if (want > nchunks / 2) want = nchunks / 2;
             while (want > 1 && (size_t)want * (fin0 + fin1) > ws_floats) --want;
@@ -1310,8 +1471,26 @@ extern "C" int cu_conv_gemm_ex(const cu_conv_desc* d, const void* src0, const fl
             }
         }
     }
+    // modes 3 / 4 of the epilogue: the finish pass of a tiny map also does the layer's InstanceNorm + LeakyReLU
+    const bool fin_norm = ep && stats_done && (ep->mode == 3 || ep->mode == 4) && a.ksplit > 1 && fin1 == 0 &&
+                          d->OH * d->OW <= 64 && d->DC0 % 32 == 0 && ep->stats &&
+                          (ep->mode == 3 ? (ep->act_out && !d->accum0) : (ep->z != nullptr));
     auto finish = [&]() -> int {
         if (a.ksplit <= 1) return 0;
+        if (fin_norm) {
+            const dim3 g(d->DC0 / 32, d->N);
+            const int HW = d->OH * d->OW;
+            if (bf) {
+                if (ep->mode == 3) hipLaunchKernelGGL((ksplit_finish_norm_kernel<bf16_t, false>), g, dim3(256), 0, st, a.ws0, a.ws_slice, a.ksplit, (bf16_t*)dst0, bias, d->N, HW, d->DC0, d->accum0, *ep);
+                else hipLaunchKernelGGL((ksplit_finish_norm_kernel<bf16_t, true>), g, dim3(256), 0, st, a.ws0, a.ws_slice, a.ksplit, (bf16_t*)dst0, bias, d->N, HW, d->DC0, d->accum0, *ep);
+            } else {
+                if (ep->mode == 3) hipLaunchKernelGGL((ksplit_finish_norm_kernel<float, false>), g, dim3(256), 0, st, a.ws0, a.ws_slice, a.ksplit, (float*)dst0, bias, d->N, HW, d->DC0, d->accum0, *ep);
+                else hipLaunchKernelGGL((ksplit_finish_norm_kernel<float, true>), g, dim3(256), 0, st, a.ws0, a.ws_slice, a.ksplit, (float*)dst0, bias, d->N, HW, d->DC0, d->accum0, *ep);
+            }
+            CU_LAUNCH_CHECK();
+            *stats_done = 1;
+            return 0;
+        }
         for (int k = 0; k < 2; ++k) {
             const size_t n = k ? fin1 : fin0;
             if (!n) continue;

@@ -90,8 +90,10 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
 // statistics are those of z BEFORE its rounding to the storage type, as in the streaming kernel's epilogue (tconv.hip).
 constexpr int C1M_PX = 16;
 constexpr int C1M_N = 54;
+constexpr int C1M_LD = 68;           // LDS row stride (floats): 16-byte aligned rows
 __global__ __launch_bounds__(256) void c1_moments_kernel(const float* __restrict__ img, float* __restrict__ part, int H, int W) {
-    __shared__ float red[4][C1M_N];
+    __shared__ __attribute__((aligned(16))) float red[4 * C1M_N * C1M_LD];
+    __shared__ float tot[4][C1M_N];
     const int n = blockIdx.y;
     const int segs = (W + C1M_PX - 1) / C1M_PX;
     const int s = blockIdx.x * 256 + threadIdx.x;
@@ -127,53 +129,66 @@ __global__ __launch_bounds__(256) void c1_moments_kernel(const float* __restrict
             }
         }
     }
+    // reduce over the workgroup through LDS (a shuffle tree costs 6 cross-lane steps per moment: 5x the pixel arithmetic):
+    // every lane stores its 54 moments as a column, lane j < 54 then sums row j of its wave, wave 0 the four waves
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* mine = red + wave * (C1M_N * C1M_LD);
 #pragma unroll
-    for (int j = 0; j < C1M_N; ++j) {
-        float v = m[j];
-        for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) red[wave][j] = v;
+    for (int j = 0; j < C1M_N; ++j) mine[j * C1M_LD + lane] = m[j];
+    __syncthreads();
+    if (lane < C1M_N) {
+        const f32x4* row = reinterpret_cast<const f32x4*>(mine + lane * C1M_LD);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const f32x4 v = row[k]; a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3]; }
+        tot[wave][lane] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
     if (threadIdx.x < C1M_N)
         part[((size_t)n * gridDim.x + blockIdx.x) * C1M_N + threadIdx.x] =
-            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            (tot[0][threadIdx.x] + tot[1][threadIdx.x]) + (tot[2][threadIdx.x] + tot[3][threadIdx.x]);
 }
 
-// moments -> the four statistics planes (mean, rstd, scale, shift) of cu_instnorm_stats.  One thread per (n, c); the 81-term
-// quadratic form in double (it cancels: mean^2 against the second moment).
-__global__ void c1_stats_kernel(const float* __restrict__ part, int nwg, const float* __restrict__ w,
-                                const float* __restrict__ bias, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, float eps, float* __restrict__ stats, int N, int HW, int CO) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * CO) return;
-    const int n = i / CO, c = i % CO;
-    double m[C1M_N];
-    for (int j = 0; j < C1M_N; ++j) {
+// moments -> the four statistics planes (mean, rstd, scale, shift) of cu_instnorm_stats.  One 64-thread workgroup per image:
+// thread j < 54 sums moment j over the workgroups' partials (fixed order), then thread c (strided over CO) evaluates the
+// 81-term quadratic form in double (it cancels: mean^2 against the second moment).
+__global__ __launch_bounds__(64) void c1_stats_kernel(const float* __restrict__ part, int nwg, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps,
+                                                      float* __restrict__ stats, int N, int HW, int CO) {
+    __shared__ double m[C1M_N];
+    const int n = blockIdx.x;
+    if (threadIdx.x < C1M_N) {
         double a = 0.0;
-        for (int g = 0; g < nwg; ++g) a += (double)part[((size_t)n * nwg + g) * C1M_N + j];
-        m[j] = a;
+        for (int g = 0; g < nwg; ++g) a += (double)part[((size_t)n * nwg + g) * C1M_N + threadIdx.x];
+        m[threadIdx.x] = a;
     }
-    double wt[9];
-    for (int t = 0; t < 9; ++t) wt[t] = (double)w[t * CO + c];
-    double s1 = 0.0, s2 = 0.0;
-    int j = 9;
-    for (int t = 0; t < 9; ++t) {
-        s1 += wt[t] * m[t];
-        for (int u = t; u < 9; ++u) s2 += (u == t ? 1.0 : 2.0) * wt[t] * wt[u] * m[j + u - t];
-        j += 9 - t;
-    }
+    __syncthreads();
     const double inv = 1.0 / (double)HW;
-    const double m1 = s1 * inv, m2 = s2 * inv;
-    const double var = fmax(m2 - m1 * m1, 0.0);
-    const float mean = (float)((bias ? (double)bias[c] : 0.0) + m1);
-    const float rstd = 1.f / sqrtf((float)var + eps);
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const size_t NC = (size_t)N * CO;
-    stats[i] = mean;
-    stats[NC + i] = rstd;
-    stats[2 * NC + i] = g * rstd;
-    stats[3 * NC + i] = b - mean * g * rstd;
+    for (int c = threadIdx.x; c < CO; c += 64) {
+        double wt[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[t] = (double)w[t * CO + c];
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            s1 += wt[t] * m[t];
+#pragma unroll
+            for (int u = t; u < 9; ++u)
+                s2 += (u == t ? 1.0 : 2.0) * wt[t] * wt[u] * m[9 + t * 9 - t * (t - 1) / 2 + (u - t)];
+        }
+        const double m1 = s1 * inv, m2 = s2 * inv;
+        const double var = fmax(m2 - m1 * m1, 0.0);
+        const float mean = (float)((bias ? (double)bias[c] : 0.0) + m1);
+        const float rstd = 1.f / sqrtf((float)var + eps);
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        const size_t i = (size_t)n * CO + c;
+        stats[i] = mean;
+        stats[NC + i] = rstd;
+        stats[2 * NC + i] = g * rstd;
+        stats[3 * NC + i] = b - mean * g * rstd;
+    }
 }
 
 template <typename T>
@@ -742,8 +757,8 @@ extern "C" int cu_conv_c1_fwd_norm(int dtype, int N, int H, int W, int CO, const
     const unsigned nwg = (unsigned)(((size_t)H * ((W + C1M_PX - 1) / C1M_PX) + 255) / 256);
     hipLaunchKernelGGL(c1_moments_kernel, dim3(nwg, N), dim3(256), 0, st, img, ws, H, W);
     CU_LAUNCH_CHECK();
-    hipLaunchKernelGGL(c1_stats_kernel, dim3(cdiv(N * CO, 64)), dim3(64), 0, st, (const float*)ws, (int)nwg, w, bias, gamma,
-                       beta, eps, stats, N, H * W, CO);
+    hipLaunchKernelGGL(c1_stats_kernel, dim3(N), dim3(64), 0, st, (const float*)ws, (int)nwg, w, bias, gamma, beta, eps, stats,
+                       N, H * W, CO);
     CU_LAUNCH_CHECK();
     const size_t total = (size_t)N * H * ((W + C1_PX - 1) / C1_PX) * (CO / PIECE);
     const unsigned blocks = (unsigned)((total + 255) / 256);

@@ -131,6 +131,10 @@ class UNetEngine:
         # True: the first layer (Cin = 1) derives its InstanceNorm statistics from moments of the image and writes z and a in one pass
         # (cu_conv_c1_fwd_norm) instead of conv -> statistics pass over z -> apply pass
         self.first_fused = os.environ.get("CONTOUR_FIRST_FUSED", "1") == "1"
+        # True: on maps of <= 64 pixels (8x8 and below) the split-K finish pass of the convolution / input-gradient launch
+        # carries the layer's InstanceNorm + LeakyReLU forward / backward (no separate, latency-bound norm launch)
+        self.small_norm = os.environ.get("CONTOUR_SMALL_NORM", "1") == "1"
+        self._bwd_done = set()
         # True: InstanceNorm + LeakyReLU forward (statistics + materialise) and backward (reduce + apply) each run as ONE
         # resident-chunk launch that reads every tensor once (norm.hip); False: the two-pass kernels
         self.fused_norm = True
@@ -226,11 +230,19 @@ class UNetEngine:
                    and n * oh * ow >= (1 << 20) and not (ctx.training and prefix in self.drop_layers))
         if fusable:
             sums = self._arena["fwd"].take(2 * n * co, z.device)
+        small = None
+        if (not fusable and self.small_norm and self.fused_norm and self.materialize and oh * ow <= 64 and co % 32 == 0
+                and not (ctx.training and prefix in self.drop_layers)):
+            small = (P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"], self.eps, self.slope,
+                     torch.empty((4, n, co), dtype=torch.float32, device=z.device), torch.empty_like(z))
         got = ops.conv_gemm(srcs, wf, P[f"{prefix}.conv.bias"], grid=(oh, ow), in_stride=stride, taps=TAPS3, dsts=[z],
-                            dst_cols=[co], stat_sums=sums)
+                            dst_cols=[co], stat_sums=sums, norm_fwd=small)
         if got:
-            out = ops.instnorm_fwd_given(z, P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"], self.slope, sums,
-                                         P[f"{prefix}.conv.bias"], self.eps, materialize=not self._lazy(ctx, z))
+            if small is not None:      # the launch's finish pass wrote z, the statistics and the activation
+                out = Act(z, small[4], self.slope, small[5], None)
+            else:
+                out = ops.instnorm_fwd_given(z, P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"], self.slope, sums,
+                                             P[f"{prefix}.conv.bias"], self.eps, materialize=not self._lazy(ctx, z))
             if not ctx.keep and out.a is not None:
                 return Act(out.a, None, 1.0)
             ctx.convs[prefix] = _ConvRec(prefix, srcs, out, stride, drop_mask=None)
@@ -470,7 +482,9 @@ class UNetEngine:
         # d(conv bias) = sum_p dz is identically zero behind an InstanceNorm (dz has zero mean per (n, c)); the reference
         # accumulates rounding noise there.  G[conv.bias] stays exactly 0 (no kernel work, no atomics contention).
         given = self._given_sums.pop(prefix, None)
-        if given is not None:          # the launch that produced g already did the reduction pass (tconv epilogue)
+        if prefix in self._bwd_done:   # the launch that produced g did this layer's whole norm backward: g IS dL/dz
+            self._bwd_done.discard(prefix)
+        elif given is not None:        # the launch that produced g already did the reduction pass (tconv epilogue)
             ops.instnorm_bwd_given(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
                                    G[f"{prefix}.norm.bias"], given)
         elif self.fused_norm:
@@ -520,18 +534,25 @@ class UNetEngine:
             if (tgt is not None and self.fused_norm_bwd and not self.deterministic and self.fused_norm and self.dtype == torch.bfloat16 and not acc[0]
                     and n * sh * sw >= (1 << 20) and ctx.convs[tgt].drop_mask is None and ctx.convs[tgt].out.stats is not None):
                 nb = (ctx.convs[tgt].out, self._arena["bwd"].take(2 * n * cols[0], g.device))
+            full = self._small_norm_bwd(P, G, ctx, src, n, sh * sw, cols[0]) if nb is None and len(dsts) == 1 else None
             got = ops.conv_gemm([gz], wd, None, grid=(sh, sw), in_stride=1, taps=TAPS3_D, dsts=dsts, dst_cols=cols,
-                                accum=acc, norm_bwd=nb)
-            if got:
+                                accum=acc, norm_bwd=nb, norm_bwd_full=full[1] if full else None)
+            if got and full:
+                self._bwd_done.add(full[0])
+            elif got:
                 self._given_sums[tgt] = nb[1]
         elif ONE_PASS_S2_DGRAD and self.dtype == torch.bfloat16 and len(dsts) == 1 and cols[0] % 32 == 0:
             # all four input parities in one pass: gather taps = the 2x2 neighbourhood of dz, the weight tap of
             # (gather tap, parity) from S2_PARITY_TAPS (9 of the 16 pairs exist, the others are skipped); dz is read once.
             # (On the tile-generic kernel this form was slower than four parity launches -- 16/9 of the MFMA work; the
             # lean gather-GEMM skips the absent pairs.  tools/conv_bench.py s2dgrad compares the two.)
-            ops.conv_gemm([gz], wd, None, grid=(sh // 2, sw // 2), in_stride=1,
-                          taps=[(u, v, 0) for u in range(2) for v in range(2)], dsts=dsts, dst_cols=cols, out_stride=2,
-                          accum=acc, n_cols=4 * cols[0], parity_cols=cols[0], parity_taps=S2_PARITY_TAPS)
+            full = self._small_norm_bwd(P, G, ctx, rec.srcs[0], n, sh * sw, cols[0])
+            got = ops.conv_gemm([gz], wd, None, grid=(sh // 2, sw // 2), in_stride=1,
+                                taps=[(u, v, 0) for u in range(2) for v in range(2)], dsts=dsts, dst_cols=cols, out_stride=2,
+                                accum=acc, n_cols=4 * cols[0], parity_cols=cols[0], parity_taps=S2_PARITY_TAPS,
+                                norm_bwd_full=full[1] if full else None)
+            if got and full:
+                self._bwd_done.add(full[0])
         else:
             for py in range(2):
                 for px in range(2):
@@ -539,7 +560,19 @@ class UNetEngine:
                     ops.conv_gemm([gz], wd, None, grid=(sh // 2, sw // 2), in_stride=1, taps=taps, dsts=dsts,
                                   dst_cols=cols, out_stride=2, out_off=(py, px), accum=acc)
 
-    def _convT_bwd(self, P, G, rec: _UpRec, du: Tensor, d_in: Tensor, accum: int):
+    def _small_norm_bwd(self, P, G, ctx: UNetCtx, src: Optional[Act], n: int, hw: int, c: int):
+        """(target layer, ``norm_bwd_full`` argument) when the input-gradient launch that differentiates ``src`` may carry
+        the norm backward of the layer that produced it (maps of <= 64 pixels), else None."""
+        tgt = self._producer.get(id(src)) if src is not None else None
+        if (tgt is None or not self.small_norm or not self.fused_norm or self.deterministic or self.debug is not None
+                or hw > 64 or c % 32 != 0):
+            return None
+        rec = ctx.convs.get(tgt)
+        if rec is None or rec.drop_mask is not None or rec.out.stats is None or rec.first:
+            return None
+        return tgt, (rec.out, P[f"{tgt}.norm.weight"], G[f"{tgt}.norm.weight"], G[f"{tgt}.norm.bias"])
+
+    def _convT_bwd(self, P, G, ctx: UNetCtx, rec: _UpRec, du: Tensor, d_in: Tensor, accum: int):
         w = P[f"{rec.prefix}.weight"]
         ci, co = w.shape[0], w.shape[1]
         n, h, w_, _ = rec.src.z.shape
@@ -548,9 +581,12 @@ class UNetEngine:
             self._wgrad([rec.src], du, (4, co, ci), G[f"{rec.prefix}.weight"], "convT", rec.prefix, grid=(h, w_),
                         in_stride=1, z_stride=2, taps=taps, n_cols=co)
         _, wd = self._operands(f"{rec.prefix}.weight", w, "convT")
-        ops.conv_gemm([Act(du, None, 1.0)], wd, None, grid=(h, w_), in_stride=2,
-                      taps=[(dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)], dsts=[d_in], dst_cols=[ci],
-                      accum=[accum])
+        full = self._small_norm_bwd(P, G, ctx, rec.src, n, h * w_, ci)
+        got = ops.conv_gemm([Act(du, None, 1.0)], wd, None, grid=(h, w_), in_stride=2,
+                            taps=[(dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)], dsts=[d_in], dst_cols=[ci],
+                            accum=[accum], norm_bwd_full=full[1] if full else None)
+        if got and full:
+            self._bwd_done.add(full[0])
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, P: Dict[str, Tensor], G: Dict[str, Tensor], ctx: UNetCtx, dlogits: Optional[Tensor],
@@ -573,6 +609,7 @@ class UNetEngine:
                 self._red_done = [None, None]
                 self._side_keep.clear()
                 self._given_sums.clear()
+                self._bwd_done.clear()
                 self._dw9_ws = None
                 hook = getattr(self.grad_ready_hook, "__self__", None)
                 if hook is not None and hasattr(hook, "abort"):
@@ -585,6 +622,7 @@ class UNetEngine:
         n, h, w_, c_last = last.z.shape
         self._arena["bwd"].begin(last.z.device)
         self._given_sums.clear()
+        self._bwd_done.clear()
         # the previous backward joined the reduction stream into this one: its "buffer read" events are history (and must not
         # be waited for inside a hipGraph capture, which they precede)
         self._red_done = [None, None]
@@ -626,7 +664,7 @@ class UNetEngine:
             else:
                 accum = 0
                 d_in = torch.empty_like(up.src.z)
-            self._convT_bwd(P, G, up, du, d_in, accum)
+            self._convT_bwd(P, G, ctx, up, du, d_in, accum)
             del du
             g = d_in
         # ---- bottleneck + encoder

@@ -33,7 +33,9 @@ class ConvDesc(C.Structure):
 
 
 class ConvEpilogue(C.Structure):      # cu_conv_epilogue
-    _fields_ = [("mode", C.c_int), ("sums", C.c_void_p), ("z", C.c_void_p), ("stats", C.c_void_p), ("slope", C.c_float)]
+    _fields_ = [("mode", C.c_int), ("sums", C.c_void_p), ("z", C.c_void_p), ("stats", C.c_void_p), ("slope", C.c_float),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("act_out", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):

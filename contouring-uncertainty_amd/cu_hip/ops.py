@@ -84,9 +84,14 @@ def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: T
               out_stride: int = 1, out_off: Tuple[int, int] = (0, 0), accum: Sequence[int] = (0, 0),
               out_nchw: bool = False, n_cols: Optional[int] = None, parity_cols: int = 0,
               parity_taps: Optional[Sequence[int]] = None, stat_sums: Optional[Tensor] = None,
-              norm_bwd: Optional[Tuple[Act, Tensor]] = None, alg_cin: Optional[int] = None) -> bool:
+              norm_bwd: Optional[Tuple[Act, Tensor]] = None, alg_cin: Optional[int] = None,
+              norm_fwd: Optional[tuple] = None, norm_bwd_full: Optional[tuple] = None) -> bool:
     """D[p, n] = bias[n] + sum_t sum_c act(S[p*IS + off_t, c]) W[tap_w[t]][n][c]  (cu_conv_gemm).
-    ``parity_taps`` (16 ints, with ``parity_cols``): weight tap of (gather tap t, parity group g) at [t*4+g], -1 = none."""
+    ``parity_taps`` (16 ints, with ``parity_cols``): weight tap of (gather tap t, parity group g) at [t*4+g], -1 = none.
+    Tiny maps (<= 64 pixels per image; cu_conv_epilogue modes 3 / 4 -- the split-K finish pass carries the norm):
+    ``norm_fwd=(gamma, beta, eps, slope, stats, a)``: the layer's InstanceNorm + LeakyReLU forward (``stats`` (4, N, C) and
+    ``a`` are written); ``norm_bwd_full=(act, gamma, dgamma, dbeta)``: dsts[0] receives dL/dz of the layer ``act`` belongs to.
+    Returns True when the launch took the requested epilogue (otherwise dsts hold the plain result)."""
     lib = L.load()
     s0 = srcs[0]
     s1 = srcs[1] if len(srcs) > 1 else None
@@ -144,6 +149,14 @@ def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: T
     elif norm_bwd is not None:                # input gradient: the reduction pass of the target layer's norm backward
         tgt, sums = norm_bwd
         ep = L.ConvEpilogue(2, L.ptr(sums), L.ptr(tgt.z), L.ptr(tgt.stats), float(tgt.slope))
+    elif norm_fwd is not None:
+        gamma, beta, eps, slope, stats, a = norm_fwd
+        ep = L.ConvEpilogue(3, None, None, L.ptr(stats), float(slope), L.ptr(gamma), L.ptr(beta), float(eps), L.ptr(a), None,
+                            None)
+    elif norm_bwd_full is not None:
+        tgt, gamma, dgamma, dbeta = norm_bwd_full
+        ep = L.ConvEpilogue(4, None, L.ptr(tgt.z), L.ptr(tgt.stats), float(tgt.slope), L.ptr(gamma), None, 0.0, None,
+                            L.ptr(dgamma), L.ptr(dbeta))
     with _Prof("igemm_conv", flops, note, nbytes, exec_flops):
         rc = lib.cu_conv_gemm_ex(d, L.ptr(t0), L.ptr(sc0), L.ptr(sh0), L.ptr(t1), L.ptr(sc1), L.ptr(sh1), L.ptr(w),
                                  L.ptr(bias), L.ptr(dst0), L.ptr(dsts[1]) if len(dsts) > 1 else None, L.ptr(ws),

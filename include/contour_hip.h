@@ -99,12 +99,26 @@ int cu_conv_gemm_stats(const cu_conv_desc* d,
  * (zero on entry) += {sum of gl, sum of gl * zhat} with gl = g * LeakyReLU'(scale z + shift), zhat = (z - mean) * rstd --
  * the reduction pass of that layer's norm backward (z [N][H][W][CO] of the launch's dtype, stats = the four planes of
  * cu_instnorm_stats).  Consumer: cu_instnorm_bwd_given.  *done as in cu_conv_gemm_stats. */
+/* modes 3 and 4 (tiny feature maps, <= 64 pixels per image, taken when the launch splits its channel reduction over
+ * workgroups -- cu_conv_gemm_ws): the split-K finish pass, which holds whole images per workgroup, carries the layer's
+ * WHOLE InstanceNorm + LeakyReLU instead of a separate norm launch.
+ *   mode 3 (forward): dst0 = z; stats (written: the four planes of cu_instnorm_stats, of the z as stored);
+ *                     act_out = LeakyReLU(z*scale + shift) (dst0's layout and type).  gamma / beta / eps / slope given.
+ *   mode 4 (input gradient): dst0 = dL/dz of the layer whose activation this launch differentiates (NOT dL/da): its norm
+ *                     backward from z, stats (read), gamma, slope; dgamma / dbeta [C] += (atomics, may be NULL).
+ * *done = 1 when the launch took this form, else nothing of it happened (dst0 holds the plain result). */
 typedef struct {
     int mode;
     float* sums;
     const void* z;
-    const float* stats;
+    float* stats;
     float slope;
+    const float* gamma;
+    const float* beta;
+    float eps;
+    void* act_out;
+    float* dgamma;
+    float* dbeta;
 } cu_conv_epilogue;
 int cu_conv_gemm_ex(const cu_conv_desc* d,
                     const void* src0, const float* scale0, const float* shift0,

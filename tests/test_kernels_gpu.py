@@ -857,3 +857,105 @@ def test_normalise_on_load_equals_the_materialised_operand(case):
             ops.grad_unprep_parts(ws, slabs, 32, gw, "conv", accumulate=True)
             gs.append(gw)
         assert torch.equal(gs[0], gs[1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [
+    # n, cin0, cin1, cout, size, stride (output maps of <= 64 pixels at batch 64: the split-K path)
+    (64, 480, 0, 480, 4, 1), (64, 480, 480, 480, 4, 1), (64, 480, 0, 480, 2, 1), (64, 480, 0, 480, 4, 2),
+    (64, 480, 0, 480, 8, 1), (64, 480, 480, 480, 8, 1), (64, 480, 0, 480, 16, 2), (16, 256, 0, 480, 8, 1),
+])
+def test_small_map_conv_carries_the_norm_forward(dtype, case):
+    """cu_conv_epilogue mode 3: the split-K finish pass writes z, the statistics and LeakyReLU(InstanceNorm(z)).  z must be
+    bit-identical to the plain launch; statistics / activation are compared with the separate norm launch and with
+    F.instance_norm."""
+    ops = _ops()
+    from cu_hip.engine import TAPS3
+    n, c0, c1, co, size, stride = case
+    g = torch.Generator(device=DEV).manual_seed(21)
+    srcs = [ops.Act(nhwc(torch.randn(n, c0, size, size, device=DEV, generator=g), dtype), None, 1.0)]
+    if c1:
+        srcs.append(ops.Act(nhwc(torch.randn(n, c1, size, size, device=DEV, generator=g), dtype), None, 1.0))
+    w = torch.randn(co, c0 + c1, 3, 3, device=DEV, generator=g) / math.sqrt(9 * (c0 + c1))
+    b = torch.randn(co, device=DEV, generator=g)
+    gamma = torch.rand(co, device=DEV, generator=g) + 0.5
+    beta = torch.randn(co, device=DEV, generator=g)
+    wf, _ = ops.weight_prep(w, "conv", dtype)
+    os_ = size // stride
+    z0 = torch.empty(n, os_, os_, co, device=DEV, dtype=dtype)
+    ops.conv_gemm(srcs, wf, b, grid=(os_, os_), in_stride=stride, taps=TAPS3, dsts=[z0], dst_cols=[co])
+    old = ops.instnorm_fwd_fused(z0, gamma, beta, 0.01, 1e-5)
+    z = torch.full_like(z0, float("nan"))
+    stats = torch.full((4, n, co), float("nan"), device=DEV)
+    a = torch.full_like(z0, float("nan"))
+    got = ops.conv_gemm(srcs, wf, b, grid=(os_, os_), in_stride=stride, taps=TAPS3, dsts=[z], dst_cols=[co],
+                        norm_fwd=(gamma, beta, 1e-5, 0.01, stats, a))
+    if not got:
+        assert n < 64                       # too much work per tile for a split: the plain result must be there
+        assert torch.equal(z, z0)
+        return
+    # (a split the plain launch did not make -- 8x8 -- sums in another order: not bit-identical there)
+    assert torch.equal(z, z0) or (os_ == 8 and rel_err(z.float(), z0.float()) < (1e-5 if dtype == torch.float32 else 8e-3))
+    zs = z.float()
+    ref = F.leaky_relu(F.instance_norm(nchw(z).float(), weight=gamma, bias=beta, eps=1e-5), 0.01)
+    assert rel_err(nchw(a), ref) < tol(dtype)
+    mean = zs.mean((1, 2))
+    rstd = (zs.var((1, 2), unbiased=False) + 1e-5).rsqrt()
+    assert rel_err(stats[0], mean) < 1e-5 and rel_err(stats[1], rstd) < 1e-4
+    assert rel_err(stats[2], gamma * rstd) < 1e-4 and rel_err(stats[3], beta - mean * gamma * rstd) < 1e-4
+    if torch.equal(z, z0):
+        assert rel_err(stats, old.stats) < 1e-4
+        assert rel_err(a.float(), old.a.float()) < (1e-5 if dtype == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["s1", "s2", "s2_accum", "convT", "convT_accum"])
+@pytest.mark.parametrize("size", [2, 4, 8])
+def test_small_map_input_gradient_carries_the_norm_backward(dtype, kind, size):
+    """cu_conv_epilogue mode 4: the split-K finish pass of an input-gradient launch writes dL/dz of the layer whose
+    activation it differentiates (+ dgamma, dbeta) -- against the plain launch followed by the norm-backward launch."""
+    ops = _ops()
+    from cu_hip.engine import TAPS3_D, S2_PARITY_TAPS
+    n, c = 64, 480
+    g = torch.Generator(device=DEV).manual_seed(31 + size)
+    # the target layer: z, statistics, activation on a size x size map
+    zt = nhwc(torch.randn(n, c, size, size, device=DEV, generator=g) * 2 + 0.3, dtype)
+    gamma = torch.rand(c, device=DEV, generator=g) + 0.5
+    beta = torch.randn(c, device=DEV, generator=g) * 0.2
+    tgt = ops.instnorm_fwd_fused(zt, gamma, beta, 0.01, 1e-5)
+    accum = kind.endswith("accum")
+    base = nhwc(torch.randn(n, c, size, size, device=DEV, generator=g), dtype)
+    w = torch.randn(c, c, 3, 3, device=DEV, generator=g) / math.sqrt(9 * c)
+    if kind == "s1":
+        dz = ops.Act(nhwc(torch.randn(n, c, size, size, device=DEV, generator=g), dtype), None, 1.0)
+        _, wd = ops.weight_prep(w, "conv", dtype)
+        kw = dict(grid=(size, size), in_stride=1, taps=TAPS3_D, dst_cols=[c], accum=[0])
+    elif kind.startswith("s2"):
+        if size < 4 or dtype != torch.bfloat16:
+            pytest.skip("one-pass stride-2 input gradient: bf16, destination >= 4x4")
+        os_ = size // 2
+        dz = ops.Act(nhwc(torch.randn(n, c, os_, os_, device=DEV, generator=g), dtype), None, 1.0)
+        _, wd = ops.weight_prep(w, "conv", dtype)
+        kw = dict(grid=(os_, os_), in_stride=1, taps=[(u, v, 0) for u in range(2) for v in range(2)], dst_cols=[c],
+                  out_stride=2, accum=[int(accum)], n_cols=4 * c, parity_cols=c, parity_taps=S2_PARITY_TAPS)
+    else:
+        wt = torch.randn(c, c, 2, 2, device=DEV, generator=g) / math.sqrt(4 * c)
+        dz = ops.Act(nhwc(torch.randn(n, c, 2 * size, 2 * size, device=DEV, generator=g), dtype), None, 1.0)
+        _, wd = ops.weight_prep(wt, "convT", dtype)
+        kw = dict(grid=(size, size), in_stride=2, taps=[(dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)],
+                  dst_cols=[c], accum=[int(accum)])
+    # plain launch + norm backward launch
+    d_ref = base.clone()
+    ops.conv_gemm([dz], wd, None, dsts=[d_ref], **kw)
+    dg_ref, db_ref = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    ops.instnorm_bwd_fused(d_ref, tgt, gamma, dg_ref, db_ref)
+    # fused
+    d = base.clone()
+    dg, db = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    got = ops.conv_gemm([dz], wd, None, dsts=[d], norm_bwd_full=(tgt, gamma, dg, db), **kw)
+    assert got, "the launch did not take the fused finish"
+    t = 2e-5 if dtype == torch.float32 else 1.2e-2
+    assert rel_err(d.float(), d_ref.float()) < t
+    # (bf16 at 8x8: the plain launch does not split there, g rounds from another summation order)
+    tg = 1e-4 if dtype == torch.float32 else 1e-3
+    assert rel_err(dg, dg_ref) < tg and rel_err(db, db_ref) < tg

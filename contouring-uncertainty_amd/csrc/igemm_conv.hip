@@ -44,6 +44,7 @@ struct ConvKArgs {
     float* ws0; float* ws1;     // channels and stores its f32 partial tile into slice blockIdx.z of ws (laid out like
     size_t ws_slice;            // dst0 | dst1; ws_slice floats per split)
     int dbg;                    // CU_CONV_DBG bits (timing experiments only): 1 no stores, 2 no MFMA, 4 no commit, 8 no loads
+    float* stat_sums;           // LDS-DMA kernels, cu_conv_epilogue mode 1: [N][CO][2] += {sum, sum of squares} of (out - bias)
 };
 
 template <typename T> struct Cfg;
@@ -533,6 +534,93 @@ __global__ __launch_bounds__(256, WRES ? 2 : 1) void igemm_conv_kernel(const Con
 //     holds piece s ^ ((i >> 2) & 3), which makes the ds_read_b128 fragment reads of 32 consecutive rows conflict-free
 //     (lane groups of ds_read_b128: MI355X_MICROARCH.md, LDS); zero padding comes from the buffer range check.
 constexpr int DW = 8;                 // waves
+
+// ---- InstanceNorm statistics of the finished tile (cu_conv_epilogue mode 1 on the LDS-DMA kernels) ------------------------
+// A lane owns one pixel; register i of a column block is channel (i & 3) + 8 (i >> 2) + 4 h.  Summing a register over the
+// 32 pixel lanes with a plain butterfly costs 5 cross-lane steps per register (80 per block and statistic, each an LDS
+// permute: measured +12 us on a 64^2 x 128-channel layer, as much as the statistics pass it removed).  The halving
+// butterfly below exchanges HALF the registers per step (lane pairs split the register set between them): 8 + 4 + 2 + 1
+// exchanges bring the 16 registers down to one per lane -- in DPP / permlane-swap form (no LDS round trip), one last LDS
+// permute joins the lane pairs the DPP patterns cannot reach.  The totals end up one channel per lane.
+// Lane l then holds register i = (l & 1) << 3 | (l & 2) << 1 | (l & 8) >> 2 | (l & 16) >> 4 (bit 2 of l: replicated).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_reduce16(float (&v)[16], int lane) {
+    {   // lanes l, l ^ 1 (quad_perm [1,0,3,2]): odd lanes keep registers 8..15
+        const bool up = lane & 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float lo = v[j] + dpp_mov<0xB1>(v[j]), hi = v[j + 8] + dpp_mov<0xB1>(v[j + 8]);
+            v[j] = up ? hi : lo;
+        }
+    }
+    {   // l, l ^ 2 (quad_perm [2,3,0,1])
+        const bool up = lane & 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = v[j] + dpp_mov<0x4E>(v[j]), hi = v[j + 4] + dpp_mov<0x4E>(v[j + 4]);
+            v[j] = up ? hi : lo;
+        }
+    }
+    {   // l, l ^ 8 (row_ror:8)
+        const bool up = lane & 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float lo = v[j] + dpp_mov<0x128>(v[j]), hi = v[j + 2] + dpp_mov<0x128>(v[j + 2]);
+            v[j] = up ? hi : lo;
+        }
+    }
+    // l, l ^ 16: v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second: the two
+    // results are (v0 of rows 0,0,2,2 | v1 of rows ... ) such that their sum is v0 + v0' in even rows, v1 + v1' in odd rows
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
+    const float t = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    return t + __shfl_xor(t, 4, 64);
+}
+
+// All 8 waves call this after their MFMAs (it starts with a barrier: the LDS is reused).  valid[a]: block a holds pixels
+// of an existing image; img_l: the wave's image inside the tile (wave-uniform: the host only enables the statistics when
+// a wave's 32 * MA pixels lie in one image).  Every wave stores its 2 x BN column totals into a slot of its own; after one
+// barrier the workgroup adds the slots of each image and issues one global atomic per (image, column, statistic).
+template <int MA, int NB>
+__device__ __forceinline__ void tile_stats(const f32x16 (&acc)[MA][NB], const bool (&valid)[MA], int img_l, float* lds,
+                                           float* __restrict__ sums, int img0, int imgs, int N, int CO, int n0, int wpi) {
+    constexpr int BN = 32 * NB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    __syncthreads();
+    const int reg = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+    float* mine = lds + wave * (2 * BN);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float s[16], q[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s[i] = q[i] = 0.f;
+#pragma unroll
+            for (int a = 0; a < MA; ++a) {
+                const float v = valid[a] ? acc[a][b][i] : 0.f;
+                s[i] += v;
+                q[i] = fmaf(v, v, q[i]);
+            }
+        }
+        const float st = lane_reduce16(s, lane), qt = lane_reduce16(q, lane);
+        if (!(lane & 4)) {
+            const int col = b * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            mine[2 * col] = st;
+            mine[2 * col + 1] = qt;
+        }
+    }
+    __syncthreads();
+    // wpi waves per image (8 / imgs': 8 when the tile is one image or part of one, 4 with two images per tile)
+    for (int i = tid; i < (DW / wpi) * 2 * BN; i += 64 * DW) {
+        const int img = i / (2 * BN), rem = i - img * 2 * BN, col = rem >> 1;
+        const int n = img0 + img;
+        float t = 0.f;
+        for (int w = 0; w < wpi; ++w) t += lds[(img * wpi + w) * (2 * BN) + rem];
+        if (img < imgs && n < N && n0 + col < CO) unsafeAtomicAdd(sums + ((size_t)n * CO + n0 + col) * 2 + (rem & 1), t);
+    }
+}
 constexpr int DMA_MAXX = 9;           // halo items per thread: halo_px * 4 <= 512 * 9 (stride-2 gathers: 17 x 65 pixels)
 // MA = 32-pixel blocks per wave (tile = 256 * MA pixels): 2 for stride-1 gathers, 1 for stride-2 gathers, whose halo patch
 // is four times larger per pixel.
@@ -735,6 +823,13 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs
                 *reinterpret_cast<u32x2*>(o) = pk;
             }
         }
+    }
+    if (p.stat_sums) {
+        bool valid[MA];
+#pragma unroll
+        for (int a = 0; a < MA; ++a) valid[a] = pim[a] < p.imgs;
+        tile_stats<MA, NB>(acc, valid, (wave * 32 * MA) >> (p.twl + p.thl), reinterpret_cast<float*>(smem), p.stat_sums, img0,
+                           p.imgs, p.N, p.CO, n0, p.imgs == 2 ? DW / 2 : DW);
     }
 }
 
@@ -965,6 +1060,13 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_ring_kernel(const Conv
             }
         }
     }
+    if (p.stat_sums) {
+        bool valid[MA];
+#pragma unroll
+        for (int a = 0; a < MA; ++a) valid[a] = pim[a] < p.imgs;
+        tile_stats<MA, NB>(acc, valid, (wave * 32 * MA) >> (p.twl + p.thl), reinterpret_cast<float*>(smem), p.stat_sums, img0,
+                           p.imgs, p.N, p.CO, n0, p.imgs == 2 ? DW / 2 : DW);
+    }
 }
 
 template <typename T, int MA, int NB, int NX, int NT, bool WRES, bool PLAIN>
@@ -1064,27 +1166,32 @@ __global__ __launch_bounds__(256) void ksplit_finish_norm_kernel(const float* __
             *reinterpret_cast<f32x4*>(ptr) = f32x4{o[0], o[1], o[2], o[3]};
         }
     };
+    // every load below is UNCONDITIONAL (clamped pixel / slice, masked afterwards): predicated loads are serialised with a
+    // full wait each, and this kernel is nothing but one round trip of loads (all 2 x 8 slice loads in flight together)
     float v[2][4];
     bool live[2];
     size_t off[2];
+    f32x4 part[2][8];
+    float old[2][4];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int px = pl + 32 * it;
         live[it] = px < HW;
-        off[it] = ((size_t)n * HW + (live[it] ? px : 0)) * C + c;
-        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (live[it]) {
-            a = *reinterpret_cast<const f32x4*>(ws + off[it]);
-            for (int k = 1; k < ksplit; ++k) a += *reinterpret_cast<const f32x4*>(ws + (size_t)k * slice + off[it]);
-            if (bias) a += *reinterpret_cast<const f32x4*>(bias + c);
-            if (accum) {
-                float o[4];
-                load_t(dst + off[it], o);
-                a += f32x4{o[0], o[1], o[2], o[3]};
-            }
-        }
+        off[it] = ((size_t)n * HW + (live[it] ? px : HW - 1)) * C + c;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[it][e] = round_t(a[e]);
+        for (int k = 0; k < 8; ++k)
+            part[it][k] = *reinterpret_cast<const f32x4*>(ws + (size_t)(k < ksplit ? k : ksplit - 1) * slice + off[it]);
+        if (accum) load_t(dst + off[it], old[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        f32x4 a = part[it][0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) a += k < ksplit ? part[it][k] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias) a += *reinterpret_cast<const f32x4*>(bias + c);
+        if (accum) a += f32x4{old[it][0], old[it][1], old[it][2], old[it][3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[it][e] = live[it] ? round_t(a[e]) : 0.f;
     }
     const float inv = 1.f / (float)HW;
     if constexpr (!BWD) {
@@ -1135,8 +1242,8 @@ __global__ __launch_bounds__(256) void ksplit_finish_norm_kernel(const float* __
         for (int j = 0; j < 8; ++j) s[j] = 0.f;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            float zv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (live[it]) load_t(reinterpret_cast<const T*>(ep.z) + off[it], zv);
+            float zv[4];
+            load_t(reinterpret_cast<const T*>(ep.z) + off[it], zv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float y = zv[e] * sc[e] + sh[e];
@@ -1300,6 +1407,13 @@ extern "C" int cu_conv_gemm_ex(const cu_conv_desc* d, const void* src0, const fl
             if (a.twl >= 0 && a.thl >= 0 && a.iml >= 0 && d->PW % tw == 0 && d->PH % th == 0 && halo_pad <= 128 * DMA_MAXX &&
                 lds <= 160 * 1024 && ilog2_exact(d->PW / tw) >= 0 && ilog2_exact(d->PH / th) >= 0) {
                 a.imgs = imgs; a.halo_px = halo_pad;
+                // the tile's InstanceNorm statistics in the epilogue (mode 1): a wave's pixels must lie in one image
+                const int wave_px = 32 * (d->IS == 1 ? 2 : 1);
+                if (ep && stats_done && ep->mode == 1 && ep->sums && d->D0 == d->CO && !d->accum0 && (tw * th) % wave_px == 0 &&
+                    imgs <= 2 && !cu_env_set("CU_CONV_NO_DMA_STATS")) {
+                    a.stat_sums = ep->sums;
+                    *stats_done = 1;
+                }
                 a.tiles_x = d->PW / tw; a.tiles_y = d->PH / th;
                 a.txl = ilog2_exact(a.tiles_x); a.tyl = ilog2_exact(a.tiles_y);
                 a.ntiles = a.tiles_x * a.tiles_y * cdiv(d->N, imgs);

@@ -226,8 +226,10 @@ class UNetEngine:
         z = torch.empty((n, oh, ow, co), dtype=self.dtype, device=w.device)
         # thin, large layers: the streaming kernel gathers the InstanceNorm statistics in its epilogue (no statistics pass)
         sums = None
-        fusable = (self.fused_stats and not self.deterministic and self.fused_norm and self.materialize and stride == 1 and self.dtype == torch.bfloat16
-                   and n * oh * ow >= (1 << 20) and not (ctx.training and prefix in self.drop_layers))
+        # (thin layers: the streaming kernel, stride 1 only; from 64 channels on: the LDS-DMA kernels, both strides -- the
+        # launch reports whether its kernel gathered them)
+        fusable = (self.fused_stats and not self.deterministic and self.fused_norm and self.materialize and self.dtype == torch.bfloat16
+                   and n * oh * ow >= (1 << 14) and oh * ow > 64 and not (ctx.training and prefix in self.drop_layers))
         if fusable:
             sums = self._arena["fwd"].take(2 * n * co, z.device)
         small = None

@@ -959,3 +959,47 @@ def test_small_map_input_gradient_carries_the_norm_backward(dtype, kind, size):
     # (bf16 at 8x8: the plain launch does not split there, g rounds from another summation order)
     tg = 1e-4 if dtype == torch.float32 else 1e-3
     assert rel_err(dg, dg_ref) < tg and rel_err(db, db_ref) < tg
+
+
+@pytest.mark.parametrize("case", [
+    # n, cin0, cin1, cout, size, stride
+    (16, 128, 0, 128, 64, 1),        # ring kernel, one image per tile
+    (16, 128, 128, 128, 64, 1),      # two sources
+    (64, 256, 0, 256, 32, 1),
+    (64, 480, 0, 480, 16, 1),        # two images per tile, ragged last column tile
+    (63, 480, 0, 480, 16, 1),        # odd batch: the last tile's second image does not exist
+    (16, 64, 0, 128, 128, 2),        # stride-2 gather
+    (64, 256, 0, 480, 32, 2),
+])
+def test_wide_conv_gathers_the_norm_statistics(case):
+    """cu_conv_epilogue mode 1 on the LDS-DMA kernels: sums [N][CO][2] += {sum, sum of squares} of (output - bias) over
+    each image, from the f32 accumulators -- against the same sums of an f32 convolution of the same bf16 operands."""
+    ops = _ops()
+    from cu_hip.engine import TAPS3
+    dtype = torch.bfloat16
+    n, c0, c1, co, size, stride = case
+    g = torch.Generator(device=DEV).manual_seed(41)
+    xs = [rq(torch.randn(n, c0, size, size, device=DEV, generator=g), dtype)]
+    if c1:
+        xs.append(rq(torch.randn(n, c1, size, size, device=DEV, generator=g), dtype))
+    srcs = [ops.Act(nhwc(x, dtype), None, 1.0) for x in xs]
+    w = torch.randn(co, c0 + c1, 3, 3, device=DEV, generator=g) / math.sqrt(9 * (c0 + c1))
+    b = torch.randn(co, device=DEV, generator=g)
+    wf, _ = ops.weight_prep(w, "conv", dtype)
+    os_ = size // stride
+    z0 = torch.empty(n, os_, os_, co, device=DEV, dtype=dtype)
+    ops.conv_gemm(srcs, wf, b, grid=(os_, os_), in_stride=stride, taps=TAPS3, dsts=[z0], dst_cols=[co])
+    z = torch.empty_like(z0)
+    sums = torch.zeros(n, co, 2, device=DEV)
+    got = ops.conv_gemm(srcs, wf, b, grid=(os_, os_), in_stride=stride, taps=TAPS3, dsts=[z], dst_cols=[co], stat_sums=sums)
+    assert got, "the launch did not gather the statistics"
+    assert torch.equal(z, z0)
+    ref = F.conv2d(torch.cat(xs, 1), rq(w, dtype), None, stride=stride, padding=1)
+    s1, s2 = ref.sum((2, 3)), (ref * ref).sum((2, 3))
+    assert rel_err(sums[:, :, 0], s1) < 2e-4          # (sums near zero against the largest: f32 summation order)
+    assert rel_err(sums[:, :, 1], s2) < 2e-5
+    gamma = torch.rand(co, device=DEV, generator=g) + 0.5
+    beta = torch.randn(co, device=DEV, generator=g)
+    out = ops.instnorm_fwd_given(z, gamma, beta, 0.01, sums, b)
+    refa = F.leaky_relu(F.instance_norm(nchw(z).float(), weight=gamma, bias=beta, eps=1e-5), 0.01)
+    assert rel_err(nchw(out.a), refa) < tol(dtype)

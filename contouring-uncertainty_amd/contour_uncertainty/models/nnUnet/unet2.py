@@ -8,6 +8,7 @@ runs the kernel schedule of :mod:`cu_hip.engine` through one autograd node (hand
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Sequence, Tuple
 
 import torch
@@ -96,9 +97,17 @@ class _UNetFn(torch.autograd.Function):
         # the slot exists exactly when grad mode was on at the call)
         need = slot is not None and any(ctx.needs_input_grad)
         logits, feats, ectx = module.engine.forward(P, x, module.bottleneck_out, module.training or module.mc_dropout,
-                                                    keep=need)
+                                                    keep=need, fused_head=need and slot.fused)
         ctx.module, ctx.ectx, ctx.slot = module, (ectx if need else None), slot
         ctx.save_for_backward(*params)
+        if logits is None:
+            # fused head (cu_hip.head runs cu_head_fused_fwd on ectx.head): the logits do not exist; their stand-in in
+            # autograd is a stride-0 zero tensor of their shape that only cu_hip.head.dsnt_nll knows how to read
+            slot.head = ectx.head
+            n, _, h, w_ = x.shape
+            logits = torch.zeros((), dtype=torch.float32, device=x.device).expand(n, module.num_classes, h, w_)
+        elif slot is not None:
+            slot.fused = False
         if module.bottleneck_out:
             return logits, feats
         return logits
@@ -121,6 +130,22 @@ class _UNetFn(torch.autograd.Function):
             module.flat_grad_hook(flat)
         # the DSNT head may have left dL/dlogits in the engine's layout (cu_hip.head.GradSlot); its stand-in in autograd is
         # a stride-0 zero tensor, and anything else that reached ``dlogits`` is a genuine extra gradient to add
+        if ctx.ectx is not None and ctx.ectx.head is not None:
+            # fused head: dL/d(mu, Sigma) were left in the slot by dsnt_nll's backward (none = the loss does not depend on
+            # the landmarks); a dense gradient on the placeholder means something else read the stand-in logits
+            if dlogits is not None and not all(s == 0 for s in dlogits.stride()) and bool(dlogits.ne(0).any()):
+                raise _lib.ContourHipError("UNet.fused_head(): the logits placeholder was used outside cu_hip.head.dsnt_nll")
+            hg = ctx.slot.take_head()
+            if hg is None:
+                n, k = ctx.ectx.img.shape[0], module.num_classes
+                z0 = torch.zeros((n, k, 3), dtype=torch.float32, device=params[0].device)
+                aux0 = torch.zeros((n, k, 8), dtype=torch.float32, device=params[0].device)
+                aux0[..., 1] = 1.0
+                hg = (aux0, z0[..., :2].contiguous(), z0, True)
+            with _lib.device_guard(hg[0]):
+                module.engine.backward(P, G, ctx.ectx, None, dfeats, head_grads=hg)
+            ctx.ectx = None
+            return (None, None, None) + tuple(G.get(n) for n in module._pnames)
         dl_nhwc = ctx.slot.take() if ctx.slot is not None else None
         if dl_nhwc is not None and all(s == 0 for s in dlogits.stride()):
             dlogits = None
@@ -213,6 +238,7 @@ class UNet(nn.Module):
         self._flat = None
         self.last_flat_grad = None
         self.flat_grad_hook = None     # called with the flat gradient buffer at the start of every backward (DDP)
+        self._fuse_head = False        # set inside ``with model.fused_head():``
 
     def initialize_weights(self, module: nn.Module) -> None:
         """Kaiming-normal(a=negative_slope) weights, zero conv biases (reference unet2.py:309-314)."""
@@ -235,6 +261,20 @@ class UNet(nn.Module):
         self._ensure_flat()
         return self._flat, self.last_flat_grad
 
+    @contextlib.contextmanager
+    def fused_head(self):
+        """Inside this block a grad-enabled ``forward`` may return a PLACEHOLDER for the logits (a stride-0 zero tensor of
+        their shape): the last ConvLayer's activation, the 1x1 OutputBlock and the DSNT moments then run as one pass over
+        that layer's raw output inside ``cu_hip.head.dsnt_nll`` (head_fused.hip), and the logits never exist.  Only
+        ``dsnt_nll`` may consume such a tensor (its shape is real, its values are not) -- which is why this is opt-in and
+        used by the dsnt tasks' ``_shared_step`` alone.  Not taken (ordinary logits come back) in f32 parity mode, without
+        grad, in deterministic mode, or for shapes the kernels do not serve."""
+        prev, self._fuse_head = self._fuse_head, True
+        try:
+            yield self
+        finally:
+            self._fuse_head = prev
+
     def forward(self, input_data: Tensor):  # noqa: D102
         _lib.require_gpu()
         if not input_data.is_cuda:
@@ -245,6 +285,8 @@ class UNet(nn.Module):
             raise _lib.ContourHipError(f"input on {input_data.device}, parameters on {params[0].device}")
         from cu_hip.head import GradSlot
         slot = GradSlot(self.engine.dtype) if torch.is_grad_enabled() else None
+        if slot is not None and self._fuse_head and input_data.dim() == 4:
+            slot.fused = self.engine.head_fusable(input_data.shape[0], input_data.shape[2], input_data.shape[3])
         with _lib.device_guard(input_data):
             out = _UNetFn.apply(self, slot, input_data.float(), *params)
         if slot is not None:

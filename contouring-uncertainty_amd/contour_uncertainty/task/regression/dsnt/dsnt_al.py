@@ -7,6 +7,7 @@ Same constructor keys, step-dict keys and predict outputs as the reference class
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, Tuple
 
 import numpy as np
@@ -52,7 +53,9 @@ class DSNTAleatoric(AleatoricUncertaintyTask):
 
     def _shared_step(self, batch: Dict[str, Tensor], batch_idx: int) -> Dict[str, Tensor]:  # noqa: D102
         x, y = batch[Tags.img], batch[ContourTags.contour]
-        heatmaps = self.model(x)
+        # (inside fused_head() the heat maps may be a placeholder that only dsnt_nll reads: cu_hip/head_fused.hip)
+        with (self.model.fused_head() if hasattr(self.model, "fused_head") else contextlib.nullcontext()):
+            heatmaps = self.model(x)
         logs, pixel_coords, _ = dsnt_nll(heatmaps, y, None, self.hparams.covar, self.hparams.mse_weight,
                                          self.hparams.log_penalty_weight)
         if self.is_val_step and Tags.gt in batch:

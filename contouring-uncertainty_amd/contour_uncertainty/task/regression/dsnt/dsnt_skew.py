@@ -5,6 +5,7 @@ sibling module (``self.skew_block``), so checkpoint keys are ``model.*`` and ``s
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, Tuple
 
 import torch
@@ -59,7 +60,9 @@ class DSNTSkew(SkewUncertaintyTask):
 
     def _shared_step(self, batch: Dict[str, Tensor], batch_idx: int) -> Dict[str, Tensor]:  # noqa: D102
         x, y = batch[Tags.img], batch[ContourTags.contour]
-        heatmaps, features = self.model(x)
+        # (inside fused_head() the heat maps may be a placeholder that only dsnt_nll reads: cu_hip/head_fused.hip)
+        with (self.model.fused_head() if hasattr(self.model, "fused_head") else contextlib.nullcontext()):
+            heatmaps, features = self.model(x)
         alpha = self._alpha(heatmaps, features)
         logs, pixel_coords, _ = dsnt_nll(heatmaps, y, alpha, self.hparams.covar)
         if self.is_val_step and Tags.gt in batch:

@@ -94,6 +94,47 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- halving butterfly over the 32 pixel lanes of a half wave (MFMA 32x32 output layout: a lane owns one pixel, register i
+// of a column block is channel (i & 3) + 8 (i >> 2) + 4 h).  8 + 4 + 2 + 1 exchanges bring 16 registers down to one per
+// lane in DPP / permlane-swap form; lane l then holds the total of register
+// i = (l & 1) << 3 | (l & 2) << 1 | (l & 8) >> 2 | (l & 16) >> 4 (bit 2 of l: replicated).  See igemm_conv.hip (tile_stats).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_reduce16(float (&v)[16], int lane) {
+    {   // lanes l, l ^ 1 (quad_perm [1,0,3,2]): odd lanes keep registers 8..15
+        const bool up = lane & 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float lo = v[j] + dpp_mov<0xB1>(v[j]), hi = v[j + 8] + dpp_mov<0xB1>(v[j + 8]);
+            v[j] = up ? hi : lo;
+        }
+    }
+    {   // l, l ^ 2 (quad_perm [2,3,0,1])
+        const bool up = lane & 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = v[j] + dpp_mov<0x4E>(v[j]), hi = v[j + 4] + dpp_mov<0x4E>(v[j + 4]);
+            v[j] = up ? hi : lo;
+        }
+    }
+    {   // l, l ^ 8 (row_ror:8)
+        const bool up = lane & 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float lo = v[j] + dpp_mov<0x128>(v[j]), hi = v[j + 2] + dpp_mov<0x128>(v[j + 2]);
+            v[j] = up ? hi : lo;
+        }
+    }
+    // l, l ^ 16: v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second: the two
+    // results are (v0 of rows 0,0,2,2 | v1 of rows ... ) such that their sum is v0 + v0' in even rows, v1 + v1' in odd rows
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
+    const float t = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    return t + __shfl_xor(t, 4, 64);
+}
+
+
 // ---- LDS-DMA helpers (gfx950: buffer_load_dwordx4 ... lds) ----------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 

@@ -543,42 +543,6 @@ constexpr int DW = 8;                 // waves
 // exchanges bring the 16 registers down to one per lane -- in DPP / permlane-swap form (no LDS round trip), one last LDS
 // permute joins the lane pairs the DPP patterns cannot reach.  The totals end up one channel per lane.
 // Lane l then holds register i = (l & 1) << 3 | (l & 2) << 1 | (l & 8) >> 2 | (l & 16) >> 4 (bit 2 of l: replicated).
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float lane_reduce16(float (&v)[16], int lane) {
-    {   // lanes l, l ^ 1 (quad_perm [1,0,3,2]): odd lanes keep registers 8..15
-        const bool up = lane & 1;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float lo = v[j] + dpp_mov<0xB1>(v[j]), hi = v[j + 8] + dpp_mov<0xB1>(v[j + 8]);
-            v[j] = up ? hi : lo;
-        }
-    }
-    {   // l, l ^ 2 (quad_perm [2,3,0,1])
-        const bool up = lane & 2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float lo = v[j] + dpp_mov<0x4E>(v[j]), hi = v[j + 4] + dpp_mov<0x4E>(v[j + 4]);
-            v[j] = up ? hi : lo;
-        }
-    }
-    {   // l, l ^ 8 (row_ror:8)
-        const bool up = lane & 8;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float lo = v[j] + dpp_mov<0x128>(v[j]), hi = v[j + 2] + dpp_mov<0x128>(v[j + 2]);
-            v[j] = up ? hi : lo;
-        }
-    }
-    // l, l ^ 16: v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second: the two
-    // results are (v0 of rows 0,0,2,2 | v1 of rows ... ) such that their sum is v0 + v0' in even rows, v1 + v1' in odd rows
-    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
-    const float t = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    return t + __shfl_xor(t, 4, 64);
-}
-
 // All 8 waves call this after their MFMAs (it starts with a barrier: the LDS is reused).  valid[a]: block a holds pixels
 // of an existing image; img_l: the wave's image inside the tile (wave-uniform: the host only enables the statistics when
 // a wave's 32 * MA pixels lie in one image).  Every wave stores its 2 x BN column totals into a slot of its own; after one

@@ -81,6 +81,8 @@ class UNetCtx:
     bott: Optional[Act] = None
     last: Optional[Act] = None
     n_up: int = 0
+    raw_prefix: Optional[str] = None     # fused head: this layer keeps only its raw output + statistics
+    head: Optional[dict] = None          # fused head: {"act", "w_cls", "w_ch"} of the launch pair in head_fused.hip
 
 
 class _WsArena:
@@ -134,6 +136,11 @@ class UNetEngine:
         # True: on maps of <= 64 pixels (8x8 and below) the split-K finish pass of the convolution / input-gradient launch
         # carries the layer's InstanceNorm + LeakyReLU forward / backward (no separate, latency-bound norm launch)
         self.small_norm = os.environ.get("CONTOUR_SMALL_NORM", "1") == "1"
+        # True: when the caller asks for it (UNet.fused_head(), i.e. the dsnt tasks' training step), the last ConvLayer's
+        # InstanceNorm + LeakyReLU, the 1x1 OutputBlock and the DSNT moments run as ONE pass over that layer's raw output, and
+        # the backward of all three (+ the reduction pass of that layer's norm backward) as one more (head_fused.hip)
+        self.fused_head = os.environ.get("CONTOUR_FUSED_HEAD", "1") == "1"
+        self._head_parts: Optional[Tensor] = None
         self._bwd_done = set()
         # True: InstanceNorm + LeakyReLU forward (statistics + materialise) and backward (reduce + apply) each run as ONE
         # resident-chunk launch that reads every tensor once (norm.hip); False: the two-pass kernels
@@ -244,7 +251,8 @@ class UNetEngine:
                 out = Act(z, small[4], self.slope, small[5], None)
             else:
                 out = ops.instnorm_fwd_given(z, P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"], self.slope, sums,
-                                             P[f"{prefix}.conv.bias"], self.eps, materialize=not self._lazy(ctx, z))
+                                             P[f"{prefix}.conv.bias"], self.eps,
+                                             materialize=not (self._lazy(ctx, z) or prefix == ctx.raw_prefix))
             if not ctx.keep and out.a is not None:
                 return Act(out.a, None, 1.0)
             ctx.convs[prefix] = _ConvRec(prefix, srcs, out, stride, drop_mask=None)
@@ -258,7 +266,7 @@ class UNetEngine:
                 keep = torch.rand((n, co), device=z.device) >= self.drop_p
                 mask = keep.float() / (1.0 - self.drop_p)
             ops.channel_scale(z, mask)
-        out = self._norm_act_fwd(P, prefix, z, ctx)
+        out = self._norm_act_fwd(P, prefix, z, ctx, raw=prefix == ctx.raw_prefix)
         if not ctx.keep and out.a is not None:
             return Act(out.a, None, 1.0)      # inference: z, the statistics and the layer record die here
         ctx.convs[prefix] = _ConvRec(prefix, srcs, out, stride, drop_mask=mask)
@@ -280,12 +288,12 @@ class UNetEngine:
         return src.a is None and src.stats is not None and (ci, co) in ((32, 32), (64, 64)) and n * h * w_ >= (1 << 20) \
             and h % 8 == 0 and w_ % 32 == 0
 
-    def _norm_act_fwd(self, P, prefix: str, z: Tensor, ctx: Optional["UNetCtx"] = None) -> Act:
+    def _norm_act_fwd(self, P, prefix: str, z: Tensor, ctx: Optional["UNetCtx"] = None, raw: bool = False) -> Act:
         gamma, beta = P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"]
         if self.fused_norm and self.materialize:
             ws = self._arena["fwd"].take(ops.resident_ws_floats(z.shape[0], z.shape[3]), z.device)
             return ops.instnorm_fwd_fused(z, gamma, beta, self.slope, self.eps, ws=ws, mode=self._norm_mode(),
-                                          materialize=not (ctx is not None and self._lazy(ctx, z)))
+                                          materialize=not (raw or (ctx is not None and self._lazy(ctx, z))))
         out = Act(z, ops.instnorm_stats(z, gamma, beta, self.eps), self.slope)
         if self.materialize:
             ops.instnorm_apply(out)
@@ -335,8 +343,13 @@ class UNetEngine:
         return out
 
     # ------------------------------------------------------------------------------------------ forward
+    def head_fusable(self, n: int, h: int, w_: int) -> bool:
+        """True when ``forward(fused_head=True)`` will take the fused head for an (n, 1, h, w_) batch."""
+        return (self.fused_head and self.fused_norm and self.materialize and not self.deterministic and self.debug is None
+                and not self.lazy_act and ops.head_fused_ok(n, h, w_, self.filters[0], self.num_classes, self.dtype))
+
     def forward(self, P: Dict[str, Tensor], img: Tensor, want_bottleneck: bool, training: bool = False,
-                keep: bool = True):
+                keep: bool = True, fused_head: bool = False):
         """P: parameter name -> float32 device tensor (reference names).  img: (N, 1, H, W) float32.
         keep=False (no gradient will be asked for): every layer drops its raw output and statistics as soon as its
         activated output exists, so predict-time peak memory is the encoder skips + one block, not a training step's."""
@@ -346,6 +359,9 @@ class UNetEngine:
         if self.debug is not None:
             self._last_ctx = ctx
         st = self.strides
+        fused_head = fused_head and keep and self.head_fusable(img.shape[0], img.shape[2], img.shape[3])
+        if fused_head:      # the last ConvLayer feeds nothing but the head: its activation is never materialised
+            ctx.raw_prefix = f"upsamples.{len(st) - 2}.conv_block.conv2"
         assert st[0] == 1
         self._arena["fwd"].begin(img.device)
         self._producer.clear()
@@ -368,10 +384,16 @@ class UNetEngine:
         ctx.n_up = len(ctx.enc)
         # (the 1x1 head's kernels read the materialised activation: the generic kernel's fused load made the head's forward
         # 419 instead of 143 us and its weight gradient 231 instead of 165 us at batch 64 -- profiles/r03_lazy_act.txt)
+        w = P["output_block.conv.weight"]
+        if fused_head and a.a is None and a.stats is not None:
+            # fused head (head_fused.hip): the caller (cu_hip.head) runs cu_head_fused_fwd on the raw output; no logits
+            wf, wd = self._operands("output_block.conv.weight", w, "conv", cop=32)
+            ctx.last = a
+            ctx.head = {"act": a, "w_cls": wf, "w_ch": wd, "k": self.num_classes}
+            return None, feats, ctx
         a = ops.materialized(a)
         ctx.last = a
         # 1x1 output conv -> NCHW f32 logits (K planes; GEMM columns padded to 32)
-        w = P["output_block.conv.weight"]
         wf, _ = self._operands("output_block.conv.weight", w, "conv", cop=32)
         n, h, w_, _ = a.z.shape
         logits = torch.empty((n, self.num_classes, h, w_), dtype=torch.float32, device=img.device)
@@ -592,12 +614,12 @@ class UNetEngine:
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, P: Dict[str, Tensor], G: Dict[str, Tensor], ctx: UNetCtx, dlogits: Optional[Tensor],
-                 dfeats: Optional[Tensor], dl_nhwc: Optional[Tensor] = None):
+                 dfeats: Optional[Tensor], dl_nhwc: Optional[Tensor] = None, head_grads: Optional[tuple] = None):
         """Accumulates parameter gradients into G (float32, reference layouts; every touched tensor is ``+=``).
         dL/dlogits arrives as ``dlogits`` (N, K, H, W) float32 and / or as ``dl_nhwc`` (N, H, W, 32) in the engine's
         element type (``cu_dsnt_head_bwd_nhwc``); both given = their sum."""
         try:
-            self._backward(P, G, ctx, dlogits, dfeats, dl_nhwc)
+            self._backward(P, G, ctx, dlogits, dfeats, dl_nhwc, head_grads)
         except BaseException:
             # an aborted step (launch error, OOM, KeyboardInterrupt, an exception from the DDP ready hook) must not leave
             # state behind that a later step would silently consume: join the weight-gradient stream, drop the epilogue
@@ -618,7 +640,25 @@ class UNetEngine:
                     hook.abort()
             raise
 
-    def _backward(self, P, G, ctx: UNetCtx, dlogits, dfeats, dl_nhwc):
+    def _head_bwd(self, P, G, ctx: UNetCtx, head_grads) -> Tensor:
+        """fused head backward: dL/d(mu, Sigma) -> g = dL/d(activation of the last ConvLayer); that layer's norm-backward sums
+        and the 1x1 weight gradient come out of the same launch (cu_head_fused_bwd)."""
+        hd = ctx.head
+        act: Act = hd["act"]
+        n = act.z.shape[0]
+        dev = act.z.device
+        aux, gmu, gsigma, covar = head_grads
+        sums = self._arena["bwd"].take(2 * n * 32, dev)
+        if self._head_parts is None or self._head_parts.device != dev:
+            self._head_parts = torch.empty(1025 * 1024, dtype=torch.float32, device=dev)
+        g, slabs = ops.head_fused_bwd(act, hd["w_cls"], hd["w_ch"], hd["k"], aux, gmu.contiguous(), gsigma.contiguous(),
+                                      bool(covar), sums, self._head_parts)
+        ops.grad_unprep_parts(self._head_parts, slabs, 32, G["output_block.conv.weight"], "conv", accumulate=True)
+        self._ready("output_block")
+        self._given_sums[ctx.raw_prefix] = sums
+        return g
+
+    def _backward(self, P, G, ctx: UNetCtx, dlogits, dfeats, dl_nhwc, head_grads=None):
         dt = self.dtype
         last = ctx.last
         n, h, w_, c_last = last.z.shape
@@ -628,6 +668,17 @@ class UNetEngine:
         # the previous backward joined the reduction stream into this one: its "buffer read" events are history (and must not
         # be waited for inside a hipGraph capture, which they precede)
         self._red_done = [None, None]
+        if ctx.head is not None:
+            assert head_grads is not None and dlogits is None and dl_nhwc is None, "fused head: gradients arrive as head_grads"
+            g = self._head_bwd(P, G, ctx, head_grads)
+        else:
+            g = self._output_bwd(P, G, ctx, dlogits, dl_nhwc)
+        self._decoder_encoder_bwd(P, G, ctx, g, dfeats)
+
+    def _output_bwd(self, P, G, ctx: UNetCtx, dlogits, dl_nhwc) -> Tensor:
+        dt = self.dtype
+        last = ctx.last
+        n, h, w_, c_last = last.z.shape
         # ---- 1x1 output conv
         if dl_nhwc is not None:
             assert dl_nhwc.dtype == dt and dl_nhwc.shape == (n, h, w_, 32)
@@ -642,7 +693,10 @@ class UNetEngine:
         g = torch.empty_like(last.z)
         ops.conv_gemm([Act(dl, None, 1.0)], wd, None, grid=(h, w_), in_stride=1, taps=[(0, 0, 0)], dsts=[g],
                       dst_cols=[c_last], alg_cin=self.num_classes)
-        del dl
+        return g
+
+    def _decoder_encoder_bwd(self, P, G, ctx: UNetCtx, g: Tensor, dfeats):
+        dt = self.dtype
         # ---- decoder
         d_enc: List[Optional[Tensor]] = [None] * len(ctx.enc)
         n_up = ctx.n_up

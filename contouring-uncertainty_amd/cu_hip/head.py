@@ -30,12 +30,31 @@ class GradSlot:
     gradient -- ``torch.autograd.grad(loss, logits)``, ``logits.retain_grad()``, a tensor hook on the logits: those see the
     zero stand-in.  ``dsnt_nll(..., dense_grad=True)`` (or ``slot.enabled = False``) selects the dense NCHW float32
     gradient for such uses."""
-    __slots__ = ("dtype", "dl", "enabled")
+    __slots__ = ("dtype", "dl", "enabled", "fused", "head", "head_grads")
 
     def __init__(self, dtype):
         self.dtype = dtype
         self.dl: Optional[Tensor] = None
         self.enabled = True
+        # fused head (head_fused.hip; ``UNet.fused_head()``): ``fused`` = asked for, ``head`` = the engine's handle when the
+        # forward took it (the logits are then a placeholder), ``head_grads`` = (aux, dL/dmu, dL/dSigma3, covar) on the way back
+        self.fused = False
+        self.head: Optional[dict] = None
+        self.head_grads: Optional[tuple] = None
+
+    def put_head(self, aux: Tensor, gmu: Tensor, gsigma: Tensor, covar: bool):
+        if not covar:
+            gsigma = gsigma.clone()
+            gsigma[..., 2] = 0
+        if self.head_grads is None:
+            self.head_grads = (aux, gmu, gsigma, True)
+        else:       # several heads on the same logits: dL/dlogits is linear in (dL/dmu, dL/dSigma)
+            a0, m0, s0, _ = self.head_grads
+            self.head_grads = (a0, m0 + gmu, s0 + gsigma, True)
+
+    def take_head(self) -> Optional[tuple]:
+        hg, self.head_grads = self.head_grads, None
+        return hg
 
     def put(self, dl: Tensor):
         self.dl = dl if self.dl is None else self.dl + dl
@@ -49,15 +68,26 @@ class _DsntNllFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits: Tensor, y: Tensor, alpha: Optional[Tensor], covar: bool, w_mse: float, w_log: float,
                 slot: Optional[GradSlot] = None):
-        ctx.slot = slot if (slot is not None and slot.enabled and logits.is_contiguous()) else None
-        logits = logits.contiguous()
+        fused = slot is not None and slot.head is not None
+        ctx.fused = fused
+        if fused:
+            ctx.slot = slot          # ``logits`` is the placeholder of UNet.fused_head(): never read
+        else:
+            ctx.slot = slot if (slot is not None and slot.enabled and logits.is_contiguous()) else None
+            logits = logits.contiguous()
         need_grad = logits.requires_grad or (alpha is not None and alpha.requires_grad)
-        with ops.L.device_guard(logits):
-            mu, sigma, aux = ops.dsnt_head_fwd(logits, covar)
+        with ops.L.device_guard(y if fused else logits):
+            if fused:
+                hd = slot.head
+                mu, sigma, aux = ops.head_fused_fwd(hd["act"], hd["w_cls"], hd["k"], covar)
+                logits = logits.new_empty(0)
+            else:
+                mu, sigma, aux = ops.dsnt_head_fwd(logits, covar)
             al = alpha.contiguous().float() if alpha is not None else None
             logs, gmu, gsigma, galpha = ops.nll_fwd_bwd(mu, sigma, y.contiguous().float(), al, w_mse, w_log, need_grad)
         ctx.covar = covar
         ctx.has_alpha = alpha is not None
+        ctx.map_hw = (slot.head["act"].z.shape[1], slot.head["act"].z.shape[2]) if fused else None
         if need_grad:
             ctx.save_for_backward(logits, aux, gmu, gsigma, galpha if galpha is not None else torch.empty(0))
         ctx.mark_non_differentiable(logs, mu, sigma)
@@ -67,6 +97,12 @@ class _DsntNllFn(torch.autograd.Function):
     def backward(ctx, gloss, _glogs, _gmu, _gsigma):
         logits, aux, gmu, gsigma, galpha = ctx.saved_tensors
         scale = gloss.reshape(1)
+        if ctx.fused:
+            # dL/d(mu, Sigma) go to the UNet's backward, which runs cu_head_fused_bwd (no dL/dlogits anywhere)
+            ctx.slot.put_head(aux, (gmu * scale).contiguous(), (gsigma * scale).contiguous(), ctx.covar)
+            shape = (gmu.shape[0], gmu.shape[1]) + tuple(ctx.map_hw)
+            dl = torch.zeros((), dtype=torch.float32, device=gmu.device).expand(shape)
+            return dl, None, ((galpha * scale) if ctx.has_alpha else None), None, None, None, None
         with ops.L.device_guard(logits):
             if ctx.slot is not None:
                 ctx.slot.put(ops.dsnt_head_bwd_nhwc(logits, aux, (gmu * scale).contiguous(), (gsigma * scale).contiguous(),
@@ -83,7 +119,12 @@ def dsnt_nll(logits: Tensor, y: Tensor, alpha: Optional[Tensor] = None, covar: b
     """logits (N,K,H,W) f32, y (N,K,2) pixel (x,y), alpha (N,K,2) or None ->
     (logs dict of 0-dim tensors with a differentiable ``loss``, mu (N,K,2), Sigma (N,K,2,2)).
     ``dense_grad``: give autograd the real NCHW float32 dL/dlogits instead of the :class:`GradSlot` hand-over."""
-    slot = None if dense_grad else getattr(logits, "_cu_grad_slot", None)
+    slot = getattr(logits, "_cu_grad_slot", None)
+    if slot is not None and slot.head is not None:
+        if dense_grad:
+            raise ValueError("dense_grad=True needs real logits: call the UNet outside `with model.fused_head():`")
+    elif dense_grad:
+        slot = None
     loss, logs, mu, sigma3 = _DsntNllFn.apply(logits, y, alpha, bool(covar), float(mse_weight),
                                               float(log_penalty_weight), slot)
     out: Dict[str, Tensor] = {"loss": loss, "distance_loss": logs[1], "loss_term1": logs[2], "loss_term2": logs[3]}

@@ -83,6 +83,9 @@ _SIGS = {
     "cu_dsnt_head_fwd": (C.c_int, [C.c_int] * 3 + [_P, C.c_int] + [_P] * 4),
     "cu_dsnt_head_bwd": (C.c_int, [C.c_int] * 3 + [_P] * 4 + [C.c_int] + [_P] * 2),
     "cu_dsnt_head_bwd_nhwc": (C.c_int, [C.c_int] * 5 + [_P] * 4 + [C.c_int] + [_P] * 2),
+    "cu_head_fused_ws_floats": (C.c_size_t, [C.c_int] * 3),
+    "cu_head_fused_fwd": (C.c_int, [C.c_int] * 4 + [_P, _P, C.c_float, _P, C.c_int, _P, C.c_size_t] + [_P] * 4),
+    "cu_head_fused_bwd": (C.c_int, [C.c_int] * 4 + [_P, _P, C.c_float] + [_P] * 5 + [C.c_int] + [_P] * 3 + [C.c_size_t, C.POINTER(C.c_int), _P]),
     "cu_nll_fwd_bwd": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float] + [_P] * 10),
     "cu_linear_fwd": (C.c_int, [C.c_int] * 3 + [_P] * 5),
     "cu_linear_bwd": (C.c_int, [C.c_int] * 3 + [_P] * 7),

@@ -465,6 +465,55 @@ def dsnt_head_bwd_nhwc(logits: Tensor, aux: Tensor, gmu: Tensor, gsigma: Tensor,
     return dl
 
 
+def head_fused_ok(n: int, h: int, w_: int, c: int, k: int, dtype) -> bool:
+    """shapes ``head_fused_fwd`` / ``head_fused_bwd`` serve (head_fused.hip)"""
+    return dtype == torch.bfloat16 and c == 32 and 0 < k <= 32 and h == w_ and w_ % 32 == 0 and h % 16 == 0 and \
+        n * h * w_ * 64 < 0x7fff0000 * 4
+
+
+def head_fused_fwd(act: Act, w_cls: Tensor, k: int, use_covar: bool = True):
+    """InstanceNorm + LeakyReLU of the last ConvLayer -> 1x1 OutputBlock -> DSNT moments from the RAW conv output in one pass
+    (cu_head_fused_fwd): ``act`` = Act(z (N, H, W, 32) bf16, stats), ``w_cls`` (1, 32, 32) bf16 class-major.
+    -> mu (N, K, 2), sigma (N, K, 3), aux (N, K, 8) as :func:`dsnt_head_fwd`."""
+    lib = L.load()
+    z = act.z
+    n, h, w_, c = z.shape
+    assert head_fused_ok(n, h, w_, c, k, z.dtype) and act.stats is not None and w_cls.dtype == torch.bfloat16 and w_cls.numel() == 1024
+    dev = z.device
+    mu = torch.empty((n, k, 2), dtype=torch.float32, device=dev)
+    sigma = torch.empty((n, k, 3), dtype=torch.float32, device=dev)
+    aux = torch.empty((n, k, 8), dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.cu_head_fused_ws_floats(n, h, w_), dtype=torch.float32, device=dev)
+    flops = 2.0 * n * h * w_ * 32 * k
+    with _Prof("dsnt_head", flops, f"N{n} {h}x{w_} fused head fwd", z.numel() * 2, 2.0 * n * h * w_ * 32 * 32):
+        L.check(lib.cu_head_fused_fwd(n, h, w_, k, L.ptr(z), L.ptr(act.stats), act.slope, L.ptr(w_cls), int(use_covar), L.ptr(ws),
+                                      ws.numel(), L.ptr(mu), L.ptr(sigma), L.ptr(aux), L.stream_ptr()), "cu_head_fused_fwd")
+    return mu, sigma, aux
+
+
+_HEAD_PARTS_FLOATS = 1025 * 1024
+
+
+def head_fused_bwd(act: Act, w_cls: Tensor, w_ch: Tensor, k: int, aux: Tensor, gmu: Tensor, gsigma: Tensor, use_covar: bool,
+                   sums: Tensor, parts: Tensor):
+    """dL/d(mu, Sigma) -> g = dL/d(activation of the last ConvLayer) (N, H, W, 32) bf16, ``sums`` (N, 32, 2) += the two sums of
+    that layer's InstanceNorm backward (:func:`instnorm_bwd_given`), ``parts`` <- partial 1x1 weight gradients; returns
+    (g, slabs) with ``slabs`` for :func:`grad_unprep_parts` (cu_head_fused_bwd)."""
+    import ctypes as _C
+    lib = L.load()
+    z = act.z
+    n, h, w_, c = z.shape
+    assert head_fused_ok(n, h, w_, c, k, z.dtype) and parts.numel() >= _HEAD_PARTS_FLOATS and sums.numel() >= 2 * n * 32
+    g = torch.empty_like(z)
+    nparts = _C.c_int(0)
+    flops = 3 * 2.0 * n * h * w_ * 32 * k            # logits again, input gradient, weight gradient
+    with _Prof("dsnt_head", flops, f"N{n} {h}x{w_} fused head bwd", 2 * z.numel() * 2, 3 * 2.0 * n * h * w_ * 32 * 32):
+        L.check(lib.cu_head_fused_bwd(n, h, w_, k, L.ptr(z), L.ptr(act.stats), act.slope, L.ptr(w_cls), L.ptr(w_ch), L.ptr(aux),
+                                      L.ptr(gmu), L.ptr(gsigma), int(use_covar), L.ptr(g), L.ptr(sums), L.ptr(parts),
+                                      parts.numel(), _C.byref(nparts), L.stream_ptr()), "cu_head_fused_bwd")
+    return g, (nparts.value, 0xffff)
+
+
 def nll_fwd_bwd(mu: Tensor, sigma: Tensor, y: Tensor, alpha: Optional[Tensor], w_mse: float = 1.0,
                 w_log: float = 1.0, need_grad: bool = True, terms: Optional[Tensor] = None):
     m = mu.numel() // 2

@@ -272,6 +272,26 @@ int cu_dsnt_head_bwd(int NK, int H, int W, const float* logits, const float* aux
 int cu_dsnt_head_bwd_nhwc(int dtype, int N, int K, int H, int W, const float* logits, const float* aux,
                           const float* gmu, const float* gsigma, int use_covar, void* dl, void* stream);
 
+/* Fused head of the bf16 production path (head_fused.hip): the LAST ConvLayer's InstanceNorm + LeakyReLU (layers.py:192-205),
+ * the 1x1 OutputBlock (layers.py:441-463) and the DSNT moments above in one pass over that layer's RAW output -- the
+ * activation, the logits and dL/dlogits never exist in HBM.
+ *   z [N][H][W][32] bf16 (raw conv output), stats [4][N][32] f32 (the planes of cu_instnorm_stats), slope;
+ *   w_cls [32][32] bf16 = the 1x1 weight, class-major, rows K..31 zero (cu_weight_prep's forward copy with COP = 32);
+ *   w_ch  [32][32] bf16 = the same weight channel-major (cu_weight_prep's input-gradient copy).
+ * Square maps, W % 32 == 0, H % 16 == 0, K <= 32.
+ * forward: ws = scratch of cu_head_fused_ws_floats(N, H, W) floats (per-tile partial moments); mu / sigma / aux as
+ *   cu_dsnt_head_fwd (aux feeds either backward).
+ * backward: g [N][H][W][32] bf16 = dL/d(activation of the last ConvLayer) (written); sums [N][32][2] += the two sums of that
+ *   layer's InstanceNorm backward (consumer: cu_instnorm_bwd_given); parts = scratch of >= 1025 * 1024 floats that receives
+ *   *nparts partial 1x1 weight gradients in the plain [32 classes][32 channels] layout (consumer: cu_grad_unprep_parts with
+ *   layout CU_PARTS_PLAIN = 0xffff, T = 1, COP = 32).  gmu / gsigma as cu_dsnt_head_bwd. */
+size_t cu_head_fused_ws_floats(int N, int H, int W);
+int cu_head_fused_fwd(int N, int H, int W, int K, const void* z, const float* stats, float slope, const void* w_cls,
+                      int use_covar, float* ws, size_t ws_floats, float* mu, float* sigma, float* aux, void* stream);
+int cu_head_fused_bwd(int N, int H, int W, int K, const void* z, const float* stats, float slope, const void* w_cls,
+                      const void* w_ch, const float* aux, const float* gmu, const float* gsigma, int use_covar, void* g,
+                      float* sums, float* parts, size_t parts_floats, int* nparts, void* stream);
+
 /* Gaussian NLL of dsnt_al.py:64-74 and skew-normal NLL of bivariateskewnormal.py:36-61 (closed-form 2x2 algebra,
  * Sigma^-1/2 = ((Sigma + sqrt(det) I)/sqrt(tr + 2 sqrt(det)))^-1 instead of distributions/utils.py:100-129's eig).
  * y [M][2]; alpha [M][2] or NULL (gauss).  logs[8] = {loss, distance_loss, term1, term2, term3, alpha_norm, 0, 0}

@@ -1,0 +1,198 @@
+"""Fused head (head_fused.hip: InstanceNorm + LeakyReLU of the last ConvLayer -> 1x1 OutputBlock -> DSNT moments, and its
+backward) against (i) the unfused kernel chain it replaces and (ii) a float64 PyTorch restatement of the same math
+(reference layers.py:192-205,441-463; dsnt/utils.py:7-47,71-77; dsnt_al.py:52-60).
+
+Both GPU paths see the same bf16 activation and bf16 weights, so they differ by accumulation order, the exp
+implementation and the f32-vs-f64 moment sums only: the forward is held to 1e-4 (north_star's bound for mu / Sigma), the
+backward to the bf16 rounding of its operands.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+SLOPE = 0.01
+
+
+def _setup(n, size, k, seed, peak=3.0):
+    from cu_hip import ops
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    z = (torch.randn(n, size, size, 32, device=DEV, generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    gamma = torch.rand(32, device=DEV, generator=g) + 0.5
+    beta = torch.randn(32, device=DEV, generator=g) * 0.2
+    act = ops.instnorm_fwd_fused(z, gamma, beta, SLOPE)                     # Act(z, stats, a)
+    w = torch.randn(k, 32, 1, 1, device=DEV, generator=g) * (peak / 32 ** 0.5)
+    w_cls, w_ch = ops.weight_prep(w, "conv", torch.bfloat16, 32)
+    return ops, act, w, w_cls, w_ch
+
+
+def _unfused_fwd(ops, act, w_cls, k, covar):
+    n, h, w_, _ = act.z.shape
+    logits = torch.empty((n, k, h, w_), dtype=torch.float32, device=DEV)
+    ops.conv_gemm([ops.Act(act.a, None, 1.0)], w_cls, None, grid=(h, w_), in_stride=1, taps=[(0, 0, 0)], dsts=[logits],
+                  dst_cols=[32], out_nchw=True, n_cols=32)
+    return logits, ops.dsnt_head_fwd(logits, covar)
+
+
+def _f64_moments(act, w_cls, k):
+    """the same bf16 activation and weights, everything else in float64 on the CPU"""
+    a = act.a.double().cpu()                                            # (N, H, W, 32)
+    wk = w_cls.view(32, 32)[:k].double().cpu()                          # (K, 32)
+    n, h, w_, _ = a.shape
+    logits = torch.einsum("nhwc,kc->nkhw", a, wk)
+    p = torch.softmax(logits.reshape(n, k, -1), -1).reshape(n, k, h, w_)
+    lin = (2 * torch.arange(w_, dtype=torch.float64) + 1) / w_ - 1
+    X, Y = lin[None, None, None, :], lin[None, None, :, None]
+    xb, yb = (p * X).sum((2, 3)), (p * Y).sum((2, 3))
+    vx = (p * (X - xb[..., None, None]) ** 2).sum((2, 3))
+    vy = (p * (Y - yb[..., None, None]) ** 2).sum((2, 3))
+    cv = (p * (X - xb[..., None, None]) * (Y - yb[..., None, None])).sum((2, 3))
+    mu = torch.stack([0.5 * ((xb + 1) * w_ - 1), 0.5 * ((yb + 1) * h - 1)], -1)
+    sig = torch.stack([vx, vy, cv], -1) * (0.5 * w_) ** 2
+    return mu, sig
+
+
+@pytest.mark.parametrize("n,size,k,peak", [(3, 64, 21, 3.0), (2, 128, 21, 12.0), (2, 32, 5, 3.0), (1, 64, 32, 6.0),
+                                           (1, 256, 21, 25.0)])
+def test_fused_head_forward(n, size, k, peak):
+    ops, act, w, w_cls, w_ch = _setup(n, size, k, seed=size + k, peak=peak)
+    logits, (mu0, sg0, aux0) = _unfused_fwd(ops, act, w_cls, k, True)
+    mu1, sg1, aux1 = ops.head_fused_fwd(ops.Act(act.z, act.stats, SLOPE), w_cls, k, True)
+    torch.cuda.synchronize()
+    mu64, sg64 = _f64_moments(act, w_cls, k)
+    # pixel coordinates: absolute error relative to the image size; covariances: relative to their own scale
+    for name, got in (("unfused", (mu0, sg0)), ("fused", (mu1, sg1))):
+        e_mu = float((got[0].double().cpu() - mu64).abs().max()) / size
+        e_sg = float(((got[1].double().cpu() - sg64).abs() / sg64.abs().amax(-1, keepdim=True)).max())
+        assert e_mu < 1e-4 and e_sg < 1e-4, (name, e_mu, e_sg)
+    # aux: log-sum-exp = max - log(1 / sum) agrees although the two paths use different reference logits
+    lse0 = aux0[..., 0] - torch.log(aux0[..., 1])
+    lse1 = aux1[..., 0] - torch.log(aux1[..., 1])
+    assert float((lse0 - lse1).abs().max()) < 2e-4
+    assert float((aux0[..., 2:7] - aux1[..., 2:7]).abs().max()) < 1e-5
+
+
+def test_fused_head_forward_far_reference():
+    """the first pixel of a tile far below / above the rest: the moving reference logit (threshold 40) is exercised"""
+    ops, act, w, w_cls, w_ch = _setup(2, 64, 21, seed=7, peak=60.0)
+    logits, (mu0, sg0, aux0) = _unfused_fwd(ops, act, w_cls, 21, True)
+    assert float(logits.amax() - logits.amin()) > 100.0
+    mu1, sg1, aux1 = ops.head_fused_fwd(ops.Act(act.z, act.stats, SLOPE), w_cls, 21, True)
+    mu64, sg64 = _f64_moments(act, w_cls, 21)
+    assert float((mu1.double().cpu() - mu64).abs().max()) / 64 < 1e-4
+    # One map of this input is a one-pixel peak (variance 1e-11 px^2).  The fused kernel's f32 partial moments are taken
+    # about tile centres: their rounding is ~6e-8 x (half a tile)^2 = 1.5e-5 px^2 ABSOLUTE whatever the variance (the f64
+    # kernel of the parity path has no such floor); relative 2e-4 above that
+    err = (sg1.double().cpu() - sg64).abs() - 5e-5
+    assert float((err / sg64.abs().amax(-1, keepdim=True)).max()) < 2e-4
+    assert torch.isfinite(aux1).all()
+
+
+@pytest.mark.parametrize("n,size,k,covar", [(3, 64, 21, True), (2, 128, 21, False), (2, 32, 5, True), (1, 64, 32, True)])
+def test_fused_head_backward(n, size, k, covar):
+    ops, act, w, w_cls, w_ch = _setup(n, size, k, seed=100 + size + k)
+    logits, (mu0, sg0, aux0) = _unfused_fwd(ops, act, w_cls, k, covar)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    gmu = torch.randn(n, k, 2, device=DEV, generator=g) * 0.1
+    gsg = torch.randn(n, k, 3, device=DEV, generator=g) * 0.01
+    # ---- the chain the fused launch replaces
+    dl = ops.dsnt_head_bwd_nhwc(logits, aux0, gmu, gsg, covar, torch.bfloat16)
+    g_ref = torch.empty_like(act.z)
+    ops.conv_gemm([ops.Act(dl, None, 1.0)], w_ch, None, grid=(size, size), in_stride=1, taps=[(0, 0, 0)], dsts=[g_ref],
+                  dst_cols=[32], alg_cin=k)
+    gf = torch.einsum("nhwk,ck->nhwc", dl.float(), w_ch.view(32, 32).float())           # unrounded g
+    y = act.z.float() * act.stats[2][:, None, None, :] + act.stats[3][:, None, None, :]
+    gl = torch.where(y > 0, gf, gf * SLOPE)
+    zhat = (act.z.float() - act.stats[0][:, None, None, :]) * act.stats[1][:, None, None, :]
+    sums_ref = torch.stack([gl.sum((1, 2)), (gl * zhat).sum((1, 2))], -1)                # (N, 32, 2)
+    dw_ref = torch.einsum("nhwk,nhwc->kc", dl.float(), act.a.float())[:k]                # (K, 32)
+    # ---- fused
+    mu1, sg1, aux1 = ops.head_fused_fwd(ops.Act(act.z, act.stats, SLOPE), w_cls, k, covar)
+    sums = torch.zeros(n, 32, 2, device=DEV)
+    parts = torch.empty(1025 * 1024, device=DEV)
+    g_fu, slabs = ops.head_fused_bwd(ops.Act(act.z, act.stats, SLOPE), w_cls, w_ch, k, aux1, gmu, gsg, covar, sums, parts)
+    dw = torch.zeros(k, 32, 1, 1, device=DEV)
+    ops.grad_unprep_parts(parts, slabs, 32, dw, "conv", accumulate=True)
+    torch.cuda.synchronize()
+    scale = float(gf.abs().max())
+    assert float((g_fu.float() - gf).abs().max()) < 1.2e-2 * scale            # bf16 rounding of dl and of g
+    assert float((g_fu.float() - g_ref.float()).abs().max()) < 1.2e-2 * scale
+    assert float((sums - sums_ref).abs().max()) < 5e-3 * float(sums_ref.abs().max())
+    assert float((dw.view(k, 32) - dw_ref).abs().max()) < 5e-3 * float(dw_ref.abs().max())
+
+
+def test_fused_head_rejects_bad_shapes():
+    from cu_hip import lib as L, ops
+    z = torch.zeros(1, 48, 48, 32, dtype=torch.bfloat16, device=DEV)
+    st = torch.zeros(4, 1, 32, device=DEV)
+    w = torch.zeros(1, 32, 32, dtype=torch.bfloat16, device=DEV)
+    out = [torch.zeros(1, 21, 2, device=DEV), torch.zeros(1, 21, 3, device=DEV), torch.zeros(1, 21, 8, device=DEV)]
+    ws = torch.zeros(1 << 16, device=DEV)
+    rc = L.load().cu_head_fused_fwd(1, 48, 48, 21, L.ptr(z), L.ptr(st), 0.01, L.ptr(w), 1, L.ptr(ws), ws.numel(), L.ptr(out[0]),
+                                    L.ptr(out[1]), L.ptr(out[2]), L.stream_ptr())
+    assert rc == -22 and b"W % 32" in L.load().cu_last_error()
+    assert not ops.head_fused_ok(1, 48, 48, 32, 21, torch.bfloat16)
+    assert not ops.head_fused_ok(1, 64, 64, 32, 21, torch.float32)
+
+
+def _task(dtype="bf16", stages=6):
+    from contour_uncertainty._compat import DataParameters
+    from contour_uncertainty.task.regression.dsnt.dsnt_skew import DSNTSkew
+    model_cfg = {"_target_": "contour_uncertainty.models.nnUnet.unet2.UNet", "kernels": [[3, 3]] * stages,
+                 "strides": [[1, 1]] + [[2, 2]] * (stages - 1), "patch_size": [256, 256], "compute_dtype": dtype}
+    task = DSNTSkew(model=model_cfg, optim={"_target_": "torch.optim.Adam", "lr": 1e-3, "weight_decay": 1e-3}, choices={},
+                    data_params=DataParameters((1, 64, 64), (21, 2), [0, 1]), psm_path="unused.npy",
+                    seq_psm_path="unused.npy", t_a=25, t_e=1)
+    return task.to(DEV)
+
+
+def test_training_step_fused_head_equals_unfused():
+    """the dsnt-skew training step through UNet.fused_head() (placeholder logits) against the same step with the switch
+    off: same loss and logs, every parameter gradient within the bf16 rounding of the two backward chains"""
+    from contour_uncertainty.data.synthetic import synthetic_batch
+    torch.manual_seed(0)
+    task = _task()
+    img, contour = synthetic_batch(4, 64, 21, seed=3)
+    batch = {"img": img.to(DEV), "contour": contour.to(DEV)}
+    res = {}
+    for mode in (True, False):
+        task.model.engine.fused_head = mode
+        task.zero_grad(set_to_none=True)
+        out = task.training_step(batch, 0)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        res[mode] = ({k: float(v.detach()) for k, v in out.items() if torch.is_tensor(v) and v.numel() == 1},
+                     {n: p.grad.detach().clone() for n, p in task.named_parameters() if p.grad is not None})
+    logs1, g1 = res[True]
+    logs0, g0 = res[False]
+    assert set(logs1) == set(logs0)
+    for k in logs0:
+        assert abs(logs1[k] - logs0[k]) <= 2e-4 * max(1.0, abs(logs0[k])), (k, logs1[k], logs0[k])
+    assert set(g1) == set(g0)
+    worst = 0.0
+    for n in g0:
+        den = float(g0[n].norm())
+        if den < 1e-12:
+            assert float(g1[n].norm()) < 1e-10, n
+            continue
+        worst = max(worst, float((g1[n] - g0[n]).norm()) / den)
+    assert worst < 3e-2, worst
+    # the fused forward really was taken: its head handle exists only then
+    task.model.engine.fused_head = True
+    with task.model.fused_head():
+        hm, _ = task.model(batch["img"])
+    assert hm._cu_grad_slot.head is not None and all(s == 0 for s in hm.stride())
+
+
+def test_fused_head_placeholder_misuse_raises():
+    task = _task()
+    from contour_uncertainty.data.synthetic import synthetic_batch
+    img, _ = synthetic_batch(2, 64, 21, seed=3)
+    with task.model.fused_head():
+        hm, feats = task.model(img.to(DEV))
+    from cu_hip.head import dsnt_nll
+    with pytest.raises(ValueError):
+        dsnt_nll(hm, torch.zeros(2, 21, 2, device=DEV), None, True, dense_grad=True)
+    with pytest.raises(Exception):
+        (hm * torch.ones_like(hm)).sum().backward()          # a dense gradient on the placeholder

@@ -14,6 +14,22 @@ constexpr int C1_PX = 8;
 // MODE 0: z = conv + bias -> dst.
 // MODE 2 (round 3): z -> dst AND LeakyReLU(z * scale + shift) -> dst2 from finished statistics (stats planes 2 and 3, see
 //         c1_moments_kernel): the layer's conv and apply passes in one, each tensor written once and none re-read.
+// MODE 3: only the activation (dst2); z is never stored -- the backward (c1_bwd_kernel) recomputes it from the image with
+//         c1_z(), the SAME expressions, so that both sides decide the LeakyReLU branch on the same value.
+template <typename T, int PIECE>
+__device__ __forceinline__ void c1_z(const float (&v)[9], const float (&wr)[9][PIECE], const float (&b)[PIECE], float (&z)[PIECE]) {
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) z[e] = b[e];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) z[e] = fmaf(v[t], wr[t][e], z[e]);
+}
+// the value the layer's consumers see: z as stored (rounded to the storage type)
+template <typename T> __device__ __forceinline__ float c1_stored(float z) {
+    if constexpr (sizeof(T) == 2) return bf16_to_f32(f32_to_bf16(z));
+    return z;
+}
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                           const float* __restrict__ bias, T* __restrict__ dst, int N,
@@ -37,8 +53,8 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
         for (int e = 0; e < PIECE; ++e) wr[t][e] = w[t * CO + piece * PIECE + e];
 #pragma unroll
     for (int e = 0; e < PIECE; ++e) b[e] = bias ? bias[piece * PIECE + e] : 0.f;
-    float sc[MODE == 2 ? PIECE : 1], sh[MODE == 2 ? PIECE : 1];
-    if constexpr (MODE == 2) {
+    float sc[MODE >= 2 ? PIECE : 1], sh[MODE >= 2 ? PIECE : 1];
+    if constexpr (MODE >= 2) {
         const size_t NC = (size_t)N * CO, si = (size_t)n * CO + piece * PIECE;
 #pragma unroll
         for (int e = 0; e < PIECE; ++e) { sc[e] = stats[2 * NC + si + e]; sh[e] = stats[3 * NC + si + e]; }
@@ -56,24 +72,17 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < C1_PX; ++k) {
         if (x0 + k >= W) break;
-        float acc[PIECE];
+        float acc[PIECE], v9[9];
 #pragma unroll
-        for (int e = 0; e < PIECE; ++e) acc[e] = b[e];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float v = win[t / 3][k + t % 3];
-#pragma unroll
-            for (int e = 0; e < PIECE; ++e) acc[e] += v * wr[t][e];
-        }
+        for (int t = 0; t < 9; ++t) v9[t] = win[t / 3][k + t % 3];
+        c1_z<T, PIECE>(v9, wr, b, acc);
         const size_t o = (((size_t)n * H + y) * W + x0 + k) * CO + piece * PIECE;
-        store_piece<T>(dst + o, acc);
-        if constexpr (MODE == 2) {
+        if constexpr (MODE != 3) store_piece<T>(dst + o, acc);
+        if constexpr (MODE >= 2) {
             float a[PIECE];
 #pragma unroll
             for (int e = 0; e < PIECE; ++e) {
-                float zr = acc[e];
-                if constexpr (sizeof(T) == 2) zr = bf16_to_f32(f32_to_bf16(zr));
-                const float yv = zr * sc[e] + sh[e];
+                const float yv = fmaf(c1_stored<T>(acc[e]), sc[e], sh[e]);
                 a[e] = yv > 0.f ? yv : yv * slope;
             }
             store_piece<T>(dst2 + o, a);
@@ -325,6 +334,146 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_finish_kernel(const float* 
     float s = 0.f;
     for (int g = 0; g < nwg; ++g) s += part[(size_t)g * n_out + o];
     dw[o] += s;
+}
+
+// First layer, whole backward without z and without dz (round 3).  The layer's dz feeds nothing but its own 9 x CO weight
+// gradient (there is no input gradient), and its z is 9 FMAs per channel away from the image: so neither tensor needs to
+// exist.  Two passes over g = dL/da (each: 268 MB at batch 64 instead of read g + z, write dz, read dz = 1.07 GB):
+//   PASS 1: z recomputed (c1_z), gl = g LeakyReLU'(y), per-(image, channel) sums of gl and gl zhat -> sums [N][CO][2] (+=);
+//   PASS 2: dz = gamma rstd (gl - S1/HW - zhat S2/HW) (bwd_apply_kernel's expression, norm.hip) formed in registers and
+//           accumulated into dw[t][c] += x[p + t] dz[p][c]; dgamma / dbeta += the image's sums.
+// Geometry of conv_c1_wgrad_rows_kernel: a workgroup owns R image rows (staged in LDS with a zero border), thread =
+// (piece of channels, pixel row slot), four g pieces in flight.
+template <typename T, int PASS>
+__global__ __launch_bounds__(256, 2) void c1_bwd_kernel(const float* __restrict__ img, const T* __restrict__ g,
+                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     float slope, float* __restrict__ sums, float* __restrict__ dw,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int H, int W,
+                                                     int CO, int R) {
+    constexpr int PIECE = Elem<T>::PIECE;
+    constexpr int NV = PASS == 1 ? 2 : 9;          // accumulator rows per thread
+    extern __shared__ float lds[];                 // (R + 2) x (W + 2) image rows, afterwards the reduction scratch
+    const int ppp = CO / PIECE, rows = 256 / ppp;
+    const int piece = threadIdx.x % ppp, prow = threadIdx.x / ppp;
+    const int n = blockIdx.y, y0 = blockIdx.x * R;
+    const int WP = W + 2;
+    const int Rv = min(R, H - y0);
+    for (int i = threadIdx.x; i < (R + 2) * WP; i += 256) {
+        const int ry = i / WP, rx = i - ry * WP;
+        const int sy = y0 + ry - 1, sx = rx - 1;
+        lds[i] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? img[((size_t)n * H + sy) * W + sx] : 0.f;
+    }
+    // PASS 1 accumulates sum gl and sum gl z (zhat = (z - mean) rstd is linear in z: fixed up once at the end);
+    // PASS 2 uses dz = gr gl + B z + C with B = -gr a2 rstd, C = -gr a1 + gr a2 rstd mean (bwd_apply_kernel's expression, expanded)
+    float wr[9][PIECE], b[PIECE], sc[PIECE], sh[PIECE], gr[PIECE], cB[PIECE], cC[PIECE];
+    const size_t NC = (size_t)N * CO, sidx = (size_t)n * CO + piece * PIECE;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) wr[t][e] = w[t * CO + piece * PIECE + e];
+    const float inv = 1.f / (float)(H * W);
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) {
+        b[e] = bias ? bias[piece * PIECE + e] : 0.f;
+        sc[e] = stats[2 * NC + sidx + e]; sh[e] = stats[3 * NC + sidx + e];
+        if constexpr (PASS == 2) {
+            const float mean = stats[sidx + e], rstd = stats[NC + sidx + e];
+            const float a1 = sums[(sidx + e) * 2] * inv, a2 = sums[(sidx + e) * 2 + 1] * inv;
+            gr[e] = (gamma ? gamma[piece * PIECE + e] : 1.f) * rstd;
+            cB[e] = -gr[e] * a2 * rstd;
+            cC[e] = -gr[e] * a1 - cB[e] * mean;
+        }
+    }
+    if constexpr (PASS == 2) {
+        if (blockIdx.x == 0 && prow == 0) {          // one contribution per (image, channel)
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) {
+                if (dbeta) unsafeAtomicAdd(dbeta + piece * PIECE + e, sums[(sidx + e) * 2]);
+                if (dgamma) unsafeAtomicAdd(dgamma + piece * PIECE + e, sums[(sidx + e) * 2 + 1]);
+            }
+        }
+    }
+    __syncthreads();
+    float acc[NV][PIECE];
+#pragma unroll
+    for (int t = 0; t < NV; ++t)
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) acc[t][e] = 0.f;
+    const int npx = Rv * W;
+    const T* gb = g + ((size_t)n * H + y0) * W * CO + piece * PIECE;
+    auto add = [&](int q, const float (&gv)[PIECE]) {
+        const int y = q / W, x = q - y * W;
+        const float* s = lds + y * WP + x;         // top-left of the 3x3 window in padded coordinates
+        float v[9], z[PIECE];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] = s[(t / 3) * WP + t % 3];
+        c1_z<T, PIECE>(v, wr, b, z);
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+            const float zr = c1_stored<T>(z[e]);
+            const float yv = fmaf(zr, sc[e], sh[e]);
+            const float gl = yv > 0.f ? gv[e] : gv[e] * slope;
+            if constexpr (PASS == 1) {
+                acc[0][e] += gl;
+                acc[1][e] = fmaf(gl, zr, acc[1][e]);
+            } else {
+                const float dz = fmaf(zr, cB[e], fmaf(gr[e], gl, cC[e]));
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t][e] = fmaf(v[t], dz, acc[t][e]);
+            }
+        }
+    };
+    constexpr int UF = PASS == 1 ? 4 : 2;          // g pieces in flight per thread (PASS 2 holds 2 x 72 registers of w and dw)
+    int p = prow;
+    for (; p + (UF - 1) * rows < npx; p += UF * rows) {
+        float gv[UF][PIECE];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) load_piece<T>(gb + (size_t)(p + u * rows) * CO, gv[u]);
+#pragma unroll
+        for (int u = 0; u < UF; ++u) add(p + u * rows, gv[u]);
+    }
+    for (; p < npx; p += rows) {
+        float gv[PIECE];
+        load_piece<T>(gb + (size_t)p * CO, gv);
+        add(p, gv);
+    }
+    // lane = (prow % (64 / ppp)) * ppp + piece: lanes 16 and 32 apart hold the same piece of other pixel rows
+#pragma unroll
+    for (int t = 0; t < NV; ++t)
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+            acc[t][e] += __shfl_xor(acc[t][e], 32);
+            acc[t][e] += __shfl_xor(acc[t][e], 16);
+        }
+    __syncthreads();                               // every wave is done with the image rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rpw = 16 / ppp;                      // partial rows per wave that are left
+    if (lane < 16) {
+        float* d = lds + ((size_t)(wave * rpw + lane / ppp) * ppp + piece) * NV * PIECE;
+#pragma unroll
+        for (int t = 0; t < NV; ++t)
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) d[t * PIECE + e] = acc[t][e];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < NV * CO; o += 256) {
+        const int t = o / CO, c = o - t * CO;
+        const int pc = c / PIECE, e = c - pc * PIECE;
+        float sum = 0.f;
+        for (int rr = 0; rr < 4 * rpw; ++rr) sum += lds[((size_t)rr * ppp + pc) * NV * PIECE + t * PIECE + e];
+        if constexpr (PASS == 1) {
+            // row 0: sum gl; row 1: sum gl z -> sum gl zhat = rstd (sum gl z - mean sum gl), per workgroup (linear)
+            if (t == 1) {
+                float s0 = 0.f;
+                for (int rr = 0; rr < 4 * rpw; ++rr) s0 += lds[((size_t)rr * ppp + pc) * NV * PIECE + e];
+                sum = stats[NC + (size_t)n * CO + c] * (sum - stats[(size_t)n * CO + c] * s0);
+            }
+            unsafeAtomicAdd(sums + ((size_t)n * CO + c) * 2 + t, sum);
+        } else {
+            unsafeAtomicAdd(dw + o, sum);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------- operand copies
@@ -751,7 +900,7 @@ extern "C" int cu_conv_c1_fwd_norm(int dtype, int N, int H, int W, int CO, const
                                    float* ws, float* stats, void* z, void* a, void* stream) {
     CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_conv_c1_fwd_norm: bad dtype");
     const int PIECE = dtype == CU_BF16 ? 8 : 4;
-    CU_CHECK_ARG(N > 0 && N < 65536 && H > 0 && W > 0 && CO > 0 && CO % PIECE == 0 && img && w && ws && stats && z && a,
+    CU_CHECK_ARG(N > 0 && N < 65536 && H > 0 && W > 0 && CO > 0 && CO % PIECE == 0 && img && w && ws && stats && a,
                  "cu_conv_c1_fwd_norm: bad argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const unsigned nwg = (unsigned)(((size_t)H * ((W + C1M_PX - 1) / C1M_PX) + 255) / 256);
@@ -762,12 +911,51 @@ extern "C" int cu_conv_c1_fwd_norm(int dtype, int N, int H, int W, int CO, const
     CU_LAUNCH_CHECK();
     const size_t total = (size_t)N * H * ((W + C1_PX - 1) / C1_PX) * (CO / PIECE);
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (dtype == CU_BF16)
+    if (!z) {          // activation only: cu_conv_c1_bwd recomputes z
+        if (dtype == CU_BF16)
+            hipLaunchKernelGGL((conv_c1_fwd_kernel<bf16_t, 3>), dim3(blocks), dim3(256), 0, st, img, w, bias, (bf16_t*)nullptr, N, H,
+                               W, CO, (const float*)stats, slope, (bf16_t*)a);
+        else
+            hipLaunchKernelGGL((conv_c1_fwd_kernel<float, 3>), dim3(blocks), dim3(256), 0, st, img, w, bias, (float*)nullptr, N, H, W,
+                               CO, (const float*)stats, slope, (float*)a);
+    } else if (dtype == CU_BF16)
         hipLaunchKernelGGL((conv_c1_fwd_kernel<bf16_t, 2>), dim3(blocks), dim3(256), 0, st, img, w, bias, (bf16_t*)z, N, H, W,
                            CO, (const float*)stats, slope, (bf16_t*)a);
     else
         hipLaunchKernelGGL((conv_c1_fwd_kernel<float, 2>), dim3(blocks), dim3(256), 0, st, img, w, bias, (float*)z, N, H, W, CO,
                            (const float*)stats, slope, (float*)a);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_conv_c1_bwd(int dtype, int N, int H, int W, int CO, const float* img, const float* w, const float* bias,
+                              const float* stats, const float* gamma, float slope, const void* g, float* sums, float* dw,
+                              float* dgamma, float* dbeta, void* stream) {
+    CU_CHECK_ARG(dtype == CU_F32 || dtype == CU_BF16, "cu_conv_c1_bwd: bad dtype");
+    const int PIECE = dtype == CU_BF16 ? 8 : 4;
+    CU_CHECK_ARG(N > 0 && N < 65536 && H > 0 && W > 0 && CO > 0 && CO % PIECE == 0 && img && w && stats && g && sums && dw,
+                 "cu_conv_c1_bwd: bad argument");
+    const int ppp = CO / PIECE;
+    CU_CHECK_ARG((ppp & (ppp - 1)) == 0 && ppp <= 16, "cu_conv_c1_bwd: CO / piece must be a power of two <= 16 (CO=%d)", CO);
+    const int want = cdiv(1024, N);
+    int R = cdiv(H, want < H ? want : H);
+    while (R > 1 && (size_t)(R + 2) * (W + 2) * 4 > 48 * 1024) --R;
+    const size_t img_b = sizeof(float) * (size_t)(R + 2) * (W + 2), red_b = sizeof(float) * (size_t)64 * 9 * PIECE;
+    const size_t lds = img_b > red_b ? img_b : red_b;
+    CU_CHECK_ARG(lds <= 64 * 1024, "cu_conv_c1_bwd: image rows of %d pixels do not fit the LDS", W);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(cdiv(H, R), N);
+    if (dtype == CU_BF16) {
+        hipLaunchKernelGGL((c1_bwd_kernel<bf16_t, 1>), grid, dim3(256), lds, st, img, (const bf16_t*)g, w, bias, stats, gamma, slope,
+                           sums, dw, dgamma, dbeta, N, H, W, CO, R);
+        hipLaunchKernelGGL((c1_bwd_kernel<bf16_t, 2>), grid, dim3(256), lds, st, img, (const bf16_t*)g, w, bias, stats, gamma, slope,
+                           sums, dw, dgamma, dbeta, N, H, W, CO, R);
+    } else {
+        hipLaunchKernelGGL((c1_bwd_kernel<float, 1>), grid, dim3(256), lds, st, img, (const float*)g, w, bias, stats, gamma, slope,
+                           sums, dw, dgamma, dbeta, N, H, W, CO, R);
+        hipLaunchKernelGGL((c1_bwd_kernel<float, 2>), grid, dim3(256), lds, st, img, (const float*)g, w, bias, stats, gamma, slope,
+                           sums, dw, dgamma, dbeta, N, H, W, CO, R);
+    }
     CU_LAUNCH_CHECK();
     return 0;
 }

@@ -60,6 +60,7 @@ class _ConvRec:
     out: Act
     stride: int
     first: bool = False          # Cin == 1 direct conv
+    no_z: bool = False           # first layer without a stored z (out.z aliases the activation): backward = ops.conv_c1_bwd
     drop_mask: Optional[Tensor] = None   # Dropout2d multipliers (N, C) applied between conv and norm
 
 
@@ -133,6 +134,9 @@ class UNetEngine:
         # True: the first layer (Cin = 1) derives its InstanceNorm statistics from moments of the image and writes z and a in one pass
         # (cu_conv_c1_fwd_norm) instead of conv -> statistics pass over z -> apply pass
         self.first_fused = os.environ.get("CONTOUR_FIRST_FUSED", "1") == "1"
+        # True (with first_fused): the first layer never stores z; its whole backward (norm backward + the 9 x CO weight
+        # gradient) is two passes over dL/da that recompute z from the image (cu_conv_c1_bwd) -- no z, no dz
+        self.first_no_z = os.environ.get("CONTOUR_FIRST_NO_Z", "1") == "1"
         # True: on maps of <= 64 pixels (8x8 and below) the split-K finish pass of the convolution / input-gradient launch
         # carries the layer's InstanceNorm + LeakyReLU forward / backward (no separate, latency-bound norm launch)
         self.small_norm = os.environ.get("CONTOUR_SMALL_NORM", "1") == "1"
@@ -311,8 +315,15 @@ class UNetEngine:
         n, _, h, w_ = img.shape
         if self.first_fused and self.fused_norm and self.materialize and self.debug is None:
             # statistics from moments of the image, then z and a in one pass (no pass over z between conv and apply)
+            no_z = self.first_no_z and ctx.keep and not self.deterministic and not self.lazy_act and co % 32 == 0
             out = ops.conv_c1_fwd_norm(img, w9, P[f"{prefix}.conv.bias"], P[f"{prefix}.norm.weight"],
-                                       P[f"{prefix}.norm.bias"], self.slope, self.eps, self.dtype)
+                                       P[f"{prefix}.norm.bias"], self.slope, self.eps, self.dtype, keep_z=not no_z)
+            if no_z:
+                if not ctx.keep:
+                    return Act(out.a, None, 1.0)
+                ctx.convs[prefix] = _ConvRec(prefix, [], out, 1, first=True, no_z=True)
+                self._producer[id(out)] = prefix
+                return out
         else:
             z = torch.empty((n, h, w_, co), dtype=self.dtype, device=img.device)
             ops.conv_c1_fwd(img, w9, P[f"{prefix}.conv.bias"], z)
@@ -505,6 +516,17 @@ class UNetEngine:
             self.debug[f"{prefix}:da"] = g.float().clone()
         # d(conv bias) = sum_p dz is identically zero behind an InstanceNorm (dz has zero mean per (n, c)); the reference
         # accumulates rounding noise there.  G[conv.bias] stays exactly 0 (no kernel work, no atomics contention).
+        if rec.no_z:
+            # the first layer's whole backward from dL/da: z recomputed from the image, dz never stored (cu_conv_c1_bwd)
+            n, oh, ow, co = g.shape
+            with self._wgrad_stream(g, ctx.img):
+                sums = torch.zeros((n, co, 2), dtype=torch.float32, device=g.device)
+                dw9 = self._dwk((9, co), g.device)
+                ops.conv_c1_bwd(ctx.img, self._opcache[prefix][1], P[f"{prefix}.conv.bias"], rec.out.stats,
+                                P[f"{prefix}.norm.weight"], self.slope, g, sums, dw9, G[f"{prefix}.norm.weight"],
+                                G[f"{prefix}.norm.bias"])
+                self._unprep(dw9.view(9, co, 1), G[f"{prefix}.conv.weight"], "conv", prefix)
+            return
         given = self._given_sums.pop(prefix, None)
         if prefix in self._bwd_done:   # the launch that produced g did this layer's whole norm backward: g IS dL/dz
             self._bwd_done.discard(prefix)
@@ -556,7 +578,8 @@ class UNetEngine:
             src = rec.srcs[0] if len(rec.srcs) == 1 else None
             tgt = self._producer.get(id(src)) if src is not None else None
             if (tgt is not None and self.fused_norm_bwd and not self.deterministic and self.fused_norm and self.dtype == torch.bfloat16 and not acc[0]
-                    and n * sh * sw >= (1 << 20) and ctx.convs[tgt].drop_mask is None and ctx.convs[tgt].out.stats is not None):
+                    and n * sh * sw >= (1 << 20) and ctx.convs[tgt].drop_mask is None and ctx.convs[tgt].out.stats is not None
+                    and not ctx.convs[tgt].no_z):
                 nb = (ctx.convs[tgt].out, self._arena["bwd"].take(2 * n * cols[0], g.device))
             full = self._small_norm_bwd(P, G, ctx, src, n, sh * sw, cols[0]) if nb is None and len(dsts) == 1 else None
             got = ops.conv_gemm([gz], wd, None, grid=(sh, sw), in_stride=1, taps=TAPS3_D, dsts=dsts, dst_cols=cols,

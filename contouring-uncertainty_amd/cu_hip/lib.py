@@ -62,6 +62,7 @@ _SIGS = {
     "cu_conv_c1_fwd": (C.c_int, [C.c_int] * 5 + [_P] * 5),
     "cu_conv_c1_norm_ws_floats": (C.c_size_t, [C.c_int] * 3),
     "cu_conv_c1_fwd_norm": (C.c_int, [C.c_int] * 5 + [_P] * 5 + [C.c_float] * 2 + [_P] * 5),
+    "cu_conv_c1_bwd": (C.c_int, [C.c_int] * 5 + [_P] * 5 + [C.c_float] + [_P] * 6),
     "cu_conv_c1_wgrad": (C.c_int, [C.c_int] * 5 + [_P] * 4),
     "cu_conv_c1_wgrad_det": (C.c_int, [C.c_int] * 5 + [_P] * 4 + [C.c_size_t, _P]),
     "cu_instnorm_stats": (C.c_int, [C.c_int] * 4 + [_P] * 3 + [C.c_float] + [_P] * 3),

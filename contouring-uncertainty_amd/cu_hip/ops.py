@@ -233,20 +233,31 @@ def conv_c1_fwd(img: Tensor, w9: Tensor, bias: Optional[Tensor], dst: Tensor):
 
 
 def conv_c1_fwd_norm(img: Tensor, w9: Tensor, bias: Optional[Tensor], gamma: Optional[Tensor], beta: Optional[Tensor],
-                     slope: float, eps: float, dtype) -> Act:
+                     slope: float, eps: float, dtype, keep_z: bool = True) -> Act:
     """first layer conv -> InstanceNorm -> LeakyReLU with the statistics derived from moments of the image and z, a written
-    by one pass (cu_conv_c1_fwd_norm) -> Act(z, stats, a)."""
+    by one pass (cu_conv_c1_fwd_norm) -> Act(z, stats, a).  ``keep_z=False``: only the activation is written and ``Act.z``
+    IS the activation tensor (shape / dtype holder): the layer's backward must be :func:`conv_c1_bwd`, which recomputes z."""
     n, _, h, w_ = img.shape
     co = w9.shape[1]
-    z = torch.empty((n, h, w_, co), dtype=dtype, device=img.device)
-    a = torch.empty_like(z)
+    a = torch.empty((n, h, w_, co), dtype=dtype, device=img.device)
+    z = torch.empty_like(a) if keep_z else None
     stats = torch.empty((4, n, co), dtype=torch.float32, device=img.device)
     sums = torch.empty((L.load().cu_conv_c1_norm_ws_floats(n, h, w_),), dtype=torch.float32, device=img.device)
-    with _Prof("conv_c1", 0.0, f"N{n} {h}x{w_} C{co} +norm", 2 * z.numel() * z.element_size()):
+    with _Prof("conv_c1", 0.0, f"N{n} {h}x{w_} C{co} +norm", (2 if keep_z else 1) * a.numel() * a.element_size()):
         L.check(L.load().cu_conv_c1_fwd_norm(L.dtype_code(dtype), n, h, w_, co, L.ptr(img), L.ptr(w9), L.ptr(bias),
                                              L.ptr(gamma), L.ptr(beta), eps, slope, L.ptr(sums), L.ptr(stats), L.ptr(z),
                                              L.ptr(a), L.stream_ptr()), "cu_conv_c1_fwd_norm")
-    return Act(z, stats, slope, a, None)
+    return Act(z if keep_z else a, stats, slope, a, None)
+
+
+def conv_c1_bwd(img: Tensor, w9: Tensor, bias: Optional[Tensor], stats: Tensor, gamma: Optional[Tensor], slope: float,
+                g: Tensor, sums: Tensor, dw9: Tensor, dgamma: Optional[Tensor], dbeta: Optional[Tensor]):
+    """the first layer's whole backward from g = dL/da (cu_conv_c1_bwd): ``sums`` (N, CO, 2) zeroed scratch, ``dw9`` (9, CO) +=."""
+    n, h, w_, co = g.shape
+    with _Prof("conv_c1", 0.0, f"N{n} {h}x{w_} C{co} bwd", 2 * g.numel() * g.element_size()):
+        L.check(L.load().cu_conv_c1_bwd(L.dtype_code(g.dtype), n, h, w_, co, L.ptr(img), L.ptr(w9), L.ptr(bias), L.ptr(stats),
+                                        L.ptr(gamma), slope, L.ptr(g), L.ptr(sums), L.ptr(dw9), L.ptr(dgamma), L.ptr(dbeta),
+                                        L.stream_ptr()), "cu_conv_c1_bwd")
 
 
 def conv_c1_wgrad(img: Tensor, dz: Tensor, dw9: Tensor, det_ws: Optional[Tensor] = None):

@@ -176,6 +176,16 @@ size_t cu_conv_c1_norm_ws_floats(int N, int H, int W);
 int cu_conv_c1_fwd_norm(int dtype, int N, int H, int W, int CO, const float* img, const float* w, const float* bias,
                         const float* gamma, const float* beta, float eps, float slope, float* ws, float* stats,
                         void* z, void* a, void* stream);
+/* z == NULL: only the activation is written (the backward below recomputes z from the image, 9 FMAs per channel, with
+ * the very same expressions -- so both sides decide every LeakyReLU branch on the same value). */
+/* The first layer's WHOLE backward from g = dL/da (NHWC, read only) without z and without dz: the layer has no input
+ * gradient, so its dz feeds nothing but its own 9 x CO weight gradient.  Pass 1: sums [N][CO][2] += (sum gl, sum gl zhat)
+ * with gl = g LeakyReLU'(z scale + shift) (sums must arrive zeroed); pass 2: dz = gamma rstd (gl - S1/HW - zhat S2/HW)
+ * (layers.py:192-205 backward) formed in registers, dw [9][CO] += sum_p x[p + t] dz[p], dgamma / dbeta [CO] += (may be NULL).
+ * stats: the four planes of cu_conv_c1_fwd_norm.  2 x (g + image) of HBM reads instead of read g, z + write dz + read dz. */
+int cu_conv_c1_bwd(int dtype, int N, int H, int W, int CO, const float* img, const float* w, const float* bias,
+                   const float* stats, const float* gamma, float slope, const void* g, float* sums, float* dw,
+                   float* dgamma, float* dbeta, void* stream);
 int cu_conv_c1_wgrad(int dtype, int N, int H, int W, int CO, const float* img, const void* dz /* NHWC */,
                      float* dw /* [9][CO] f32, += */, void* stream);
 /* The same with the workgroups' partial sums stored in ws (>= (rows chunks x N) x 9 x CO floats; 2^20 covers every shape

@@ -7,8 +7,10 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 STEPS = 20
-BAND = 0.5        # nats: |NLL_bf16 - NLL_f32| from step 5 to step 20 (measured 0.10 ... 0.29; start 6.87, f32 end 5.80 ... 5.90;
-                  # f32 against f32: 0.01 ... 0.03)
+BAND = 0.75       # nats: |NLL_bf16 - NLL_f32| from step 5 to step 20.  Start 6.87; f32 ends at 5.82 ... 5.90 (f32 against f32:
+                  # 0.01 ... 0.05); bf16 ends at 5.37 ... 5.93 over 16 runs (four per build variant, round 3: the spread is
+                  # the same with and without the fused head / the z-free first layer) -- run-to-run noise of the default
+                  # mode's f32 atomics amplified by 20 Adam steps, on the LOW side of f32 more often than not
 
 
 def _run(dtype):

@@ -265,6 +265,52 @@ def test_first_conv_with_norm(dtype, geom):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", [(3, 64, 64, 32), (4, 256, 256, 32), (2, 32, 128, 32), (2, 19, 45, 32), (1, 3, 5, 64)])
+def test_first_layer_backward_without_z(dtype, geom):
+    """cu_conv_c1_bwd (z recomputed from the image, dz never stored; two passes over dL/da) against autograd through
+    conv -> instance_norm -> leaky_relu on the same image, and against the chain it replaces (norm backward in place, then
+    cu_conv_c1_wgrad); the activation of the a-only forward is bit-identical to the z-keeping one."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(24)
+    n, hh, ww, co = geom
+    img = torch.rand(n, 1, hh, ww, device=DEV, generator=g) + 0.5
+    w = torch.randn(co, 1, 3, 3, device=DEV, generator=g)
+    b = torch.randn(co, device=DEV, generator=g)
+    gamma = torch.rand(co, device=DEV, generator=g) + 0.5
+    beta = torch.randn(co, device=DEV, generator=g) * 0.5
+    w9, _ = ops.weight_prep(w, "conv", torch.float32, want_dgrad=False)
+    full = ops.conv_c1_fwd_norm(img, w9, b, gamma, beta, 0.01, 1e-5, dtype)
+    lean = ops.conv_c1_fwd_norm(img, w9, b, gamma, beta, 0.01, 1e-5, dtype, keep_z=False)
+    assert torch.equal(full.a, lean.a) and torch.equal(full.stats, lean.stats) and lean.z is lean.a
+    ga = rq(torch.randn(n, co, hh, ww, device=DEV, generator=g), dtype)
+    g_nhwc = nhwc(ga, dtype)
+    # ---- the chain it replaces
+    dz = g_nhwc.clone()
+    dgam0, dbet0 = torch.zeros(co, device=DEV), torch.zeros(co, device=DEV)
+    ops.instnorm_bwd_fused(dz, full, gamma, dgam0, dbet0)
+    dw0 = torch.zeros(9, co, device=DEV)
+    ops.conv_c1_wgrad(img, dz, dw0)
+    # ---- fused
+    sums = torch.zeros(n, co, 2, device=DEV)
+    dw1 = torch.zeros(9, co, device=DEV)
+    dgam1, dbet1 = torch.zeros(co, device=DEV), torch.zeros(co, device=DEV)
+    ops.conv_c1_bwd(img, w9, b, lean.stats, gamma, 0.01, g_nhwc, sums, dw1, dgam1, dbet1)
+    torch.cuda.synchronize()
+    loose = dtype == torch.bfloat16           # the chain rounds dz to bf16 before the weight gradient, the fused form does not
+    assert rel_err(dw1, dw0) < (2e-2 if loose else 2e-4)
+    assert rel_err(dgam1, dgam0) < 2e-4 and rel_err(dbet1, dbet0) < 2e-4
+    # ---- autograd on the stored (rounded) z's statistics is not what the kernels use (moments of the unrounded conv):
+    #      f32 only, where the two coincide
+    if dtype == torch.float32 and hh * ww >= 1024:
+        wr, gr_, br = w.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        out = F.leaky_relu(F.instance_norm(F.conv2d(img, wr, b, padding=1), weight=gr_, bias=br, eps=1e-5), 0.01)
+        out.backward(ga)
+        gw = torch.zeros_like(w)
+        ops.grad_unprep(dw1.view(9, co, 1), gw, "conv", accumulate=True)
+        assert rel_err(gw, wr.grad) < 1e-3 and rel_err(dgam1, gr_.grad) < 1e-3 and rel_err(dbet1, br.grad) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 32, 64), (3, 480, 4), (2, 128, 16), (64, 480, 2)])
 def test_instnorm_fwd_bwd(dtype, shape):
     """statistics + fused backward vs F.instance_norm -> leaky_relu autograd."""

@@ -18,12 +18,19 @@ constexpr int C1_PX = 8;
 //         c1_z(), the SAME expressions, so that both sides decide the LeakyReLU branch on the same value.
 template <typename T, int PIECE>
 __device__ __forceinline__ void c1_z(const float (&v)[9], const float (&wr)[9][PIECE], const float (&b)[PIECE], float (&z)[PIECE]) {
+    // channel pairs as 2-vectors: v_pk_fma_f32 (two IEEE fmas per lane and instruction; the same values as fmaf per channel)
+    f32x2 zz[PIECE / 2];
 #pragma unroll
-    for (int e = 0; e < PIECE; ++e) z[e] = b[e];
+    for (int e = 0; e < PIECE / 2; ++e) zz[e] = f32x2{b[2 * e], b[2 * e + 1]};
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t) {
+        const f32x2 vv = {v[t], v[t]};
 #pragma unroll
-        for (int e = 0; e < PIECE; ++e) z[e] = fmaf(v[t], wr[t][e], z[e]);
+        for (int e = 0; e < PIECE / 2; ++e)
+            zz[e] = __builtin_elementwise_fma(vv, f32x2{wr[t][2 * e], wr[t][2 * e + 1]}, zz[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < PIECE / 2; ++e) { z[2 * e] = zz[e][0]; z[2 * e + 1] = zz[e][1]; }
 }
 // the value the layer's consumers see: z as stored (rounded to the storage type)
 template <typename T> __device__ __forceinline__ float c1_stored(float z) {
@@ -409,18 +416,29 @@ __global__ __launch_bounds__(256, 2) void c1_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int t = 0; t < 9; ++t) v[t] = s[(t / 3) * WP + t % 3];
         c1_z<T, PIECE>(v, wr, b, z);
+        float dzv[PIECE];
 #pragma unroll
         for (int e = 0; e < PIECE; ++e) {
             const float zr = c1_stored<T>(z[e]);
             const float yv = fmaf(zr, sc[e], sh[e]);
             const float gl = yv > 0.f ? gv[e] : gv[e] * slope;
+            dzv[e] = 0.f;
             if constexpr (PASS == 1) {
                 acc[0][e] += gl;
                 acc[1][e] = fmaf(gl, zr, acc[1][e]);
             } else {
-                const float dz = fmaf(zr, cB[e], fmaf(gr[e], gl, cC[e]));
+                dzv[e] = fmaf(zr, cB[e], fmaf(gr[e], gl, cC[e]));
+            }
+        }
+        if constexpr (PASS == 2) {
 #pragma unroll
-                for (int t = 0; t < 9; ++t) acc[t][e] = fmaf(v[t], dz, acc[t][e]);
+            for (int t = 0; t < 9; ++t) {
+                const f32x2 vv = {v[t], v[t]};
+#pragma unroll
+                for (int e = 0; e < PIECE / 2; ++e) {
+                    const f32x2 r = __builtin_elementwise_fma(vv, f32x2{dzv[2 * e], dzv[2 * e + 1]}, f32x2{acc[t][2 * e], acc[t][2 * e + 1]});
+                    acc[t][2 * e] = r[0]; acc[t][2 * e + 1] = r[1];
+                }
             }
         }
     };

@@ -30,4 +30,4 @@ import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for i in range(3): step(i)
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)

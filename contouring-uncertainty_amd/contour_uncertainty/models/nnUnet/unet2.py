@@ -251,8 +251,21 @@ class UNet(nn.Module):
         self.engine.dtype = _dtype_of(dtype)
         self.engine._opcache.clear()
 
+    def _apply(self, fn, recurse=True):
+        self._plists = None          # .to() / .float() / ... may re-home parameters: walk the module tree again
+        return super()._apply(fn, recurse)
+
+    def _params(self):
+        """(all parameters in ``_pnames`` order, the used ones) -- cached: walking the module tree costs ~1 ms per call"""
+        pl = getattr(self, "_plists", None)
+        if pl is None:
+            named = dict(self.named_parameters())
+            used = set(self._used_names)
+            pl = self._plists = ([named[n] for n in self._pnames], [named[n] for n in self._pnames if n in used])
+        return pl
+
     def _ensure_flat(self):
-        plist = [p for n, p in self.named_parameters() if n in set(self._used_names)]
+        plist = self._params()[1]
         if self._flat is None or not _is_flat(plist) or self._flat.device != plist[0].device:
             self._flat = _flatten_params(self, self._used_names)
 
@@ -280,7 +293,7 @@ class UNet(nn.Module):
         if not input_data.is_cuda:
             raise _lib.ContourHipError("UNet.forward needs a device tensor: the HIP path has no CPU fallback")
         self._ensure_flat()
-        params = [p for _, p in self.named_parameters()]
+        params = self._params()[0]
         if params[0].device != input_data.device:
             raise _lib.ContourHipError(f"input on {input_data.device}, parameters on {params[0].device}")
         from cu_hip.head import GradSlot
@@ -346,8 +359,19 @@ class ConfidenceNet(nn.Module):
         self.engine.dtype = _dtype_of(dtype)
         self.engine._opcache.clear()
 
+    def _apply(self, fn, recurse=True):
+        self._plist = None
+        return super()._apply(fn, recurse)
+
+    def _params(self):
+        pl = getattr(self, "_plist", None)
+        if pl is None:
+            named = dict(self.named_parameters())
+            pl = self._plist = [named[n] for n in self._pnames]
+        return pl
+
     def _ensure_flat(self):
-        plist = [p for _, p in self.named_parameters()]
+        plist = self._params()
         if self._flat is None or not _is_flat(plist) or self._flat.device != plist[0].device:
             self._flat = _flatten_params(self, self._pnames)
 
@@ -361,6 +385,6 @@ class ConfidenceNet(nn.Module):
             raise ValueError(f"ConfidenceNet expects a (N, 480, 2, 2) bottleneck (reference unet2.py:22,29), got "
                              f"{tuple(x.shape)}")
         self._ensure_flat()
-        params = [p for _, p in self.named_parameters()]
+        params = self._params()
         with _lib.device_guard(x):
             return _ConfidenceFn.apply(self, x.float(), *params)

@@ -79,25 +79,13 @@ def _taps(desc, dys, dxs, ws, zys=None, zxs=None):
             desc.tap_zy[i], desc.tap_zx[i] = a, b
 
 
-def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: Tuple[int, int], in_stride: int,
-              taps: Sequence[Tuple[int, int, int]], dsts: Sequence[Tensor], dst_cols: Sequence[int],
-              out_stride: int = 1, out_off: Tuple[int, int] = (0, 0), accum: Sequence[int] = (0, 0),
-              out_nchw: bool = False, n_cols: Optional[int] = None, parity_cols: int = 0,
-              parity_taps: Optional[Sequence[int]] = None, stat_sums: Optional[Tensor] = None,
-              norm_bwd: Optional[Tuple[Act, Tensor]] = None, alg_cin: Optional[int] = None,
-              norm_fwd: Optional[tuple] = None, norm_bwd_full: Optional[tuple] = None) -> bool:
-    """D[p, n] = bias[n] + sum_t sum_c act(S[p*IS + off_t, c]) W[tap_w[t]][n][c]  (cu_conv_gemm).
-    ``parity_taps`` (16 ints, with ``parity_cols``): weight tap of (gather tap t, parity group g) at [t*4+g], -1 = none.
-    Tiny maps (<= 64 pixels per image; cu_conv_epilogue modes 3 / 4 -- the split-K finish pass carries the norm):
-    ``norm_fwd=(gamma, beta, eps, slope, stats, a)``: the layer's InstanceNorm + LeakyReLU forward (``stats`` (4, N, C) and
-    ``a`` are written); ``norm_bwd_full=(act, gamma, dgamma, dbeta)``: dsts[0] receives dL/dz of the layer ``act`` belongs to.
-    Returns True when the launch took the requested epilogue (otherwise dsts hold the plain result)."""
-    lib = L.load()
-    s0 = srcs[0]
-    s1 = srcs[1] if len(srcs) > 1 else None
+_CONV_DESC: Dict[tuple, tuple] = {}
+
+
+def _conv_desc(t0, t1, sl0, sl1, w, grid, in_stride, taps, dsts, dst_cols, out_stride, out_off, accum, out_nchw, n_cols,
+               parity_cols, parity_taps, alg_cin):
+    """(cu_conv_desc, algorithmic FLOPs, executed FLOPs, bytes, note) of one conv_gemm call signature"""
     d = L.ConvDesc()
-    t0, sc0, sh0, sl0 = s0.operand()
-    t1, sc1, sh1, sl1 = s1.operand() if s1 is not None else (None, None, None, 1.0)
     d.dtype = L.dtype_code(t0.dtype)
     d.N, d.SH, d.SW, d.C0 = t0.shape
     d.C1 = t1.shape[3] if t1 is not None else 0
@@ -140,6 +128,39 @@ def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: T
     nbytes = (d.N * d.SH * d.SW * (d.C0 + d.C1) * esz if d.IS == 1 else d.N * d.PH * d.PW * d.ntaps * (d.C0 + d.C1) * esz) \
         + d.N * d.PH * d.PW * d.CO * (4 if out_nchw else esz) * (2 if any(accum) else 1)
     note = f"N{d.N} {d.PH}x{d.PW} IS{d.IS} OS{d.OS} C{d.C0}+{d.C1}->{d.CO} t{d.ntaps}"
+    return d, flops, exec_flops, nbytes, note
+
+
+def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: Tuple[int, int], in_stride: int,
+              taps: Sequence[Tuple[int, int, int]], dsts: Sequence[Tensor], dst_cols: Sequence[int],
+              out_stride: int = 1, out_off: Tuple[int, int] = (0, 0), accum: Sequence[int] = (0, 0),
+              out_nchw: bool = False, n_cols: Optional[int] = None, parity_cols: int = 0,
+              parity_taps: Optional[Sequence[int]] = None, stat_sums: Optional[Tensor] = None,
+              norm_bwd: Optional[Tuple[Act, Tensor]] = None, alg_cin: Optional[int] = None,
+              norm_fwd: Optional[tuple] = None, norm_bwd_full: Optional[tuple] = None) -> bool:
+    """D[p, n] = bias[n] + sum_t sum_c act(S[p*IS + off_t, c]) W[tap_w[t]][n][c]  (cu_conv_gemm).
+    ``parity_taps`` (16 ints, with ``parity_cols``): weight tap of (gather tap t, parity group g) at [t*4+g], -1 = none.
+    Tiny maps (<= 64 pixels per image; cu_conv_epilogue modes 3 / 4 -- the split-K finish pass carries the norm):
+    ``norm_fwd=(gamma, beta, eps, slope, stats, a)``: the layer's InstanceNorm + LeakyReLU forward (``stats`` (4, N, C) and
+    ``a`` are written); ``norm_bwd_full=(act, gamma, dgamma, dbeta)``: dsts[0] receives dL/dz of the layer ``act`` belongs to.
+    Returns True when the launch took the requested epilogue (otherwise dsts hold the plain result)."""
+    lib = L.load()
+    s0 = srcs[0]
+    s1 = srcs[1] if len(srcs) > 1 else None
+    t0, sc0, sh0, sl0 = s0.operand()
+    t1, sc1, sh1, sl1 = s1.operand() if s1 is not None else (None, None, None, 1.0)
+    dst0 = dsts[0]
+    # the descriptor (and the FLOP / byte figures of the profile) depend on shapes and static arguments only: built once per
+    # distinct call signature (the host enqueues ~120 of these per step; filling a ctypes structure field by field was
+    # a third of the wrapper's time -- tools/cpu_bound.py)
+    key = (t0.dtype, tuple(t0.shape), t1.shape[3] if t1 is not None else 0, grid, in_stride, tuple(dst0.shape),
+           dsts[1].shape[3] if len(dsts) > 1 else 0, out_stride, tuple(out_off), tuple(accum), out_nchw, n_cols, tuple(dst_cols),
+           parity_cols, tuple(parity_taps) if parity_taps is not None else None, tuple(taps), sl0, sl1, alg_cin, tuple(w.shape))
+    hit = _CONV_DESC.get(key)
+    if hit is None:
+        hit = _CONV_DESC[key] = _conv_desc(t0, t1, sl0, sl1, w, grid, in_stride, taps, dsts, dst_cols, out_stride, out_off, accum,
+                                           out_nchw, n_cols, parity_cols, parity_taps, alg_cin)
+    d, flops, exec_flops, nbytes, note = hit
     ws = _split_k_ws(t0.device)
     import ctypes as _C
     done = _C.c_int(0)
@@ -181,18 +202,12 @@ def _split_k_ws(device) -> Tensor:
     return ws
 
 
-def conv_wgrad(srcs: Sequence[Act], z: Tensor, dwk: Tensor, *, grid: Tuple[int, int], in_stride: int, z_stride: int,
-               taps: Sequence[Tuple[int, int, int, int, int]], n_cols: int, splits: int = 0, parts: bool = False,
-               alg_cols: Optional[int] = None) -> int:
-    """dWk[tap_w][n][c] += sum_p Z[p*ZS + zoff, n] * act(S[p*IS + off, c])  (cu_conv_wgrad); taps = (dy,dx,zy,zx,w).
-    ``parts=True`` (cu_conv_wgrad_parts): ``dwk`` is a flat f32 scratch; every adder stores its partial tile into a slab
-    of its own (no atomics); returns (number of slabs, their layout code) for :func:`grad_unprep_parts`."""
-    lib = L.load()
-    s0 = srcs[0]
-    s1 = srcs[1] if len(srcs) > 1 else None
+_WGRAD_DESC: Dict[tuple, tuple] = {}
+
+
+def _wgrad_desc(t0, t1, sl0, sl1, z, grid, in_stride, z_stride, taps, n_cols, splits, alg_cols):
+    """(cu_wgrad_desc, algorithmic FLOPs, executed FLOPs, bytes, note) of one conv_wgrad call signature"""
     d = L.WgradDesc()
-    t0, sc0, sh0, sl0 = s0.operand()
-    t1, sc1, sh1, sl1 = s1.operand() if s1 is not None else (None, None, None, 1.0)
     d.dtype = L.dtype_code(t0.dtype)
     d.N, d.SH, d.SW, d.C0 = t0.shape
     d.C1 = t1.shape[3] if t1 is not None else 0
@@ -206,12 +221,32 @@ def conv_wgrad(srcs: Sequence[Act], z: Tensor, dwk: Tensor, *, grid: Tuple[int, 
     d.slope0 = sl0
     d.slope1 = sl1
     d.splits = splits
-    assert dwk.dtype == torch.float32 and z.dtype == t0.dtype
     exec_flops = 2.0 * d.N * d.PH * d.PW * d.ntaps * (d.C0 + d.C1) * d.CO
     flops = exec_flops if alg_cols is None else exec_flops * alg_cols / d.CO      # padded head: K true classes of 32
     esz = t0.element_size()
     nbytes = d.N * d.SH * d.SW * (d.C0 + d.C1) * esz + d.N * d.ZH * d.ZW * d.ZC * esz
     note = f"N{d.N} {d.PH}x{d.PW} IS{d.IS} ZS{d.ZS} C{d.C0}+{d.C1}->{d.CO} t{d.ntaps}"
+    return d, flops, exec_flops, nbytes, note
+
+
+def conv_wgrad(srcs: Sequence[Act], z: Tensor, dwk: Tensor, *, grid: Tuple[int, int], in_stride: int, z_stride: int,
+               taps: Sequence[Tuple[int, int, int, int, int]], n_cols: int, splits: int = 0, parts: bool = False,
+               alg_cols: Optional[int] = None) -> int:
+    """dWk[tap_w][n][c] += sum_p Z[p*ZS + zoff, n] * act(S[p*IS + off, c])  (cu_conv_wgrad); taps = (dy,dx,zy,zx,w).
+    ``parts=True`` (cu_conv_wgrad_parts): ``dwk`` is a flat f32 scratch; every adder stores its partial tile into a slab
+    of its own (no atomics); returns (number of slabs, their layout code) for :func:`grad_unprep_parts`."""
+    lib = L.load()
+    s0 = srcs[0]
+    s1 = srcs[1] if len(srcs) > 1 else None
+    t0, sc0, sh0, sl0 = s0.operand()
+    t1, sc1, sh1, sl1 = s1.operand() if s1 is not None else (None, None, None, 1.0)
+    key = (t0.dtype, tuple(t0.shape), t1.shape[3] if t1 is not None else 0, grid, in_stride, tuple(z.shape), z_stride, n_cols,
+           tuple(taps), sl0, sl1, splits, alg_cols)
+    hit = _WGRAD_DESC.get(key)
+    if hit is None:
+        hit = _WGRAD_DESC[key] = _wgrad_desc(t0, t1, sl0, sl1, z, grid, in_stride, z_stride, taps, n_cols, splits, alg_cols)
+    d, flops, exec_flops, nbytes, note = hit
+    assert dwk.dtype == torch.float32 and z.dtype == t0.dtype
     import ctypes as _C
     nparts, layout = _C.c_int(0), _C.c_int(0)
     with _Prof("igemm_wgrad", flops, note, nbytes, exec_flops):

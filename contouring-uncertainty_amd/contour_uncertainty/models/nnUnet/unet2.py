@@ -9,12 +9,14 @@ runs the kernel schedule of :mod:`cu_hip.engine` through one autograd node (hand
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Sequence, Tuple
 
 import torch
 from torch import Tensor, nn
 
 from cu_hip import lib as _lib
+from cu_hip import ops as _ops
 from cu_hip.engine import ConfidenceEngine, UNetEngine
 
 
@@ -100,6 +102,8 @@ class _UNetFn(torch.autograd.Function):
                                                     keep=need, fused_head=need and slot.fused)
         ctx.module, ctx.ectx, ctx.slot = module, (ectx if need else None), slot
         ctx.save_for_backward(*params)
+        if slot is not None:
+            slot.feats_event = ectx.feats_event
         if logits is None:
             # fused head (cu_hip.head runs cu_head_fused_fwd on ectx.head): the logits do not exist; their stand-in in
             # autograd is a stride-0 zero tensor of their shape that only cu_hip.head.dsnt_nll knows how to read
@@ -304,14 +308,32 @@ class UNet(nn.Module):
             out = _UNetFn.apply(self, slot, input_data.float(), *params)
         if slot is not None:
             (out[0] if isinstance(out, tuple) else out)._cu_grad_slot = slot
+            if isinstance(out, tuple) and slot.feats_event is not None:
+                out[1]._cu_ready_event = slot.feats_event       # ConfidenceNet(side=True) waits for this, not for the decoder
         return out
 
 
 class _ConfidenceFn(torch.autograd.Function):
+    """``ready`` (an event recorded when ``feats`` exists) selects the SIDE mode: the head's launches go to a stream of its own
+    (the module's), behind that event only -- beside the U-Net's decoder in the forward pass and beside its backward on the
+    way back, instead of ~25 latency-bound launches in front of them.  The results are handed over through
+    ``cu_hip.ops.pending_add`` / ``pending_wait`` (see there for who waits)."""
+
     @staticmethod
-    def forward(ctx, module: "ConfidenceNet", feats: Tensor, *params: Tensor):
+    def forward(ctx, module: "ConfidenceNet", ready, feats: Tensor, *params: Tensor):
         P = dict(zip(module._pnames, params))
-        out, ectx = module.engine.forward(P, feats)
+        ctx.side = None
+        if ready is not None:
+            side = module._side_stream(feats.device)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                out, ectx = module.engine.forward(P, feats)
+                done = torch.cuda.Event()
+                done.record(side)
+            _ops.pending_add(done)
+            ctx.side = side
+        else:
+            out, ectx = module.engine.forward(P, feats)
         ctx.module, ctx.ectx = module, ectx
         ctx.need_in = feats.requires_grad
         ctx.save_for_backward(*params)
@@ -323,16 +345,26 @@ class _ConfidenceFn(torch.autograd.Function):
         params = ctx.saved_tensors
         P = dict(zip(module._pnames, params))
         total = sum(p.numel() for p in params)
-        flat = torch.zeros(total, dtype=torch.float32, device=gout.device)
-        G, off = {}, 0
-        for n, p in zip(module._pnames, params):
-            G[n] = flat[off:off + p.numel()].view(p.shape)
-            off += p.numel()
-        module.last_flat_grad = flat
-        with _lib.device_guard(gout):
-            gin = module.engine.backward(P, G, ctx.ectx, gout, ctx.need_in)
+        # side mode only when the bottleneck gradient is wanted: the U-Net's backward then waits for it where it needs it
+        side = ctx.side if (ctx.need_in and not torch.cuda.is_current_stream_capturing()) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(gout.device))
+            gout.record_stream(side)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            flat = torch.zeros(total, dtype=torch.float32, device=gout.device)
+            G, off = {}, 0
+            for n, p in zip(module._pnames, params):
+                G[n] = flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            module.last_flat_grad = flat
+            with _lib.device_guard(gout):
+                gin = module.engine.backward(P, G, ctx.ectx, gout, ctx.need_in)
+            if side is not None:
+                done = torch.cuda.Event()
+                done.record(side)
+                _ops.pending_add(done)
         ctx.ectx = None
-        return (None, gin) + tuple(G[n] for n in module._pnames)
+        return (None, None, gin) + tuple(G[n] for n in module._pnames)
 
 
 class ConfidenceNet(nn.Module):
@@ -354,6 +386,13 @@ class ConfidenceNet(nn.Module):
         self._pnames = [n for n, _ in self.named_parameters()]
         self._flat = None
         self.last_flat_grad = None
+        self._side = None
+        self.side_enabled = os.environ.get("CONTOUR_SKEW_SIDE", "1") == "1"
+
+    def _side_stream(self, device):
+        if self._side is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device)
+        return self._side
 
     def set_compute_dtype(self, dtype):
         self.engine.dtype = _dtype_of(dtype)
@@ -379,12 +418,19 @@ class ConfidenceNet(nn.Module):
         self._ensure_flat()
         return self._flat, self.last_flat_grad
 
-    def forward(self, x):
+    def forward(self, x, side: bool = False):
+        """``side=True`` (the dsnt-skew training step): run beside the U-Net on a stream of this module's own when ``x`` is the
+        bottleneck a grad-enabled ``UNet.forward`` just returned.  The CALLER then owes a ``cu_hip.ops.pending_wait()`` before
+        anything but ``cu_hip.head.dsnt_nll`` reads the result (``dsnt_nll`` does it itself)."""
         _lib.require_gpu()
         if x.shape[1] != 480 or x.shape[2] != 2 or x.shape[3] != 2:
             raise ValueError(f"ConfidenceNet expects a (N, 480, 2, 2) bottleneck (reference unet2.py:22,29), got "
                              f"{tuple(x.shape)}")
         self._ensure_flat()
         params = self._params()
+        ready = getattr(x, "_cu_ready_event", None)
+        if not (side and self.side_enabled and torch.is_grad_enabled() and x.dtype == torch.float32
+                and not torch.cuda.is_current_stream_capturing()):
+            ready = None
         with _lib.device_guard(x):
-            return _ConfidenceFn.apply(self, x.float(), *params)
+            return _ConfidenceFn.apply(self, ready, x.float(), *params)

@@ -48,12 +48,19 @@ class DSNTSkew(SkewUncertaintyTask):
     configure_optimizers = DSNTAleatoric.configure_optimizers
     _val_dice = DSNTAleatoric._val_dice
 
-    def _alpha(self, heatmaps: Tensor, features: Tensor) -> Tensor:
-        """(N, K*, 2) head output scattered into zeros (N, K, 2) at skew_indices (reference dsnt_skew.py:68-71)."""
+    def _alpha(self, heatmaps: Tensor, features: Tensor, side: bool = False) -> Tensor:
+        """(N, K*, 2) head output scattered into zeros (N, K, 2) at skew_indices (reference dsnt_skew.py:68-71).
+        ``side``: the head may run on its own stream beside the U-Net (``ConfidenceNet.forward(side=True)``); the result then
+        goes straight to ``dsnt_nll``, which waits for it."""
         n, k = heatmaps.shape[0], heatmaps.shape[1]
-        a = self.skew_block(features).view(n, len(self.skew_indices), 2)
+        if side and hasattr(self.skew_block, "side_enabled"):
+            a = self.skew_block(features, side=True).view(n, len(self.skew_indices), 2)
+        else:
+            a = self.skew_block(features).view(n, len(self.skew_indices), 2)
         if len(self.skew_indices) == k:
             return a
+        from cu_hip import ops as _ops
+        _ops.pending_wait()          # the scatter below reads the head's output on the current stream
         alpha = torch.zeros(n, k, 2, device=a.device, dtype=a.dtype)
         alpha[:, self.skew_indices, :] = a
         return alpha
@@ -63,7 +70,7 @@ class DSNTSkew(SkewUncertaintyTask):
         # (inside fused_head() the heat maps may be a placeholder that only dsnt_nll reads: cu_hip/head_fused.hip)
         with (self.model.fused_head() if hasattr(self.model, "fused_head") else contextlib.nullcontext()):
             heatmaps, features = self.model(x)
-        alpha = self._alpha(heatmaps, features)
+        alpha = self._alpha(heatmaps, features, side=True)
         logs, pixel_coords, _ = dsnt_nll(heatmaps, y, alpha, self.hparams.covar)
         if self.is_val_step and Tags.gt in batch:
             self._val_dice(logs, batch, x, pixel_coords)

@@ -20,6 +20,8 @@ import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
+
+from . import ops
 import torch.distributed as dist
 
 
@@ -271,6 +273,7 @@ class GradSync:
         """Call after ``loss.backward()`` (of the LAST micro-batch when accumulating) and before the optimizer step."""
         if self.world == 1 or self.dry:
             return
+        ops.pending_wait()                  # the skew head's gradients may come from its own stream
         if self.skew is not None:
             splist = [p for _, p in self.skew.named_parameters()]
             if any(p.grad is not None for p in splist):

@@ -82,6 +82,7 @@ class UNetCtx:
     bott: Optional[Act] = None
     last: Optional[Act] = None
     n_up: int = 0
+    feats_event: Optional[object] = None # recorded when the bottleneck features exist
     raw_prefix: Optional[str] = None     # fused head: this layer keeps only its raw output + statistics
     head: Optional[dict] = None          # fused head: {"act", "w_cls", "w_ch"} of the launch pair in head_fused.hip
 
@@ -387,6 +388,11 @@ class UNetEngine:
         a = self._block_fwd(P, ctx, "bottleneck", [a], st[-1])
         ctx.bott = a
         feats = ops.act_to_nchw_f32(a) if want_bottleneck else None
+        if feats is not None and not torch.cuda.is_current_stream_capturing():
+            # the bottleneck exists from here on: a consumer on another stream (the skew head, cu_hip ConfidenceNet side mode)
+            # waits for this event instead of for the whole decoder that is enqueued behind it
+            ctx.feats_event = torch.cuda.Event()
+            ctx.feats_event.record()
         up_strides = st[1:][::-1]
         for i, skip in enumerate(reversed(ctx.enc)):
             assert up_strides[i] == 2, "transposed conv kernel = stride = 2 on the dsnt path"
@@ -445,6 +451,7 @@ class UNetEngine:
         return torch.cuda.stream(self._side)
 
     def _join_wgrad(self, device):
+        ops.pending_wait()                  # (a side task nobody consumed inside this backward: its results are gradients)
         if self._side is not None and self._side_keep:
             torch.cuda.current_stream(device).wait_stream(self._side)
             if self._red is not None:
@@ -724,8 +731,6 @@ class UNetEngine:
         d_enc: List[Optional[Tensor]] = [None] * len(ctx.enc)
         n_up = ctx.n_up
         d_bott = None
-        if dfeats is not None:
-            d_bott = ops.nchw_f32_to_nhwc(dfeats.contiguous(), dt)
         for i in reversed(range(n_up)):
             up = ctx.ups[i]
             pre = f"upsamples.{i}.conv_block"
@@ -738,6 +743,9 @@ class UNetEngine:
             self._conv_layer_bwd(P, G, ctx, f"{pre}.conv1", g_c1, [(du, 0), (d_enc[k], 0)])
             del g_c1
             if i == 0:
+                if dfeats is not None:
+                    ops.pending_wait()       # the skew head's backward may have produced dfeats on its own stream
+                    d_bott = ops.nchw_f32_to_nhwc(dfeats.contiguous(), dt)
                 accum = 1 if d_bott is not None else 0
                 d_in = d_bott if d_bott is not None else torch.empty_like(up.src.z)
             else:

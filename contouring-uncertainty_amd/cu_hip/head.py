@@ -30,7 +30,7 @@ class GradSlot:
     gradient -- ``torch.autograd.grad(loss, logits)``, ``logits.retain_grad()``, a tensor hook on the logits: those see the
     zero stand-in.  ``dsnt_nll(..., dense_grad=True)`` (or ``slot.enabled = False``) selects the dense NCHW float32
     gradient for such uses."""
-    __slots__ = ("dtype", "dl", "enabled", "fused", "head", "head_grads")
+    __slots__ = ("dtype", "dl", "enabled", "fused", "head", "head_grads", "feats_event")
 
     def __init__(self, dtype):
         self.dtype = dtype
@@ -41,6 +41,7 @@ class GradSlot:
         self.fused = False
         self.head: Optional[dict] = None
         self.head_grads: Optional[tuple] = None
+        self.feats_event = None      # recorded when the bottleneck features of the same forward exist
 
     def put_head(self, aux: Tensor, gmu: Tensor, gsigma: Tensor, covar: bool):
         if not covar:
@@ -83,6 +84,8 @@ class _DsntNllFn(torch.autograd.Function):
                 logits = logits.new_empty(0)
             else:
                 mu, sigma, aux = ops.dsnt_head_fwd(logits, covar)
+            if alpha is not None:
+                ops.pending_wait()          # alpha may come from the skew head's own stream (ConfidenceNet side mode)
             al = alpha.contiguous().float() if alpha is not None else None
             logs, gmu, gsigma, galpha = ops.nll_fwd_bwd(mu, sigma, y.contiguous().float(), al, w_mse, w_log, need_grad)
         ctx.covar = covar

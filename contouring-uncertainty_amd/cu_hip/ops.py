@@ -70,6 +70,26 @@ class _Prof:
         return False
 
 
+# ---- side tasks: work enqueued on a stream of its own whose results a LATER launch on the main stream consumes (the skew head
+#      beside the U-Net's decoder / backward).  The producer records an event and registers it here; every consumer calls
+#      pending_wait() before its first launch that reads those results (cu_hip.head before the NLL kernel, UNetEngine.backward
+#      before the bottleneck gradient and at its end, FusedAdam.step, GradSync.finish).
+_PENDING: List[torch.cuda.Event] = []
+
+
+def pending_add(ev: "torch.cuda.Event"):
+    _PENDING.append(ev)
+
+
+def pending_wait():
+    """the current stream waits for every side task registered since the last call"""
+    if _PENDING:
+        cur = torch.cuda.current_stream()
+        for ev in _PENDING:
+            cur.wait_event(ev)
+        _PENDING.clear()
+
+
 def _taps(desc, dys, dxs, ws, zys=None, zxs=None):
     desc.ntaps = len(dys)
     for i, (a, b, c) in enumerate(zip(dys, dxs, ws)):

@@ -123,6 +123,7 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = None):
         loss = None
+        ops.pending_wait()                  # gradients produced on a side stream (the skew head's backward)
         if grad_scale is None:
             grad_scale = self.grad_scale
         if closure is not None:

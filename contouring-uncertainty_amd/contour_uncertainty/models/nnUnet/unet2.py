@@ -409,10 +409,13 @@ class ConfidenceNet(nn.Module):
             pl = self._plist = [named[n] for n in self._pnames]
         return pl
 
-    def _ensure_flat(self):
+    def _ensure_flat(self) -> bool:
+        """True when the parameters had to be re-homed by this call (copies enqueued on the current stream just now)"""
         plist = self._params()
         if self._flat is None or not _is_flat(plist) or self._flat.device != plist[0].device:
             self._flat = _flatten_params(self, self._pnames)
+            return True
+        return False
 
     def flat_params(self):
         self._ensure_flat()
@@ -426,11 +429,13 @@ class ConfidenceNet(nn.Module):
         if x.shape[1] != 480 or x.shape[2] != 2 or x.shape[3] != 2:
             raise ValueError(f"ConfidenceNet expects a (N, 480, 2, 2) bottleneck (reference unet2.py:22,29), got "
                              f"{tuple(x.shape)}")
-        self._ensure_flat()
+        moved = self._ensure_flat()
         params = self._params()
         ready = getattr(x, "_cu_ready_event", None)
-        if not (side and self.side_enabled and torch.is_grad_enabled() and x.dtype == torch.float32
-                and not torch.cuda.is_current_stream_capturing()):
+        # the side stream runs behind `ready` only, i.e. behind what the current stream held when the bottleneck was produced:
+        # parameters written later than that (re-homed just now) are not ordered before it -> this call stays on the current stream
+        if moved or not (side and self.side_enabled and torch.is_grad_enabled() and x.dtype == torch.float32
+                         and not torch.cuda.is_current_stream_capturing()):
             ready = None
         with _lib.device_guard(x):
             return _ConfidenceFn.apply(self, ready, x.float(), *params)

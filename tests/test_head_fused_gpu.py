@@ -210,3 +210,27 @@ def test_fused_head_placeholder_misuse_raises():
         dsnt_nll(hm, torch.zeros(2, 21, 2, device=DEV), None, True, dense_grad=True)
     with pytest.raises(Exception):
         (hm * torch.ones_like(hm)).sum().backward()          # a dense gradient on the placeholder
+
+
+def test_skew_head_side_stream_only_after_parameters_are_home():
+    """ConfidenceNet(side=True) runs on its own stream behind the bottleneck-ready event.  The call that re-homes the
+    parameters into the flat buffer (copies enqueued AFTER that event) must stay on the current stream; from the second step
+    on the side stream is used, and the step's logs equal those of the same step with the side mode off."""
+    from contour_uncertainty.data.synthetic import synthetic_batch
+    torch.manual_seed(0)
+    task = _task()
+    img, contour = synthetic_batch(4, 64, 21, seed=3)
+    batch = {"img": img.to(DEV), "contour": contour.to(DEV)}
+    out1 = task.training_step(batch, 0)
+    out1["loss"].backward()
+    assert task.skew_block._side is None                       # first call: parameters were flattened in it
+    out2 = task.training_step(batch, 0)
+    out2["loss"].backward()
+    assert task.skew_block._side is not None                   # second call: beside the decoder
+    task.skew_block.side_enabled = False
+    out3 = task.training_step(batch, 0)
+    out3["loss"].backward()
+    torch.cuda.synchronize()
+    for k in ("loss", "loss_term3", "alpha_norm"):
+        a, b, c = float(out1[k].detach()), float(out2[k].detach()), float(out3[k].detach())
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(a)) and abs(c - b) <= 2e-4 * max(1.0, abs(c)), (k, a, b, c)

@@ -231,6 +231,8 @@ def test_skew_head_side_stream_only_after_parameters_are_home():
     out3 = task.training_step(batch, 0)
     out3["loss"].backward()
     torch.cuda.synchronize()
-    for k in ("loss", "loss_term3", "alpha_norm"):
+    keys = [k for k in out1 if k == "loss" or k.endswith("loss_term3") or k.endswith("alpha_norm")]
+    assert len(keys) == 3, list(out1)
+    for k in keys:
         a, b, c = float(out1[k].detach()), float(out2[k].detach()), float(out3[k].detach())
         assert abs(a - b) <= 2e-4 * max(1.0, abs(a)) and abs(c - b) <= 2e-4 * max(1.0, abs(c)), (k, a, b, c)

@@ -354,7 +354,7 @@ def main():
         # HBM bytes per launch come from separate rocprofv3 --pmc passes of this very command (FETCH_SIZE x 2 + WRITE_SIZE,
         # MI355X_MICROARCH.md HBM section), committed under profiles/: a COMMITTED constant of the newest such file, not a
         # measurement of this run (traffic_source says which)
-        for cand in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+        for cand in ("r03b_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
             pmc = ROOT / "profiles" / cand
             if pmc.exists() and per_gpu == 64 and args.size == 256 and args.dtype == "bf16":
                 famrec = json.loads(pmc.read_text())["families"].get(name)

@@ -11,10 +11,11 @@ import sys
 from collections import defaultdict
 from pathlib import Path
 
-FAMILIES = [("igemm_conv", "igemm_conv"), ("pconv_kernel", "igemm_conv"), ("pconv2_kernel", "igemm_conv"), ("tconv_kernel", "igemm_conv"), ("ksplit_finish", "igemm_conv"),
+FAMILIES = [("head_fwd", "dsnt_head"), ("head_bwd", "dsnt_head"), ("c1_bwd", "conv_c1"), ("igemm_conv", "igemm_conv"), ("pconv_kernel", "igemm_conv"), ("pconv2_kernel", "igemm_conv"), ("tconv_kernel", "igemm_conv"), ("ksplit_finish", "igemm_conv"),
             ("igemm_wgrad", "igemm_wgrad"), ("gemm_tn_kernel", "igemm_wgrad"), ("parts_", "weight_prep"), ("fwd_resident", "instnorm_apply"), ("stats_", "instnorm_stats"),
             ("apply_kernel", "instnorm_apply"), ("bwd_", "instnorm_bwd"), ("act_bwd", "instnorm_bwd"),
             ("weight_prep", "weight_prep"), ("grad_unprep", "weight_prep"), ("adam", "adam"), ("conv_c1", "conv_c1"),
+            ("head_fwd", "dsnt_head"), ("head_bwd", "dsnt_head"), ("c1_bwd", "conv_c1"), ("c1_moments", "conv_c1"), ("c1_stats", "conv_c1"),
             ("dsnt", "dsnt_head"), ("nll", "dsnt_head")]
 
 

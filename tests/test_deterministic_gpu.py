@@ -46,8 +46,8 @@ def test_two_runs_of_a_step_are_bit_identical(kind, stages, size, dtype, n):
     for l, g in runs[1:]:
         assert l == l0
         assert g.keys() == g0.keys()
-        for k in g0:
-            assert torch.equal(g[k], g0[k]), k
+        bad = [k for k in g0 if not torch.equal(g[k], g0[k])]
+        assert not bad, (len(bad), len(g0), bad[:6], [float((g[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30)) for k in bad[:6]])
     # the same numbers as the default mode up to summation order.  Per-parameter comparison on the well-conditioned f32
     # network only: the 6-stage bf16 network normalises 2 x 2 maps, where the last bit of a statistic moves the deep
     # layers' gradients by tens of per cent between two DEFAULT runs already (tests/test_graph_gpu.py)

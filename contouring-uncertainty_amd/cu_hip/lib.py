@@ -163,11 +163,24 @@ def stream_ptr() -> int:
     must live there (checked here on the first operand of the call -- the wrappers allocate every output on that
     operand's device; ``device_guard`` makes an operand's device current)."""
     t, _first_operand[0] = _first_operand[0], None
-    if t is not None and t.device.index != torch.cuda.current_device():
-        raise ContourHipError(f"operand on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+    dev = _get_device()
+    if t is not None and t.device.index != dev:
+        raise ContourHipError(f"operand on {t.device} but the current device is cuda:{dev}: "
                               "launches go to the current device's stream (use torch.cuda.set_device / "
                               "cu_hip.lib.device_guard)")
-    return torch.cuda.current_stream().cuda_stream
+    # (the raw handle straight from the C side: torch.cuda.current_stream() builds a Stream object per call, ~4 us of the
+    # host's ~25 us per launch -- tools/cpu_bound.py)
+    return _raw_stream(dev)
+
+
+def _get_device() -> int:
+    f = getattr(torch._C, "_cuda_getDevice", None)
+    return f() if f is not None else torch.cuda.current_device()
+
+
+def _raw_stream(dev: int) -> int:
+    f = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    return f(dev) if f is not None else torch.cuda.current_stream().cuda_stream
 
 
 def device_guard(t):

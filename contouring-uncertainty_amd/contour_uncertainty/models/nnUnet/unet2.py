@@ -144,6 +144,7 @@ class _UNetFn(torch.autograd.Function):
                 n, k = ctx.ectx.img.shape[0], module.num_classes
                 z0 = torch.zeros((n, k, 3), dtype=torch.float32, device=params[0].device)
                 aux0 = torch.zeros((n, k, 8), dtype=torch.float32, device=params[0].device)
+                aux0[..., 0] = 1e30          # log-sum-exp far above any logit: softmax weights 0 (never 0 * inf)
                 aux0[..., 1] = 1.0
                 hg = (aux0, z0[..., :2].contiguous(), z0, True)
             with _lib.device_guard(hg[0]):

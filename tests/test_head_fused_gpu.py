@@ -236,3 +236,20 @@ def test_skew_head_side_stream_only_after_parameters_are_home():
     for k in keys:
         a, b, c = float(out1[k].detach()), float(out2[k].detach()), float(out3[k].detach())
         assert abs(a - b) <= 2e-4 * max(1.0, abs(a)) and abs(c - b) <= 2e-4 * max(1.0, abs(c)), (k, a, b, c)
+
+
+def test_fused_head_backward_when_the_loss_ignores_the_landmarks():
+    """a loss that depends on the bottleneck only (nothing reaches the placeholder logits): the U-Net's backward runs the
+    fused head with zero incoming gradients -- finite everywhere, zero for the output block"""
+    from contour_uncertainty.data.synthetic import synthetic_batch
+    torch.manual_seed(0)
+    task = _task()
+    img, _ = synthetic_batch(2, 64, 21, seed=3)
+    with task.model.fused_head():
+        hm, feats = task.model(img.to(DEV))
+    assert hm._cu_grad_slot.head is not None
+    feats.square().mean().backward()
+    grads = {n: p.grad for n, p in task.model.named_parameters() if p.grad is not None}
+    assert all(torch.isfinite(g).all() for g in grads.values())
+    assert float(grads["output_block.conv.weight"].abs().max()) == 0.0
+    assert float(grads["bottleneck.conv2.conv.weight"].abs().max()) > 0.0

@@ -805,10 +805,20 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs
 // row g): wait for its stage with a counted vmcnt, ONE barrier (publishes the stage, frees slot (g+2) % 3), issue the
 // weights of the iteration after next plus a third of the next chunk's halo image -- always six DMA instructions per
 // thread, out-of-range ones (into an 8-KiB dump area) where there is nothing to fetch, so the wait count is a constant.
+// NB = 4: 128 columns, one staging round (128 rows) per tap.  NB = 2 (round 3): 64 columns -- the layers whose column count or
+// workgroup count rules the 128-column tile out (128^2 concat 64+64 -> 64; 16^2 x 480 channels, where 128 columns leave half the
+// CUs without a workgroup) ran on the non-overlapped kernel above at ~700 TFLOP/s with their per-chunk LDS-DMA (3.4 us) and
+// MFMAs (3.4 us) in series.  A tap row of 64 columns is 12 KiB: two staging rounds per tap row (taps 0, 1 | tap 2 + padding),
+// five DMA instructions per thread and iteration instead of six.  NXR = staging rounds of the halo image (5: one image of
+// 16 x 32 pixels; 6: two images of 16 x 16).
+template <int NB, int NXR>
 __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_ring_kernel(const ConvKArgs p, unsigned src0_bytes,
                                                                      unsigned src1_bytes, unsigned w_bytes) {
-    constexpr int MA = 2, NB = 4, BN = 128, CK = 32, NXR = 5;      // halo image = 5 staging rounds of 128 rows
-    constexpr unsigned XB = NXR * 8192, WSLOT = 3 * 8192;
+    constexpr int MA = 2, BN = 32 * NB, CK = 32;
+    constexpr int WR = NB == 4 ? 3 : 2;                            // weight staging rounds (DMA instructions) per tap row
+    constexpr int IT = WR + 3;                                     // DMA instructions per thread and iteration
+    constexpr unsigned XB = NXR * 8192, WSLOT = WR * 8192;
+    static_assert((NB == 4 || NB == 2) && NXR >= 3 && NXR <= 6, "ring kernel: instances");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -840,7 +850,8 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_ring_kernel(const Conv
         xoff[j] = ok ? (unsigned)((n * p.SH + sy) * p.SW + sx) : 0xffffffffu;
         xpiece[j] = slot ^ ((hp >> 2) & 3);
     }
-    const int wcol = tid >> 2;                          // 128 weight rows (= columns) per staging round, one tap per round
+    // weight rows of a staging round: NB = 4: 128 columns of one tap; NB = 2: row (tid >> 2) + 128 j = (tap, column) pair
+    const int wcol = (tid >> 2) & (BN - 1);
     const bool wok = n0 + wcol < p.CO;
     const int wpiece = slot ^ ((wcol >> 2) & 3);
 
@@ -888,9 +899,14 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_ring_kernel(const Conv
         constexpr int g = decltype(G)::value;
         const bool live = c < nch;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int tw = p.tap_w[3 * g + j];
-            const unsigned off = (live && wok) ? (unsigned)(((tw * p.CO + n0 + wcol) * CI + c * CK + wpiece * 8)) * 2u : OOB;
+        for (int j = 0; j < WR; ++j) {
+            // the tap this thread's row of round j belongs to (NB = 4: j; NB = 2: two taps per round, the last half round empty)
+            // (static indices into the by-value argument block only: a lane-dependent one would move it to scratch)
+            const int tl = NB == 4 ? j : 2 * j + (tid >> 8);
+            const int tw_a = p.tap_w[3 * g + (NB == 4 ? j : (2 * j < 3 ? 2 * j : 0))];
+            const int tw_b = p.tap_w[3 * g + (NB == 4 ? j : (2 * j + 1 < 3 ? 2 * j + 1 : 0))];
+            const int tw = (NB == 4 || tid < 256) ? tw_a : tw_b;
+            const unsigned off = (live && wok && tl < 3) ? (unsigned)(((tw * p.CO + n0 + wcol) * CI + c * CK + wpiece * 8)) * 2u : OOB;
             dma16(rw, off, w_base + (unsigned)(g * WSLOT + j * 8192 + wave * 1024));
         }
     };
@@ -933,22 +949,22 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_ring_kernel(const Conv
     issue_w(0, G0{});
     issue_w(0, G1{});
     for (int c = 0; c < nch; ++c) {
-        // ---- tap row 0: needs X(c) and W(c, 0); younger: W(c, 1) [first chunk] / the 6 instructions of the iteration before
-        if (c == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // ---- tap row 0: needs X(c) and W(c, 0); younger: W(c, 1) [first chunk] / the IT instructions of the iteration before
+        if (c == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WR) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IT) : "memory");
         __syncthreads();
         issue_w(c, G2{});
         issue_x(c + 1, 0, 3);
         compute(c, G0{});
         // ---- tap row 1
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IT) : "memory");
         __syncthreads();
         issue_w(c + 1, G0{});
         issue_x(c + 1, 3, NXR);
         issue_dump(3 - (NXR - 3));
         compute(c, G1{});
         // ---- tap row 2
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IT) : "memory");
         __syncthreads();
         issue_w(c + 1, G1{});
         issue_dump(3);
@@ -1386,13 +1402,18 @@ extern "C" int cu_conv_gemm_ex(const cu_conv_desc* d, const void* src0, const fl
                     a.tap_w[t] = d->tap_w[t];
                     CU_CHECK_ARG(d->tap_w[t] >= 0, "cu_conv_gemm: negative weight tap index");
                 }
-                if (d->IS == 1 && dnb == 4 && halo_pad == 640 && !cu_env_set("CU_CONV_NORING")) {
-                    const size_t rl = 2 * 5 * 8192 + 3 * 3 * 8192 + 8192;          // two halo images, three tap rows, dump
-                    auto kr = igemm_conv_dma_ring_kernel;
+                const int nxr = halo_pad / 128;
+                const bool ring4 = d->IS == 1 && dnb == 4 && nxr == 5;
+                const bool ring2 = d->IS == 1 && dnb == 2 && (nxr == 5 || nxr == 6) && !cu_env_set("CU_CONV_NORING2");
+                if ((ring4 || ring2) && !cu_env_set("CU_CONV_NORING")) {
+                    // two halo images, three tap rows (3 / 2 staging rounds each), dump
+                    const size_t rl = (size_t)2 * nxr * 8192 + (size_t)3 * (ring4 ? 3 : 2) * 8192 + 8192;
+                    auto kr = ring4 ? igemm_conv_dma_ring_kernel<4, 5>
+                                    : (nxr == 5 ? igemm_conv_dma_ring_kernel<2, 5> : igemm_conv_dma_ring_kernel<2, 6>);
                     hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kr),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);
                     CU_CHECK_ARG(er == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(er));
-                    hipLaunchKernelGGL(kr, dim3(a.ntiles, cdiv(d->CO, 128)), dim3(64 * DW), rl,
+                    hipLaunchKernelGGL(kr, dim3(a.ntiles, cdiv(d->CO, 32 * dnb)), dim3(64 * DW), rl,
                                        reinterpret_cast<hipStream_t>(stream), a, (unsigned)b0, (unsigned)b1, (unsigned)bw);
                     CU_LAUNCH_CHECK();
                     return 0;

@@ -1356,6 +1356,8 @@ extern "C" int cu_conv_gemm_ex(const cu_conv_desc* d, const void* src0, const fl
         int dnb = d->CO % 128 == 0 || d->CO > 256 ? 4 : 2;             // 128-column tiles unless that wastes half a tile
         if (dnb == 4 && (px_all / dbm) * cdiv(d->CO, 128) < 256)
             dnb = 2;                                                     // ... or leaves CUs without a workgroup
+        // (64 columns for the two-chunk 64 -> 128-column input gradient at 128^2, which is mostly prologue + epilogue on the
+        //  128-column ring: measured slower, 229 / 259 us with / without the 64-column ring against 195 us)
         if (d->IS == 2) dnb = 4;
         if (d->IS == 1 && d->CO <= 32) dnb = 1;                          // thin layers (256^2 x 32 channels)
         if (d->IS == 1 && dnb > 1 && cu_env_int("CU_CONV_DNB", 0)) dnb = cu_env_int("CU_CONV_DNB", 0);
@@ -1403,6 +1405,9 @@ extern "C" int cu_conv_gemm_ex(const cu_conv_desc* d, const void* src0, const fl
                     CU_CHECK_ARG(d->tap_w[t] >= 0, "cu_conv_gemm: negative weight tap index");
                 }
                 const int nxr = halo_pad / 128;
+                // two images per tile (16 x 16 maps) and 128 columns: the two halo images + three 24-KiB tap rows exceed the
+                // LDS; the 64-column ring fits (tuning knob CU_CONV_RING2_WIDE: 0 keeps the non-overlapped 128-column kernel)
+                if (d->IS == 1 && dnb == 4 && nxr == 6 && cu_env_int("CU_CONV_RING2_WIDE", 1)) dnb = 2;
                 const bool ring4 = d->IS == 1 && dnb == 4 && nxr == 5;
                 const bool ring2 = d->IS == 1 && dnb == 2 && (nxr == 5 || nxr == 6) && !cu_env_set("CU_CONV_NORING2");
                 if ((ring4 || ring2) && !cu_env_set("CU_CONV_NORING")) {

@@ -141,6 +141,7 @@ class UNetEngine:
         # True: on maps of <= 64 pixels (8x8 and below) the split-K finish pass of the convolution / input-gradient launch
         # carries the layer's InstanceNorm + LeakyReLU forward / backward (no separate, latency-bound norm launch)
         self.small_norm = os.environ.get("CONTOUR_SMALL_NORM", "1") == "1"
+        self.small_norm_px = int(os.environ.get("CONTOUR_SMALL_NORM_PX", "64"))     # largest map (pixels per image) that takes it
         # True: when the caller asks for it (UNet.fused_head(), i.e. the dsnt tasks' training step), the last ConvLayer's
         # InstanceNorm + LeakyReLU, the 1x1 OutputBlock and the DSNT moments run as ONE pass over that layer's raw output, and
         # the backward of all three (+ the reduction pass of that layer's norm backward) as one more (head_fused.hip)
@@ -245,7 +246,7 @@ class UNetEngine:
         if fusable:
             sums = self._arena["fwd"].take(2 * n * co, z.device)
         small = None
-        if (not fusable and self.small_norm and self.fused_norm and self.materialize and oh * ow <= 64 and co % 32 == 0
+        if (not fusable and self.small_norm and self.fused_norm and self.materialize and oh * ow <= self.small_norm_px and co % 32 == 0
                 and not (ctx.training and prefix in self.drop_layers)):
             small = (P[f"{prefix}.norm.weight"], P[f"{prefix}.norm.bias"], self.eps, self.slope,
                      torch.empty((4, n, co), dtype=torch.float32, device=z.device), torch.empty_like(z))
@@ -320,8 +321,6 @@ class UNetEngine:
             out = ops.conv_c1_fwd_norm(img, w9, P[f"{prefix}.conv.bias"], P[f"{prefix}.norm.weight"],
                                        P[f"{prefix}.norm.bias"], self.slope, self.eps, self.dtype, keep_z=not no_z)
             if no_z:
-                if not ctx.keep:
-                    return Act(out.a, None, 1.0)
                 ctx.convs[prefix] = _ConvRec(prefix, [], out, 1, first=True, no_z=True)
                 self._producer[id(out)] = prefix
                 return out
@@ -619,7 +618,7 @@ class UNetEngine:
         the norm backward of the layer that produced it (maps of <= 64 pixels), else None."""
         tgt = self._producer.get(id(src)) if src is not None else None
         if (tgt is None or not self.small_norm or not self.fused_norm or self.deterministic or self.debug is not None
-                or hw > 64 or c % 32 != 0):
+                or hw > self.small_norm_px or c % 32 != 0):
             return None
         rec = ctx.convs.get(tgt)
         if rec is None or rec.drop_mask is not None or rec.out.stats is None or rec.first:

@@ -78,6 +78,8 @@ _PENDING: List[torch.cuda.Event] = []
 
 
 def pending_add(ev: "torch.cuda.Event"):
+    if len(_PENDING) >= 32:      # nobody consumed them (a caller that never reads the results): do not grow without bound
+        pending_wait()
     _PENDING.append(ev)
 
 

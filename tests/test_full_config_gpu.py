@@ -20,8 +20,9 @@ sys.path.insert(0, str(ROOT))
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
 SIZE, K = 256, 21
-CONFIGS = {"c3-dsnt-skew-b64": ("dsnt-skew", 64, True), "c2-dsnt-al-b32": ("dsnt-al", 32, False),
-           "c4-dsnt-al2-b64": ("dsnt-al", 64, True)}
+# (c2 as config/task/dsnt-al.yaml has it -- covar: True, batch 32 -- and the diagonal-covariance variant of the same task)
+CONFIGS = {"c3-dsnt-skew-b64": ("dsnt-skew", 64, True), "c2-dsnt-al-b32": ("dsnt-al", 32, True),
+           "c2-dsnt-al-b32-diagonal": ("dsnt-al", 32, False), "c4-dsnt-al2-b64": ("dsnt-al", 64, True)}
 
 
 @pytest.fixture(scope="module", params=list(CONFIGS))

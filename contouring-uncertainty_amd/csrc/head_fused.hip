@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HfArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int tile = blockIdx.x * 4 + wave;
     if (tile >= p.ntiles) return;                      // whole waves; no workgroup barrier below
+    // (a persistent loop over tiles with a one-round grid was measured: 95 us against 82 us for one tile per wave)
     const int tx = tile % p.tiles_x, rest = tile / p.tiles_x;
     const int ty = rest % p.tiles_y, n = rest / p.tiles_y;
 
@@ -509,12 +510,16 @@ extern "C" int cu_head_fused_bwd(int N, int H, int W, int K, const void* z, cons
     a.z = (const bf16_t*)z; a.stats = stats; a.w_cls = (const bf16_t*)w_cls; a.w_ch = (const bf16_t*)w_ch;
     a.N = N; a.H = H; a.W = W; a.K = K; a.slope = slope; a.use_covar = use_covar;
     a.aux = aux; a.gmu = gmu; a.gsigma = gsigma; a.g = (bf16_t*)g; a.sums = sums; a.parts = parts;
-    // runs of 32 x rows pixels per wave: enough runs to fill the chip (>= 4096 waves' worth) before they get long
+    // runs of 32 x rows pixels per wave: one round of 512 workgroups (two per CU at this kernel's 2 waves per SIMD) with one run
+    // per wave where the problem is large enough.  Measured at 64 x 256^2 (tools/head_bench.py, tuning knobs CU_HF_ROWS /
+    // CU_HF_WGS): rows 64 x 512 workgroups 155 us; 32 x 1024: 161 - 164; 16: 173 - 177; 128: 184; 256: 293
     int rows = H;
-    while (rows > 16 && rows % 2 == 0 && (long)N * (W / 32) * (H / rows) < 4096) rows /= 2;
+    while (rows > 16 && rows % 2 == 0 && (long)N * (W / 32) * (H / rows) < 2048) rows /= 2;
+    if (cu_env_int("CU_HF_ROWS", 0) > 0 && H % cu_env_int("CU_HF_ROWS", 0) == 0) rows = cu_env_int("CU_HF_ROWS", 0);
     a.rows = rows; a.tiles_x = W / 32; a.tiles_y = H / rows; a.ntiles = N * a.tiles_x * a.tiles_y;
     int wgs = cdiv(a.ntiles, 4);
-    if (wgs > 1024) wgs = 1024;
+    const int wg_cap = cu_env_int("CU_HF_WGS", 512) <= 1024 ? cu_env_int("CU_HF_WGS", 512) : 1024;
+    if (wgs > wg_cap) wgs = wg_cap;
     CU_CHECK_ARG(parts_floats >= (size_t)(wgs + 1) * 1024, "cu_head_fused_bwd: workspace of %zu floats, needs %zu", parts_floats,
                  (size_t)(wgs + 1) * 1024);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -90,7 +90,7 @@ def test_fused_head_forward_far_reference():
 
 
 @pytest.mark.parametrize("n,size,k,covar", [(3, 64, 21, True), (2, 128, 21, False), (2, 32, 5, True), (1, 64, 32, True),
-                                            (64, 256, 21, True)])      # the last: BASELINE's full size (runs of 32 rows per wave)
+                                            (64, 256, 21, True)])      # the last: BASELINE full size (runs of 64 rows per wave)
 def test_fused_head_backward(n, size, k, covar):
     ops, act, w, w_cls, w_ch = _setup(n, size, k, seed=100 + size + k)
     logits, (mu0, sg0, aux0) = _unfused_fwd(ops, act, w_cls, k, covar)

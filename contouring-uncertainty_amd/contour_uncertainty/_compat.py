@@ -340,6 +340,10 @@ class Trainer:
         self._init_distributed()
         self.datamodule = datamodule
         model.trainer = self
+        try:
+            datamodule.trainer = self       # Lightning attaches itself to the data module too (``trainer.training`` gates its hooks)
+        except AttributeError:
+            pass
         model.to(device)
         datamodule.setup("fit")
         if not any(isinstance(c, GradSyncCallback) for c in self.callbacks) and self.world > 1:
@@ -352,6 +356,7 @@ class Trainer:
         for epoch in range(epochs):
             model.current_epoch = epoch
             model.train()
+            self.training = True
             for idx, batch in self._mine(datamodule.train_dataloader()):
                 batch = _to_device(batch, device)
                 hook = getattr(datamodule, "on_after_batch_transfer", None)      # Lightning's hook: on-device augmentation
@@ -369,9 +374,14 @@ class Trainer:
                     done = True
                     break
             model.eval()
+            self.training = False
             with torch.no_grad():
                 for idx, batch in self._mine(datamodule.val_dataloader()):
-                    out = model.validation_step(_to_device(batch, device), idx)
+                    batch = _to_device(batch, device)
+                    hook = getattr(datamodule, "on_after_batch_transfer", None)      # called for every stage, as Lightning does
+                    if hook is not None:
+                        batch = hook(batch, idx)
+                    out = model.validation_step(batch, idx)
                     self.callback_metrics.update({k: v.detach() if torch.is_tensor(v) else v for k, v in out.items()})
                     if self.fast_dev_run and idx + 1 >= self.fast_dev_run:
                         break
@@ -388,6 +398,7 @@ class Trainer:
         self.datamodule = datamodule
         model.trainer = self
         model.to(device).eval()
+        self.training = False
         datamodule.setup("predict")
         model.on_predict_start()
         results = []

@@ -99,9 +99,13 @@ class SyntheticContourDataModule:
         self.transforms = self.da_transforms if da else None
 
     def on_after_batch_transfer(self, batch, dataloader_idx: int = 0):
-        """Lightning's post-transfer hook (``_compat.Trainer.fit`` calls it for training batches): image, label map and key
-        points of every item transformed with the item's own random parameters, on the device."""
+        """Lightning's post-transfer hook: image, label map and key points of every item transformed with the item's own
+        random parameters, on the device.  TRAINING batches only, as the reference augments its training subset only
+        (data/camus/datamodule.py:46-55): ``_compat.Trainer.fit`` calls the hook from its training loop; real Lightning calls
+        it for validation / test / predict batches too, where ``trainer.training`` is False."""
         if self.transforms is None or not batch[Tags.img].is_cuda:
+            return batch
+        if not getattr(getattr(self, "trainer", None), "training", True):
             return batch
         out = self.transforms(image=batch[Tags.img], mask=batch[Tags.gt], keypoints=batch[ContourTags.contour])
         batch = dict(batch)

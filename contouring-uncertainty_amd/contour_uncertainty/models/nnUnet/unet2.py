@@ -132,6 +132,15 @@ class _UNetFn(torch.autograd.Function):
         module.last_flat_grad = flat
         if module.flat_grad_hook is not None:
             module.flat_grad_hook(flat)
+        # the skew head (side mode) leaves dL/dfeats in the slot and hands autograd a stride-0 zero stand-in: the real tensor
+        # is still being written on the head's stream, so it is only read behind ops.pending_wait(), where the engine needs
+        # it; a dense ``dfeats`` is a genuine extra gradient of the bottleneck (another consumer) and is added there
+        side_gin = ctx.slot.take_feats() if ctx.slot is not None else None
+        if side_gin is not None:
+            extra = dfeats if (dfeats is not None and not all(s_ == 0 for s_ in dfeats.stride())) else None
+
+            def dfeats(extra=extra, side_gin=side_gin):       # called by the engine after its pending_wait()
+                return side_gin if extra is None else side_gin + extra
         # the DSNT head may have left dL/dlogits in the engine's layout (cu_hip.head.GradSlot); its stand-in in autograd is
         # a stride-0 zero tensor, and anything else that reached ``dlogits`` is a genuine extra gradient to add
         if ctx.ectx is not None and ctx.ectx.head is not None:
@@ -261,13 +270,26 @@ class UNet(nn.Module):
         return super()._apply(fn, recurse)
 
     def _params(self):
-        """(all parameters in ``_pnames`` order, the used ones) -- cached: walking the module tree costs ~1 ms per call"""
+        """(all parameters in ``_pnames`` order, the used ones) -- cached: walking the module tree costs ~1 ms per call.
+        ``_apply`` drops the cache; operations that replace Parameter OBJECTS without it (``load_state_dict(assign=True)``,
+        ``conv.weight = nn.Parameter(...)``) are caught by ``_param_probe``: the identity of every holder's ``weight`` / ``bias``
+        entry, checked on every call (~30 us) -- ADVICE r3."""
         pl = getattr(self, "_plists", None)
+        if pl is not None and self._param_probe() != self._plists_probe:
+            pl = None
         if pl is None:
             named = dict(self.named_parameters())
             used = set(self._used_names)
             pl = self._plists = ([named[n] for n in self._pnames], [named[n] for n in self._pnames if n in used])
+            self._holders = [m for m in self.modules() if m._parameters]
+            self._plists_probe = self._param_probe()
         return pl
+
+    def _param_probe(self):
+        hs = getattr(self, "_holders", None)
+        if hs is None:
+            return None
+        return [id(p) for m in hs for p in m._parameters.values()]
 
     def _ensure_flat(self):
         plist = self._params()[1]
@@ -311,6 +333,7 @@ class UNet(nn.Module):
             (out[0] if isinstance(out, tuple) else out)._cu_grad_slot = slot
             if isinstance(out, tuple) and slot.feats_event is not None:
                 out[1]._cu_ready_event = slot.feats_event       # ConfidenceNet(side=True) waits for this, not for the decoder
+                out[1]._cu_grad_slot = slot                     # ... and hands its input gradient back through the slot
         return out
 
 
@@ -321,9 +344,10 @@ class _ConfidenceFn(torch.autograd.Function):
     ``cu_hip.ops.pending_add`` / ``pending_wait`` (see there for who waits)."""
 
     @staticmethod
-    def forward(ctx, module: "ConfidenceNet", ready, feats: Tensor, *params: Tensor):
+    def forward(ctx, module: "ConfidenceNet", ready, slot, feats: Tensor, *params: Tensor):
         P = dict(zip(module._pnames, params))
         ctx.side = None
+        ctx.slot = slot
         if ready is not None:
             side = module._side_stream(feats.device)
             side.wait_event(ready)
@@ -346,8 +370,15 @@ class _ConfidenceFn(torch.autograd.Function):
         params = ctx.saved_tensors
         P = dict(zip(module._pnames, params))
         total = sum(p.numel() for p in params)
-        # side mode only when the bottleneck gradient is wanted: the U-Net's backward then waits for it where it needs it
-        side = ctx.side if (ctx.need_in and not torch.cuda.is_current_stream_capturing()) else None
+        # side mode only when the bottleneck gradient is wanted (the U-Net's backward then waits for it where it needs it) AND
+        # nothing autograd does with the results on the MAIN stream can read them early: the parameter gradients
+        # are only stashed when every ``p.grad`` is None (an existing ``p.grad`` -- gradient accumulation,
+        # zero_grad(set_to_none=False), GradSync's deferred mode -- makes AccumulateGrad run ``p.grad += G`` at once), and
+        # the input gradient goes through the producer's GradSlot with a stride-0 stand-in inside autograd
+        slot = ctx.slot
+        side = ctx.side if (ctx.need_in and slot is not None and slot.feats_grad is None
+                            and all(p.grad is None for p in module._params())
+                            and not torch.cuda.is_current_stream_capturing()) else None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(gout.device))
             gout.record_stream(side)
@@ -365,7 +396,10 @@ class _ConfidenceFn(torch.autograd.Function):
                 done.record(side)
                 _ops.pending_add(done)
         ctx.ectx = None
-        return (None, None, gin) + tuple(G[n] for n in module._pnames)
+        if side is not None:
+            slot.feats_grad = gin
+            gin = torch.zeros((), dtype=gin.dtype, device=gin.device).expand(gin.shape)
+        return (None, None, None, gin) + tuple(G[n] for n in module._pnames)
 
 
 class ConfidenceNet(nn.Module):
@@ -405,9 +439,13 @@ class ConfidenceNet(nn.Module):
 
     def _params(self):
         pl = getattr(self, "_plist", None)
+        if pl is not None and [id(p) for m in self._holders for p in m._parameters.values()] != self._plist_probe:
+            pl = None         # a Parameter object was replaced without _apply (load_state_dict(assign=True), ...): ADVICE r3
         if pl is None:
             named = dict(self.named_parameters())
             pl = self._plist = [named[n] for n in self._pnames]
+            self._holders = [m for m in self.modules() if m._parameters]
+            self._plist_probe = [id(p) for m in self._holders for p in m._parameters.values()]
         return pl
 
     def _ensure_flat(self) -> bool:
@@ -433,10 +471,11 @@ class ConfidenceNet(nn.Module):
         moved = self._ensure_flat()
         params = self._params()
         ready = getattr(x, "_cu_ready_event", None)
+        slot = getattr(x, "_cu_grad_slot", None)
         # the side stream runs behind `ready` only, i.e. behind what the current stream held when the bottleneck was produced:
         # parameters written later than that (re-homed just now) are not ordered before it -> this call stays on the current stream
         if moved or not (side and self.side_enabled and torch.is_grad_enabled() and x.dtype == torch.float32
                          and not torch.cuda.is_current_stream_capturing()):
             ready = None
         with _lib.device_guard(x):
-            return _ConfidenceFn.apply(self, ready, x.float(), *params)
+            return _ConfidenceFn.apply(self, ready, slot if ready is not None else None, x.float(), *params)

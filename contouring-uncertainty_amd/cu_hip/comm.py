@@ -30,10 +30,19 @@ class NativeComm:
         self.stream = torch.cuda.Stream(device=device)
         self.algo = algo or os.environ.get("CONTOUR_COMM_ALGO", "rs_ag")
         assert self.algo in ("rs_ag", "allreduce"), self.algo
-        self._fin = weakref.finalize(self, NativeComm._destroy, handle)      # never leak the RCCL communicator
+        # never leak the RCCL communicator; the finalizer drains what is still queued first, as close() does (a
+        # GradSync dropped, or a process exiting, with collectives in flight must not tear the communicator down under them)
+        self._fin = weakref.finalize(self, NativeComm._destroy, handle, self.stream, device)
 
     @staticmethod
-    def _destroy(handle):
+    def _destroy(handle, stream=None, device=None):
+        try:
+            if stream is not None:
+                stream.synchronize()
+            if device is not None:
+                torch.cuda.synchronize(device)
+        except Exception:      # noqa: BLE001 -- interpreter shutdown / a dead context: still release the communicator
+            pass
         try:
             L.load().cu_comm_destroy(handle)
         except Exception:      # noqa: BLE001 -- interpreter shutdown

@@ -166,6 +166,9 @@ class UNetEngine:
         self.drop_p = 0.5
         self.drop_mask_fn: Optional[Callable[[str, int, int, torch.device], Tensor]] = None   # tests inject masks
         self.debug: Optional[Dict[str, Tensor]] = None    # tests/tools: set to {} to capture per-layer gradients (NHWC)
+        # tests: keep the last forward's context in ``_last_ctx`` (every layer's raw output, statistics and activation) WITHOUT
+        # changing which kernels run -- ``debug`` switches the fused first layer / head / small-map paths off, this does not
+        self.keep_ctx = False
         self._prep_state = None     # (pointer key, item table, blocks, names) of the batched operand preparation
         self._dwk_ws = None                         # partial-tile scratch of the weight gradients (two buffers)
         self._red: Optional[torch.cuda.Stream] = None      # stream of the partial tiles' sums / un-preparations
@@ -367,7 +370,7 @@ class UNetEngine:
         assert img.dtype == torch.float32 and img.is_cuda and img.shape[1] == 1
         img = img.contiguous()
         ctx = UNetCtx(img=img, training=training, keep=keep or self.debug is not None)
-        if self.debug is not None:
+        if self.debug is not None or self.keep_ctx:
             self._last_ctx = ctx
         st = self.strides
         fused_head = fused_head and keep and self.head_fusable(img.shape[0], img.shape[2], img.shape[3])
@@ -512,6 +515,10 @@ class UNetEngine:
         """kernel-layout dWk -> logical gradient, layer by layer (measured in round 1: one batched launch at the end of the
         backward made the un-preparation itself 0.5 ms cheaper and the step 0.8 ms slower: cold accumulators)."""
         ops.grad_unprep(dwk, grad, kind, accumulate=True, clear=True)
+        if self.grad_ready_hook is not None and self._red is not None and dwk.is_cuda:
+            # the bucket this report may complete also holds the conv-weight gradients of the layers before it, whose slab
+            # sums run on the reduction stream: the stream the collective is ordered behind must cover both (ADVICE r3)
+            torch.cuda.current_stream(dwk.device).wait_stream(self._red)
         self._ready(prefix)
 
     def _conv_layer_bwd(self, P, G, ctx: UNetCtx, prefix: str, g: Tensor,
@@ -744,6 +751,8 @@ class UNetEngine:
             if i == 0:
                 if dfeats is not None:
                     ops.pending_wait()       # the skew head's backward may have produced dfeats on its own stream
+                    if callable(dfeats):     # ... and then hands it over lazily (unet2._UNetFn.backward)
+                        dfeats = dfeats()
                     d_bott = ops.nchw_f32_to_nhwc(dfeats.contiguous(), dt)
                 accum = 1 if d_bott is not None else 0
                 d_in = d_bott if d_bott is not None else torch.empty_like(up.src.z)

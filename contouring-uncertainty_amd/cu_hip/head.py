@@ -30,7 +30,7 @@ class GradSlot:
     gradient -- ``torch.autograd.grad(loss, logits)``, ``logits.retain_grad()``, a tensor hook on the logits: those see the
     zero stand-in.  ``dsnt_nll(..., dense_grad=True)`` (or ``slot.enabled = False``) selects the dense NCHW float32
     gradient for such uses."""
-    __slots__ = ("dtype", "dl", "enabled", "fused", "head", "head_grads", "feats_event")
+    __slots__ = ("dtype", "dl", "enabled", "fused", "head", "head_grads", "feats_event", "feats_grad")
 
     def __init__(self, dtype):
         self.dtype = dtype
@@ -42,6 +42,13 @@ class GradSlot:
         self.head: Optional[dict] = None
         self.head_grads: Optional[tuple] = None
         self.feats_event = None      # recorded when the bottleneck features of the same forward exist
+        # dL/d(bottleneck features) left by a consumer that ran its backward on a stream of its own (ConfidenceNet side mode):
+        # readable only behind ops.pending_wait(); autograd carries a stride-0 zero stand-in meanwhile
+        self.feats_grad: Optional[Tensor] = None
+
+    def take_feats(self) -> Optional[Tensor]:
+        g, self.feats_grad = self.feats_grad, None
+        return g
 
     def put_head(self, aux: Tensor, gmu: Tensor, gsigma: Tensor, covar: bool):
         if not covar:

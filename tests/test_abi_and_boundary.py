@@ -279,3 +279,22 @@ def test_synthetic_datamodule_contract():
     dm2 = SyntheticContourDataModule(size=64, batch_size=2, n_train=5, n_val=3)
     dm2.setup("fit")
     assert torch.equal(dm2.datasets["val"][1]["img"], dm.datasets["val"][1]["img"])
+
+
+def test_parameter_list_cache_follows_replaced_parameters():
+    """``UNet._params()`` / ``ConfidenceNet._params()`` cache the Parameter objects; replacing one without
+    ``_apply`` (``load_state_dict(assign=True)``, ``conv.weight = nn.Parameter(...)``) must be noticed on the next call."""
+    import torch
+    from contour_uncertainty.models.nnUnet.unet2 import ConfidenceNet, UNet
+    net = UNet((1, 64, 64), (21, 1, 64), [256, 256], [[3, 3]] * 4, [[1, 1]] + [[2, 2]] * 3)
+    first = net._params()[0][0]
+    assert net._params()[0][0] is first
+    net.input_block.conv1.conv.weight = torch.nn.Parameter(torch.zeros_like(net.input_block.conv1.conv.weight))
+    assert net._params()[0][0] is net.input_block.conv1.conv.weight and net._params()[0][0] is not first
+    net.load_state_dict({k: v.clone() for k, v in net.state_dict().items()}, assign=True)
+    named = dict(net.named_parameters())
+    assert all(p is named[n] for p, n in zip(net._params()[0], net._pnames))
+    head = ConfidenceNet(42)
+    head._params()
+    head.load_state_dict({k: v.clone() for k, v in head.state_dict().items()}, assign=True)
+    assert head._params()[0] is head.model[0].weight

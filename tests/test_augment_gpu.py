@@ -71,3 +71,21 @@ def test_datamodule_hook_augments_training_batches_on_the_device():
     assert not torch.equal(out["img"].cpu(), batch["img"]) and not torch.allclose(out["contour"].cpu(), batch["contour"])
     moved = (out["contour"].cpu() - batch["contour"]).abs().max()
     assert float(moved) < 5 + 64 * 0.06 + 1            # +-5 px translation, +-3 degrees about the centre
+
+
+def test_datamodule_hook_leaves_validation_batches_alone():
+    """The reference augments its TRAINING subset only (data/camus/datamodule.py:46-55).  Lightning calls
+    ``on_after_batch_transfer`` for every stage; outside training (``trainer.training`` False) the batch must come back
+    untouched."""
+    from types import SimpleNamespace
+    from contour_uncertainty.data.synthetic import SyntheticContourDataModule
+    dm = SyntheticContourDataModule(size=64, batch_size=4, n_train=4, n_val=4, da=True)
+    dm.setup("fit")
+    batch = next(iter(dm.val_dataloader()))
+    dev_batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    dm.trainer = SimpleNamespace(training=False)
+    out = dm.on_after_batch_transfer(dev_batch, 0)
+    assert out is dev_batch
+    dm.trainer = SimpleNamespace(training=True)
+    out = dm.on_after_batch_transfer(dev_batch, 0)
+    assert not torch.equal(out["img"], dev_batch["img"])

@@ -13,7 +13,7 @@ BAND = 0.75       # nats: |NLL_bf16 - NLL_f32| from step 5 to step 20.  Start 6.
                   # mode's f32 atomics amplified by 20 Adam steps, on the LOW side of f32 more often than not
 
 
-def _run(dtype):
+def _run(dtype, deterministic=False):
     from bench import build_task
     from contour_uncertainty.data.synthetic import synthetic_batch
     from contour_uncertainty.data.synthetic.weights import seeded_confidence_state, seeded_unet_state
@@ -22,6 +22,9 @@ def _run(dtype):
     task.model.load_state_dict(seeded_unet_state(task.model, gen), strict=True)
     task.skew_block.load_state_dict(seeded_confidence_state(task.skew_block, gen), strict=True)
     task = task.to(DEV)
+    if deterministic:        # what CONTOUR_DETERMINISTIC=1 sets: every f32 sum of the step in a fixed order
+        task.model.engine.deterministic = True
+        task.skew_block.engine.deterministic = True
     img, contour = synthetic_batch(2, 64, 21, seed=1234)
     batch = {"img": img.to(DEV), "contour": contour.to(DEV)}
     opt = task.configure_optimizers()["optimizer"]
@@ -47,3 +50,19 @@ def test_bf16_nll_tracks_f32_over_twenty_adam_steps():
     # the trajectories stay together, not only the end points.  Step 2 is a transient of Adam's first updates (loss 11 ... 45
     # in f32 and bf16 alike, different from run to run: a kink-amplified overshoot that is gone by step 4) and is skipped.
     assert max(abs(a - b) for a, b in list(zip(f32, bf16))[5:]) < BAND
+
+
+DET_BAND = 0.1    # nats; measured: profiles/r04_bf16_spread.txt
+
+
+def test_bf16_nll_tracks_f32_in_deterministic_mode():
+    """The same 20 Adam steps with every f32 sum of the step in a fixed order on both sides (``engine.deterministic``): the runs
+    are then bit-reproducible, so what separates bf16 from f32 is bf16 storage alone -- no atomics-order noise for the
+    network to amplify.  This is the check that the wide default-mode band above is noise and not a bias of the bf16 path;
+    which build switch contributes what to the default mode's spread: tools/bf16_spread.py -> profiles/r04_bf16_spread.txt."""
+    f32, bf16, bf16b = _run("f32", True), _run("bf16", True), _run("bf16", True)
+    assert bf16 == bf16b                                           # bit-identical trajectories run to run
+    assert abs(f32[0] - bf16[0]) < 2e-3 * abs(f32[0])
+    assert f32[-1] < f32[0] - 0.5 and bf16[-1] < bf16[0] - 0.5
+    assert abs(bf16[-1] - f32[-1]) < DET_BAND, (f32[-1], bf16[-1])
+    assert max(abs(a - b) for a, b in list(zip(f32, bf16))[5:]) < DET_BAND, list(zip(f32, bf16))

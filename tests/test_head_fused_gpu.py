@@ -73,6 +73,74 @@ def test_fused_head_forward(n, size, k, peak):
     assert float((aux0[..., 2:7] - aux1[..., 2:7]).abs().max()) < 1e-5
 
 
+def test_fused_head_forward_vs_oracle_head_full_size():
+    """the fused forward against oracle/head.py (the restatement of flat_softmax / dsnt / pixel rescale /
+    get_cov_matrix that tests/test_oracle_golden.py pins to the reference) at the headline map size, N = 4: the oracle is fed
+    the float64 logits of the very bf16 activation and bf16 weights the kernel multiplies."""
+    from oracle import head as OH
+    n, size, k = 4, 256, 21
+    ops, act, w, w_cls, w_ch = _setup(n, size, k, seed=11, peak=12.0)
+    mu1, sg1, _ = ops.head_fused_fwd(ops.Act(act.z, act.stats, SLOPE), w_cls, k, True)
+    torch.cuda.synchronize()
+    logits = torch.einsum("nhwc,kc->nkhw", act.a.double().cpu(), w_cls.view(32, 32)[:k].double().cpu())
+    assert float(logits.amax() - logits.amin()) > 20.0          # peaked maps, not near-uniform ones
+    mu, sigma = OH.head_moments(logits, True)                   # (N, K, 2), (N, K, 2, 2) in pixels
+    sg = torch.stack([sigma[..., 0, 0], sigma[..., 1, 1], sigma[..., 0, 1]], -1)
+    e_mu = float((mu1.double().cpu() - mu).abs().max()) / size
+    e_sg = float(((sg1.double().cpu() - sg).abs() / sg.abs().amax(-1, keepdim=True)).max())
+    assert e_mu < 1e-4 and e_sg < 1e-4, (e_mu, e_sg)
+
+
+@pytest.mark.parametrize("size", [64, 256])
+def test_fused_head_vs_reference_golden_logits(golden_dir, size):
+    """The fused kernels on the reference's OWN golden logits (tests/golden/dsnt_head.npz, written by the imported reference):
+    identity statistics, slope 1 and a 0/1 selection matrix as the 1x1 weights make the kernel's logits equal the bf16-rounded
+    golden logits, so forward (mu, Sigma) and backward (dL/dlogits = the kernel's g with W = I) are compared with oracle/head.py
+    + autograd on exactly those logits; the un-rounded golden outputs bound the rounding itself."""
+    import numpy as np
+    from cu_hip import ops
+    from oracle import head as OH
+    g = np.load(golden_dir / "dsnt_head.npz")
+    lg = torch.from_numpy(g[f"s{size}_logits"])                 # (N, K, H, W) f32
+    n, k = lg.shape[:2]
+    z = torch.zeros(n, size, size, 32, dtype=torch.bfloat16)
+    z[..., :k] = lg.permute(0, 2, 3, 1).to(torch.bfloat16)
+    z = z.to(DEV)
+    stats = torch.zeros(4, n, 32, device=DEV)
+    stats[1] = 1.0
+    stats[2] = 1.0                                              # a = LeakyReLU_1(z * 1 + 0) = z
+    w = torch.zeros(k, 32, 1, 1, device=DEV)
+    w[torch.arange(k), torch.arange(k)] = 1.0
+    w_cls, w_ch = ops.weight_prep(w, "conv", torch.bfloat16, 32)
+    act = ops.Act(z, stats, 1.0)
+    mu1, sg1, aux1 = ops.head_fused_fwd(act, w_cls, k, True)
+    lr = z[..., :k].permute(0, 3, 1, 2).double().cpu().requires_grad_(True)     # the logits the kernel really sees
+    mu, sigma = OH.head_moments(lr, True)
+    sg = torch.stack([sigma[..., 0, 0], sigma[..., 1, 1], sigma[..., 0, 1]], -1)
+    assert float((mu1.double().cpu() - mu.detach()).abs().max()) / size < 1e-4
+    assert float(((sg1.double().cpu() - sg.detach()).abs() / sg.detach().abs().amax(-1, keepdim=True)).max()) < 1e-4
+    # (the reference's own outputs on the UN-rounded logits: bf16 rounding of the logits moves mu by < 0.05 px here)
+    assert float((mu1.cpu() - torch.from_numpy(g[f"s{size}_pixel"])).abs().max()) < 5e-2
+    gen = torch.Generator().manual_seed(size)
+    gmu = torch.randn(n, k, 2, generator=gen) * 0.1
+    gsg = torch.randn(n, k, 3, generator=gen) * 0.01
+    ((mu * gmu.double()).sum() + (sg * gsg.double()).sum()).backward()
+    sums = torch.zeros(n, 32, 2, device=DEV)
+    parts = torch.empty(1025 * 1024, device=DEV)
+    g_fu, slabs = ops.head_fused_bwd(act, w_cls, w_ch, k, aux1, gmu.to(DEV), gsg.to(DEV), True, sums, parts)
+    torch.cuda.synchronize()
+    dl = g_fu[..., :k].permute(0, 3, 1, 2).double().cpu()
+    ref = lr.grad
+    scale = float(ref.abs().max())
+    err = (dl - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -7 + 2e-5 * scale).all()), float(err.max() / scale)       # bf16 storage of dl and g
+    assert float(g_fu[..., k:].abs().max()) == 0.0
+    # sums of the InstanceNorm backward with these statistics: sum(g), sum(g * z); dW = dl^T a = dl^T z
+    gf = g_fu.float()
+    s_ref = torch.stack([gf.sum((1, 2)), (gf * z.float()).sum((1, 2))], -1)
+    assert float((sums - s_ref).abs().max()) <= 1e-2 * float(s_ref.abs().max()) + 1e-6
+
+
 def test_fused_head_forward_far_reference():
     """the first pixel of a tile far below / above the rest: the moving reference logit (threshold 40) is exercised"""
     ops, act, w, w_cls, w_ch = _setup(2, 64, 21, seed=7, peak=60.0)
@@ -254,3 +322,52 @@ def test_fused_head_backward_when_the_loss_ignores_the_landmarks():
     assert all(torch.isfinite(g).all() for g in grads.values())
     assert float(grads["output_block.conv.weight"].abs().max()) == 0.0
     assert float(grads["bottleneck.conv2.conv.weight"].abs().max()) > 0.0
+
+
+def test_skew_head_side_stream_with_gradient_accumulation():
+    """with ``p.grad`` already present (gradient accumulation, zero_grad(set_to_none=False)) autograd ADDS the skew
+    head's fresh gradients into it at once, on the main stream -- the head's backward must then not be running on its side
+    stream.  Two micro-batches accumulated with the side mode on equal the same accumulation with it off (and both equal the
+    sum of the two single-batch gradients); a dense second consumer of the bottleneck is summed in as well."""
+    from contour_uncertainty.data.synthetic import synthetic_batch
+    torch.manual_seed(0)
+    task = _task()
+    batches = []
+    for seed in (3, 4):
+        img, contour = synthetic_batch(4, 64, 21, seed=seed)
+        batches.append({"img": img.to(DEV), "contour": contour.to(DEV)})
+    task.training_step(batches[0], 0)["loss"].backward()           # first call: parameters re-homed, no side stream yet
+    names = [n for n, _ in task.named_parameters() if n.startswith("skew_block") or n.startswith("model.bottleneck.conv2.conv.w")]
+
+    def grads(side, accumulate, extra=False):
+        task.skew_block.side_enabled = side
+        task.zero_grad(set_to_none=True)
+        total = None
+        for b in batches:
+            if not accumulate:
+                task.zero_grad(set_to_none=True)
+            with task.model.fused_head():
+                hm, feats = task.model(b["img"])
+            alpha = task._alpha(hm, feats, side=True)
+            from cu_hip.head import dsnt_nll
+            logs, _, _ = dsnt_nll(hm, b["contour"], alpha, True)
+            loss = logs["loss"] + (feats.square().mean() if extra else 0.0)      # extra: a second, dense consumer of feats
+            loss.backward()
+            if not accumulate:
+                torch.cuda.synchronize()
+                cur = {n: p.grad.detach().clone() for n, p in task.named_parameters() if n in names}
+                total = cur if total is None else {n: total[n] + cur[n] for n in cur}
+        torch.cuda.synchronize()
+        return total if not accumulate else {n: p.grad.detach().clone() for n, p in task.named_parameters() if n in names}
+
+    for extra in (False, True):
+        ref = grads(False, False, extra)             # sum of single-batch gradients, everything on one stream
+        floor = max(float((grads(False, False, extra)[n] - ref[n]).norm() / ref[n].norm()) for n in names)
+        for side in (True, False):
+            acc = grads(side, True, extra)
+            for n in names:
+                err = float((acc[n] - ref[n]).norm() / ref[n].norm())
+                assert err <= max(2e-3, 3 * floor), (extra, side, n, err, floor)
+        one = grads(True, False, extra)              # side mode really on (p.grad None before every backward)
+        for n in names:
+            assert float((one[n] - ref[n]).norm() / ref[n].norm()) <= max(2e-3, 3 * floor), (extra, n)

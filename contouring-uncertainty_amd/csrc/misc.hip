@@ -674,6 +674,99 @@ __global__ __launch_bounds__(256) void parts_finish_kernel(const float* __restri
         if (n0 + e < CO) o[(size_t)e * CI] = acc[e];
 }
 
+// One launch instead of parts_finish_kernel + grad_unprep_rows_kernel (round 4: 73 launches per step less): a workgroup owns
+// an 8 x 32 block of (slow channel, fast channel) of the LOGICAL gradient with all its NT taps, adds the S slabs of exactly
+// those elements in slab order (the same fixed summation order as before: bit-identical sums) and writes the logical rows
+// through LDS like grad_unprep_rows_kernel.
+//   NATIVE (conv layouts: rows = co): in the accumulators' layout an 8 (co) x 32 (ci) block of one tap is ONE contiguous
+//     1-KiB run -- pieces (q, lane = 32 h + r) = rows 8q + 4h .. + 3 of the 32-row wave block, column r -- so a wave reads a
+//     slab's share of a tap with one 16-byte load per lane;
+//   plain slabs [T][COP][CI] (gemm_tn.hip, the fused head): element loads, 128-byte rows (conv) or 32-byte runs (transposed).
+template <int NT, bool NATIVE>
+__global__ __launch_bounds__(256) void parts_sum_unprep_kernel(const float* __restrict__ parts, size_t stride, int S,
+                                                               float* __restrict__ g, int CO, int CI, int COP, long s_co,
+                                                               long s_ci, int NBLK, int CBLK, int ctiles, int accumulate) {
+    __shared__ float tile[8 * (32 * UNPREP_MAXT + 1)];
+    constexpr int pitch = 32 * NT + 1;
+    const bool co_rows = s_co > s_ci;
+    const int r0 = blockIdx.y * 8, c0 = blockIdx.x * 32;
+    const int RN = co_rows ? CO : CI, CN = co_rows ? CI : CO;
+    if constexpr (NATIVE) {          // co_rows only (checked by the host): rows = co, columns = ci
+        const int nt_ = r0 / (32 * NBLK), nblk = (r0 >> 5) % NBLK, q = (r0 & 31) >> 3;
+        const int ct = c0 / (32 * CBLK), cblk = (c0 >> 5) % CBLK;
+        const size_t blk = (size_t)(nt_ * ctiles + ct) * (NBLK * CBLK) + (nblk * CBLK + cblk);
+        for (int pidx = threadIdx.x; pidx < NT * 64; pidx += 256) {
+            const int t = pidx >> 6, lane = pidx & 63;
+            const int n0 = r0 + 4 * (lane >> 5), c = c0 + (lane & 31);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (n0 < COP && c < CI) {            // regions of inactive waves are never written: never read either
+                const f32x4* base = reinterpret_cast<const f32x4*>(parts) + (((blk * NT + t) * 4 + q) * 64 + lane);
+                acc = base[0];
+#pragma unroll 8
+                for (int s = 1; s < S; ++s) {
+                    const f32x4 v = base[(size_t)s * (stride / 4)];
+                    acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[(4 * (lane >> 5) + e) * pitch + (lane & 31) * NT + t] = acc[e];
+        }
+    } else {
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        const int r = r0 + ty, c = c0 + tx;
+        const int co = co_rows ? r : c, ci = co_rows ? c : r;
+        const bool ok = r < RN && c < CN;
+        const float* src = parts + (size_t)co * CI + ci;
+        const size_t tstride = (size_t)COP * CI;
+        float v[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) v[t] = ok ? src[t * tstride] : 0.f;
+        for (int s = 1; s < S; ++s) {
+            float w[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) w[t] = ok ? src[(size_t)s * stride + t * tstride] : 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] += w[t];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) tile[ty * pitch + tx * NT + t] = v[t];
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long s_r = co_rows ? s_co : s_ci;
+    const int cvalid = min(32, CN - c0) * NT;
+    if (r0 + ty < RN) {
+        float* dst = g + (size_t)(r0 + ty) * s_r + (size_t)c0 * NT;
+        if (accumulate & 1) {
+            float o[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) o[i] = (tx + 32 * i < cvalid) ? dst[tx + 32 * i] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                if (tx + 32 * i < cvalid) dst[tx + 32 * i] = o[i] + tile[ty * pitch + tx + 32 * i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                if (tx + 32 * i < cvalid) dst[tx + 32 * i] = tile[ty * pitch + tx + 32 * i];
+        }
+    }
+}
+
+template <bool NATIVE>
+static bool launch_sum_unprep(int T, const float* parts, size_t stride, int S, float* grad, int CO, int CI, int COP, long s_co,
+                              long s_ci, int NBLK, int CBLK, int ctiles, int accumulate, hipStream_t st) {
+    const bool co_rows = s_co > s_ci;
+    dim3 grid(cdiv(co_rows ? CI : CO, 32), cdiv(co_rows ? CO : CI, 8));
+#define CU_SUM_UNPREP(NT_) hipLaunchKernelGGL((parts_sum_unprep_kernel<NT_, NATIVE>), grid, dim3(256), 0, st, parts, stride, S, \
+                                              grad, CO, CI, COP, s_co, s_ci, NBLK, CBLK, ctiles, accumulate)
+    if (T == 9) CU_SUM_UNPREP(9);
+    else if (T == 4) CU_SUM_UNPREP(4);
+    else if (T == 1) CU_SUM_UNPREP(1);
+    else return false;
+#undef CU_SUM_UNPREP
+    return true;
+}
+
 // ---- batched form: the operand copies of every conv layer of the network in ONE launch ---------------------------------
 __device__ __forceinline__ const cu_prep_item* find_item(const cu_prep_item* items, int n, int blk) {
     int i = 0;
@@ -1079,6 +1172,22 @@ extern "C" int cu_grad_unprep_parts(int T, int CO, int CI, int COP, long s_co, l
         const size_t E = (size_t)T * COP * CI;
         CU_CHECK_ARG(E % 4 == 0 && parts_floats >= (size_t)nparts * E, "cu_grad_unprep_parts: workspace of %zu floats < %d slabs of %zu", parts_floats, nparts, E);
         const unsigned gx = (unsigned)((E / 4 + 255) / 256);
+        const bool rows_ok = (s_co > s_ci) ? s_ci == T : s_co == T;        // taps innermost in the logical layout
+        if (rows_ok && (T == 9 || T == 4 || T == 1)) {
+            // first level (many slabs of a small tile: sums of G consecutive slabs by the whole chip), then ONE launch that adds
+            // the group sums in order and writes the logical rows (before: strided sum + un-preparation, two launches)
+            size_t stride = E;
+            if (nparts > 16) {
+                const int G = cdiv(nparts, 16), groups = cdiv(nparts, G);
+                hipLaunchKernelGGL(parts_reduce_kernel, dim3(gx, groups), dim3(256), 0, st, parts, E / 4, nparts, G);
+                CU_LAUNCH_CHECK();
+                nparts = groups;
+                stride = (size_t)G * E;
+            }
+            launch_sum_unprep<false>(T, parts, stride, nparts, grad, CO, CI, COP, s_co, s_ci, 1, 1, 1, accumulate & 1, st);
+            CU_LAUNCH_CHECK();
+            return 0;
+        }
         if (nparts > 16) {
             const int G = cdiv(nparts, 16), groups = cdiv(nparts, G);
             hipLaunchKernelGGL(parts_reduce_kernel, dim3(gx, groups), dim3(256), 0, st, parts, E / 4, nparts, G);
@@ -1105,6 +1214,12 @@ extern "C" int cu_grad_unprep_parts(int T, int CO, int CI, int COP, long s_co, l
         CU_LAUNCH_CHECK();
         nparts = groups;
         stride4 = (size_t)G * (E / 4);
+    }
+    if (s_co > s_ci && s_ci == T && (T == 9 || T == 4 || T == 1)) {
+        // conv layouts (rows = co, taps innermost): slab sums + un-preparation in ONE launch straight from the native slabs
+        launch_sum_unprep<true>(T, parts, stride4 * 4, nparts, grad, CO, CI, COP, s_co, s_ci, NBLK, CBLK, ctiles, accumulate & 1, st);
+        CU_LAUNCH_CHECK();
+        return 0;
     }
     float* sum = parts + parts_floats - plain;         // the plain tile lives at the END of the workspace
     hipLaunchKernelGGL(parts_finish_kernel, dim3(gx), dim3(256), 0, st, (const float*)parts, E / 4, stride4, nparts, sum, T, COP,

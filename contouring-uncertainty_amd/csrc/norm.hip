@@ -186,10 +186,22 @@ __global__ void stats_finalize_given_kernel(const float* __restrict__ sums, cons
 // materialise a = LeakyReLU(z*scale + shift) (one streaming pass): the MFMA kernels then stage plain operands.
 // Measured on MI355X: re-doing this affine + activation inside every consumer's operand load made the thin-channel
 // convolutions VALU-bound (40-50 % of their time); one extra 2-byte write + read per element is far cheaper.
-template <typename T>
+// GIVEN (round 4): the statistics are finalised HERE from sums a convolution epilogue gathered -- the arithmetic of
+// stats_finalize_given_kernel, expression for expression, so the values are bit-identical to the two-launch form -- and the
+// first pixel chunk of every image stores them for the backward: one launch per layer less (18 per step).
+struct GivenSums {
+    const float* sums;     // [N][C][2] = {sum, sum of squares} of (z - shift[c])
+    const float* shift;    // conv bias or NULL
+    const float* gamma;
+    const float* beta;
+    float eps;
+    float* stats_out;      // [4][N][C]
+};
+
+template <typename T, bool GIVEN = false>
 __global__ __launch_bounds__(NT) void apply_kernel(const T* __restrict__ z, const float* __restrict__ stats, float slope,
                                                    T* __restrict__ out, int N, int HW, int C, int tpp, int rows,
-                                                   int chunk) {
+                                                   int chunk, GivenSums gs = GivenSums()) {
     constexpr int PIECE = Elem<T>::PIECE;
     const int n = blockIdx.x;
     const int p0 = blockIdx.y * chunk, p1 = min(HW, p0 + chunk);
@@ -198,8 +210,31 @@ __global__ __launch_bounds__(NT) void apply_kernel(const T* __restrict__ z, cons
     const size_t NC = (size_t)N * C;
     const size_t sidx = (size_t)n * C + piece * PIECE;
     float sc[PIECE], sh[PIECE];
+    if constexpr (GIVEN) {
+        const float inv = 1.f / (float)HW;
+        const bool keep = blockIdx.y == 0 && prow == 0;
 #pragma unroll
-    for (int e = 0; e < PIECE; ++e) { sc[e] = stats[2 * NC + sidx + e]; sh[e] = stats[3 * NC + sidx + e]; }
+        for (int e = 0; e < PIECE; ++e) {
+            const size_t i = sidx + e;
+            const int c = piece * PIECE + e;
+            const float m1 = gs.sums[2 * i] * inv, m2 = gs.sums[2 * i + 1] * inv;
+            const float mean = (gs.shift ? gs.shift[c] : 0.f) + m1;
+            const float var = fmaxf(m2 - m1 * m1, 0.f);
+            const float rstd = 1.f / sqrtf(var + gs.eps);
+            const float g = gs.gamma ? gs.gamma[c] : 1.f, b = gs.beta ? gs.beta[c] : 0.f;
+            sc[e] = g * rstd;
+            sh[e] = b - mean * g * rstd;
+            if (keep) {
+                gs.stats_out[i] = mean;
+                gs.stats_out[NC + i] = rstd;
+                gs.stats_out[2 * NC + i] = sc[e];
+                gs.stats_out[3 * NC + i] = sh[e];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) { sc[e] = stats[2 * NC + sidx + e]; sh[e] = stats[3 * NC + sidx + e]; }
+    }
     const size_t base = (size_t)n * HW * C + piece * PIECE;
     int p = p0 + prow;
     for (; p + 3 * rows < p1; p += 4 * rows) {
@@ -1040,8 +1075,8 @@ static int launch_apply(int nimg, int N, int HW, int C, const void* z, const flo
     const RowMap rm = row_map(C, Elem<T>::PIECE);
     int nchunks = 1;
     const int chunk = pick_chunk(nimg, HW, rm.rows, &nchunks);
-    hipLaunchKernelGGL(apply_kernel<T>, dim3(nimg, nchunks), dim3(NT), 0, st, (const T*)z, stats, slope, (T*)out, N, HW, C,
-                       rm.tpp, rm.rows, chunk);
+    hipLaunchKernelGGL((apply_kernel<T, false>), dim3(nimg, nchunks), dim3(NT), 0, st, (const T*)z, stats, slope, (T*)out, N, HW,
+                       C, rm.tpp, rm.rows, chunk, GivenSums());
     CU_LAUNCH_CHECK();
     return 0;
 }
@@ -1194,14 +1229,24 @@ extern "C" int cu_instnorm_fwd_given(int dtype, int N, int HW, int C, const void
                                      void* stream) {
     NORM_COMMON_CHECKS("cu_instnorm_fwd_given");
     CU_CHECK_ARG(z && stats && sums, "cu_instnorm_fwd_given: null pointer");      // out == NULL: statistics only
-    hipLaunchKernelGGL(stats_finalize_given_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, st, sums, shift, gamma, beta, eps,
-                       stats, N, HW, C);
     if (!out) {
+        hipLaunchKernelGGL(stats_finalize_given_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, st, sums, shift, gamma, beta, eps,
+                           stats, N, HW, C);
         CU_LAUNCH_CHECK();
         return 0;
     }
-    return dtype == CU_BF16 ? launch_apply<bf16_t>(N, N, HW, C, z, stats, slope, out, st)
-                            : launch_apply<float>(N, N, HW, C, z, stats, slope, out, st);
+    // statistics finalised inside the apply pass (every workgroup from the sums; chunk 0 of an image stores them)
+    GivenSums gs;
+    gs.sums = sums; gs.shift = shift; gs.gamma = gamma; gs.beta = beta; gs.eps = eps; gs.stats_out = stats;
+    dim3 grid(N, nchunks);
+    if (dtype == CU_BF16)
+        hipLaunchKernelGGL((apply_kernel<bf16_t, true>), grid, dim3(NT), 0, st, (const bf16_t*)z, (const float*)nullptr, slope,
+                           (bf16_t*)out, N, HW, C, rm.tpp, rm.rows, chunk, gs);
+    else
+        hipLaunchKernelGGL((apply_kernel<float, true>), grid, dim3(NT), 0, st, (const float*)z, (const float*)nullptr, slope,
+                           (float*)out, N, HW, C, rm.tpp, rm.rows, chunk, gs);
+    CU_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int cu_instnorm_bwd_given(int dtype, int N, int HW, int C, void* g, const void* z, const float* stats,

@@ -141,15 +141,19 @@ except ImportError:
         def log(self, name, value, **_kw):
             self.logged[name] = value
 
-        # checkpoints in Lightning's layout: {"state_dict": ..., "hyper_parameters": ...}
-        def save_checkpoint(self, path):
-            hp = {k: v for k, v in self._hparams.items() if k != "task"}
-            torch.save({"state_dict": self.state_dict(), "hyper_parameters": hp}, str(path))
+        # checkpoints in Lightning 1.8's layout (contour_uncertainty/utils/checkpoint.py): state_dict, hyper_parameters,
+        # optimizer_states, epoch, global_step, ...
+        def save_checkpoint(self, path, optimizer=None, epoch: int = 0, global_step: int = 0):
+            from contour_uncertainty.utils.checkpoint import lightning_checkpoint
+            ckpt = lightning_checkpoint(self, optimizer, epoch, global_step)
+            ckpt["hyper_parameters"] = {k: v for k, v in self._hparams.items() if k != "task"}   # live objects: same-process reload
+            torch.save(ckpt, str(path))
 
         @classmethod
         def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict: bool = True, **overrides):
-            ckpt = torch.load(str(checkpoint_path), map_location=map_location or "cpu", weights_only=False)
-            hp = dict(ckpt.get("hyper_parameters", {}))
+            from contour_uncertainty.utils.checkpoint import load_lightning_checkpoint
+            ckpt = load_lightning_checkpoint(checkpoint_path, map_location or "cpu")
+            hp = dict(ckpt.get("hyper_parameters") or {})
             hp.pop("task", None)
             hp.update(overrides)
             obj = cls(**hp)
@@ -351,10 +355,11 @@ class Trainer:
         model.on_fit_start()
         self._call("on_fit_start", model)
         optimizer = model.configure_optimizers()["optimizer"]
+        self._model, self._optimizer = model, optimizer
         epochs = 1 if self.fast_dev_run else self.max_epochs
         done = False
         for epoch in range(epochs):
-            model.current_epoch = epoch
+            model.current_epoch = self.current_epoch = epoch
             model.train()
             self.training = True
             for idx, batch in self._mine(datamodule.train_dataloader()):
@@ -422,10 +427,13 @@ class Trainer:
         return results
 
     def save_checkpoint(self, path):
+        """Lightning-layout checkpoint (weights, hyper-parameters, optimizer state, epoch / global_step) from rank 0"""
         if self.rank == 0 and self._model is not None:
-            self._model.save_checkpoint(path)
+            self._model.save_checkpoint(path, optimizer=self._optimizer, epoch=getattr(self, "current_epoch", 0),
+                                        global_step=self.global_step)
 
     _model = None
+    _optimizer = None
 
 
 def _slim(res):

@@ -585,6 +585,7 @@ __device__ __forceinline__ void tile_stats(const f32x16 (&acc)[MA][NB], const bo
         if (img < imgs && n < N && n0 + col < CO) unsafeAtomicAdd(sums + ((size_t)n * CO + n0 + col) * 2 + (rem & 1), t);
     }
 }
+constexpr int RING_MF16_DEFAULT = 0;   // round 4 A/B: profiles/r04_mf16_ring.txt
 constexpr int DMA_MAXX = 9;           // halo items per thread: halo_px * 4 <= 512 * 9 (stride-2 gathers: 17 x 65 pixels)
 // MA = 32-pixel blocks per wave (tile = 256 * MA pixels): 2 for stride-1 gathers, 1 for stride-2 gathers, whose halo patch
 // is four times larger per pixel.
@@ -811,7 +812,15 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_kernel(const ConvKArgs
 // MFMAs (3.4 us) in series.  A tap row of 64 columns is 12 KiB: two staging rounds per tap row (taps 0, 1 | tap 2 + padding),
 // five DMA instructions per thread and iteration instead of six.  NXR = staging rounds of the halo image (5: one image of
 // 16 x 32 pixels; 6: two images of 16 x 16).
-template <int NB, int NXR>
+//
+// MF16 (round 4): the same tile on v_mfma_f32_16x16x32_bf16 -- one MFMA takes the whole 32-channel chunk of a
+// 16-pixel x 16-column sub-block (four per 32 x 32 block: the same MFMA cycles and the same twelve 16-byte fragment reads per
+// tap as the 32x32x16 form, but the chip holds a higher clock on this shape: MI355X_MICROARCH.md, DVFS give-back item 7).
+// Lane l reads LDS row (l & 15) of its sub-block and k-group q = l >> 4; on the SAME swizzled images the four k-groups take the
+// logical 16-byte pieces {0, 3, 1, 2} (for the weights and the pixels alike, so the contraction is unchanged): with that
+// assignment every one of ds_read_b128's four hardware lane groups ({0-3, 12-15, 20-27}, ...) touches all 64 banks once.
+// C/D: lane = pixel (l & 15), registers = columns 4 q .. 4 q + 3 -> 8-byte epilogue stores (16-byte ones in the 32x32 form).
+template <int NB, int NXR, bool MF16 = false>
 __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_ring_kernel(const ConvKArgs p, unsigned src0_bytes,
                                                                      unsigned src1_bytes, unsigned w_bytes) {
     constexpr int MA = 2, BN = 32 * NB, CK = 32;
@@ -864,13 +873,35 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_ring_kernel(const Conv
     }
     const int wsw = (r >> 2) & 3;
 
-    f32x16 acc[MA][NB];
+    f32x16 acc[MF16 ? 1 : MA][MF16 ? 1 : NB];
+    if constexpr (!MF16) {
 #pragma unroll
-    for (int a = 0; a < MA; ++a)
+        for (int a = 0; a < MA; ++a)
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    }
+    // MF16: sub-block (a, ph) = pixels a * 32 + ph * 16 + (lane & 15) of the wave's 64; (b, ch) = columns b * 32 + ch * 16 + ...
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int kpiece = kq == 0 ? 0 : (kq == 1 ? 3 : (kq == 2 ? 1 : 2));
+    const int wlane16 = (l15 * 4 + (kpiece ^ ((l15 >> 2) & 3))) * 8;      // element offset of this lane's piece in a weight row block
+    int hp16[MA][2];
+    f32x4 acc16[MF16 ? MA : 1][2][MF16 ? NB : 1][2];
+    if constexpr (MF16) {
+#pragma unroll
+        for (int a = 0; a < MA; ++a)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const int m = wave * 32 * MA + a * 32 + ph * 16 + l15;
+                const int tx = m & (TW - 1), ty = (m >> p.twl) & (TH - 1), im = m >> (p.twl + p.thl);
+                hp16[a][ph] = im < p.imgs ? im * hpi + ty * p.HW + tx : 0;
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) acc16[a][ph][b][ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
 
     const int nch = CI / CK;
     // rounds [j0, j1) of chunk c's halo image into image c & 1; rounds beyond the image / chunks beyond the last go,
@@ -914,6 +945,40 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_ring_kernel(const Conv
         constexpr int g = decltype(G)::value;
         const bf16_t* X16 = reinterpret_cast<const bf16_t*>(smem + (size_t)(c & 1) * XB);
         const bf16_t* W16 = reinterpret_cast<const bf16_t*>(smem + 2 * (size_t)XB + (size_t)g * WSLOT);
+        if constexpr (MF16) {
+#pragma unroll
+            for (int tl = 0; tl < 3; ++tl) {
+                bf16x8 xf[MA][2];
+#pragma unroll
+                for (int a = 0; a < MA; ++a)
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph) {
+                        // (opaque per iteration: hoisted out of the chunk loop, the 36 row addresses of a chunk spilled the tile)
+                        int hb = hp16[a][ph];
+                        asm volatile("" : "+v"(hb));
+                        const int row = hb + p.tap_off[3 * g + tl];
+                        xf[a][ph] = *reinterpret_cast<const bf16x8*>(X16 + ((size_t)row * 4 + (kpiece ^ ((row >> 2) & 3))) * 8);
+                    }
+                // one 32-column block at a time: 4 pixel + 2 weight fragments live (all 8 weight fragments of a 128-column tile
+                // at once spilled: profiles/r04_mf16_ring_v1_all_fragments_live.txt, 1.9x slower).  Weight rows: the swizzle of row
+                // (tap, column block, 16 ch + l15) is ((l15 >> 2) & 3) whatever the block: one lane base + immediate offsets
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    bf16x8 wf[2];
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch)
+                        wf[ch] = *reinterpret_cast<const bf16x8*>(W16 + wlane16 + (size_t)(tl * BN + b * 32 + ch * 16) * 32);
+#pragma unroll
+                    for (int a = 0; a < MA; ++a)
+#pragma unroll
+                        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                            for (int ch = 0; ch < 2; ++ch)
+                                acc16[a][ph][b][ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ch], xf[a][ph], acc16[a][ph][b][ch], 0, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int tl = 0; tl < 3; ++tl) {
             int xrow[MA], xsw[MA];
@@ -972,6 +1037,52 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_ring_kernel(const Conv
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing out-of-range DMA instructions target this LDS
 
+    if constexpr (MF16) {      // lane = pixel (l & 15) of a sub-block, registers = 4 consecutive columns: 8-byte stores
+#pragma unroll
+        for (int a = 0; a < MA; ++a)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const int m = wave * 32 * MA + a * 32 + ph * 16 + l15;       // (the pixel geometry is recomputed here: kept live
+                const int im = m >> (p.twl + p.thl);                          //  through the main loop it spilled the 128-column tile)
+                const int n = img0 + im;
+                const int py = py0 + ((m >> p.twl) & (TH - 1)), px = px0 + (m & (TW - 1));
+                const bool pvalid = !(im >= p.imgs || n >= p.N || py >= p.PH || px >= p.PW);
+                const size_t opix = pvalid ? ((size_t)n * p.OH + py) * p.OW + px : 0;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const int colb = n0 + b * 32;
+                    if (colb >= p.CO) continue;                       // uniform
+                    const bool d1 = colb >= p.D0;
+                    const int accum = d1 ? p.accum1 : p.accum0;
+                    const int DC = d1 ? p.DC1 : p.DC0;
+                    bf16_t* dstp = reinterpret_cast<bf16_t*>(d1 ? p.dst1 : p.dst0);
+                    if (!pvalid) continue;
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        const int col = colb + ch * 16 + 4 * kq;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc16[a][ph][b][ch][e];
+                        if (p.bias) {
+                            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                        }
+                        bf16_t* o = dstp + opix * DC + (d1 ? col - p.D0 : col);
+                        if (accum) {
+                            const u32x2 old = *reinterpret_cast<const u32x2*>(o);
+                            v[0] += __uint_as_float(old[0] << 16); v[1] += __uint_as_float(old[0] & 0xffff0000u);
+                            v[2] += __uint_as_float(old[1] << 16); v[3] += __uint_as_float(old[1] & 0xffff0000u);
+                        }
+                        u32x2 pk;
+                        pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                        pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<u32x2*>(o) = pk;
+                    }
+                }
+            }
+        return;
+    }
     // ---- epilogue (as igemm_conv_dma_kernel)
 #pragma unroll
     for (int a = 0; a < MA; ++a) {
@@ -1040,7 +1151,7 @@ __global__ __launch_bounds__(64 * DW) void igemm_conv_dma_ring_kernel(const Conv
             }
         }
     }
-    if (p.stat_sums) {
+    if constexpr (!MF16) if (p.stat_sums) {
         bool valid[MA];
 #pragma unroll
         for (int a = 0; a < MA; ++a) valid[a] = pim[a] < p.imgs;
@@ -1413,8 +1524,11 @@ extern "C" int cu_conv_gemm_ex(const cu_conv_desc* d, const void* src0, const fl
                 if ((ring4 || ring2) && !cu_env_set("CU_CONV_NORING")) {
                     // two halo images, three tap rows (3 / 2 staging rounds each), dump
                     const size_t rl = (size_t)2 * nxr * 8192 + (size_t)3 * (ring4 ? 3 : 2) * 8192 + 8192;
-                    auto kr = ring4 ? igemm_conv_dma_ring_kernel<4, 5>
-                                    : (nxr == 5 ? igemm_conv_dma_ring_kernel<2, 5> : igemm_conv_dma_ring_kernel<2, 6>);
+                    // MF16: the 16x16x32 MFMA form (no epilogue statistics); CU_CONV_MF16 = 0 / 1 forces it off / on in the tuning build
+                    const bool mf16 = !a.stat_sums && cu_env_int("CU_CONV_MF16", RING_MF16_DEFAULT) != 0;
+                    auto kr = ring4 ? (mf16 ? igemm_conv_dma_ring_kernel<4, 5, true> : igemm_conv_dma_ring_kernel<4, 5, false>)
+                                    : (nxr == 5 ? (mf16 ? igemm_conv_dma_ring_kernel<2, 5, true> : igemm_conv_dma_ring_kernel<2, 5, false>)
+                                                : (mf16 ? igemm_conv_dma_ring_kernel<2, 6, true> : igemm_conv_dma_ring_kernel<2, 6, false>));
                     hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kr),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);
                     CU_CHECK_ARG(er == hipSuccess, "cu_conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(er));

@@ -96,7 +96,9 @@ __device__ __forceinline__ Row low_bits(int n) {      // bits [0, n)
 
 __global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, const float* __restrict__ contours,
                                                           int round_landmarks, int mode, unsigned* __restrict__ packed,
-                                                          unsigned char* __restrict__ bytes, int dbg) {
+                                                          unsigned char* __restrict__ bytes, int dbg,
+                                                          int* __restrict__ area_out = nullptr,
+                                                          float* __restrict__ length_out = nullptr) {
     __shared__ unsigned bmA[MT * 8];        // the drawn curve, then the reached background (rows)
     __shared__ unsigned bmB[MT * 8];        // transposed bitmaps
     __shared__ double px[MAXK], py[MAXK], u[MAXK], t[MAXK + 4], cx[MAXK], cy[MAXK];
@@ -189,6 +191,39 @@ __global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, c
         if (i < K) { cx[i] = solx; cy[i] = soly; }
     }
     __syncthreads();
+
+    // ---- clinical measure (cu_contour_measures): length of the open polyline through contour_spline's 1001 points
+    // (reference utils/clinical.py:31-72 `perimeter` / `global_longitudinal_strain`; utils/contour.py:9-25: n = 1001, the raw
+    // landmarks when splprep raises), summed in f64; per-thread partial sums combined in thread order (deterministic)
+    if (length_out) {
+        __shared__ double lpart[MT];
+        double acc = 0.0;
+        auto point = [&](int q, double& sx, double& sy) {
+            const double x = (double)q * (1.0 / 1000.0);
+            double N[4];
+            const int j = basis(q == 1000 ? 1.0 : x, N);
+            sx = N[0] * cx[j] + N[1] * cx[j + 1] + N[2] * cx[j + 2] + N[3] * cx[j + 3];
+            sy = N[0] * cy[j] + N[1] * cy[j + 1] + N[2] * cy[j + 2] + N[3] * cy[j + 3];
+        };
+        if (!fallback) {
+            for (int q = tid; q < 1000; q += MT) {
+                double ax, ay, bx, by;
+                point(q, ax, ay);
+                point(q + 1, bx, by);
+                acc += sqrt((bx - ax) * (bx - ax) + (by - ay) * (by - ay));
+            }
+        } else if (tid < K - 1) {
+            acc = sqrt((px[tid + 1] - px[tid]) * (px[tid + 1] - px[tid]) + (py[tid + 1] - py[tid]) * (py[tid + 1] - py[tid]));
+        }
+        lpart[tid] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int i = 0; i < MT; ++i) tot += lpart[i];
+            length_out[m] = (float)tot;
+        }
+        if (!packed && !bytes && !area_out) return;
+    }
 
     // ---- draw: 1000 spline points (or the raw landmarks), upper clip, negative indices wrap once like numpy
     auto plot = [&](int ix, int iy, bool wrap) {
@@ -286,6 +321,16 @@ __global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, c
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = bmA[tid * 8 + i];
         }
+    }
+    if (area_out) {          // pixels of the filled mask = EchoMeasure.structure_area of the LV label (reference utils/clinical.py:88-89)
+        const Row mk{{~reach.w[0] & wmask.w[0], ~reach.w[1] & wmask.w[1], ~reach.w[2] & wmask.w[2], ~reach.w[3] & wmask.w[3]}};
+        int cnt = tid < H ? (__popcll(mk.w[0]) + __popcll(mk.w[1]) + __popcll(mk.w[2]) + __popcll(mk.w[3])) : 0;
+        for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        __syncthreads();
+        int* cpart = reinterpret_cast<int*>(bmB);
+        if ((tid & 63) == 0) cpart[tid >> 6] = cnt;
+        __syncthreads();
+        if (tid == 0) area_out[m] = cpart[0] + cpart[1] + cpart[2] + cpart[3];
     }
     if (bytes) {
         __syncthreads();
@@ -395,6 +440,16 @@ extern "C" int cu_contour_masks(int M, int K, int H, int W, const float* contour
     static const int dbg = cu_env_int("CU_MASKS_DBG", 0);      // timing aid (tools/masks_bench.py)
     hipLaunchKernelGGL(contour_mask_kernel, dim3(M), dim3(MT), 0, reinterpret_cast<hipStream_t>(stream), K, H, W, contours,
                        round_landmarks, mode, packed, bytes, dbg);
+    CU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cu_contour_measures(int M, int K, int H, int W, const float* contours, int round_landmarks, int* area,
+                                   float* length, void* stream) {
+    CU_CHECK_ARG(M > 0 && K >= 2 && K <= MAXK && H > 0 && H <= MT && W > 0 && W <= MT, "cu_contour_measures: bad sizes M=%d K=%d H=%d W=%d", M, K, H, W);
+    CU_CHECK_ARG(contours && (area || length), "cu_contour_measures: null pointer");
+    hipLaunchKernelGGL(contour_mask_kernel, dim3(M), dim3(MT), 0, reinterpret_cast<hipStream_t>(stream), K, H, W, contours,
+                       round_landmarks, 0, (unsigned*)nullptr, (unsigned char*)nullptr, 0, area, length);
     CU_LAUNCH_CHECK();
     return 0;
 }

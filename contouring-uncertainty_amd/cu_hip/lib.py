@@ -101,6 +101,7 @@ _SIGS = {
                                      C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, C.c_uint64, _P, _P]),
     "cu_psm_condition": (C.c_int, [C.c_int] * 3 + [_P, C.c_int, _P, C.c_int] + [_P] * 10),
     "cu_contour_masks": (C.c_int, [C.c_int] * 4 + [_P, C.c_int, C.c_int, _P, _P, _P]),
+    "cu_contour_measures": (C.c_int, [C.c_int] * 4 + [_P, C.c_int, _P, _P, _P]),
     "cu_mask_last_value": (C.c_int, [C.c_int] * 3 + [_P] * 4),
     "cu_mask_entropy": (C.c_int, [C.c_int] * 4 + [_P] * 4),
     "cu_mask_weighted_entropy": (C.c_int, [C.c_int] * 4 + [_P] * 5),

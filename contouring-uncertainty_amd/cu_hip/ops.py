@@ -837,6 +837,21 @@ def contour_masks(contours: Tensor, height: int, width: int, round_landmarks: bo
     return pk, by
 
 
+def contour_measures(contours: Tensor, height: int, width: int, round_landmarks: bool = False, area: bool = True,
+                     length: bool = True):
+    """contours (M, K, 2) f32 (x, y) pixels -> (area (M,) int32 | None, length (M,) f32 | None)  (cu_contour_measures): pixel
+    count of the filled mask ``contour_masks`` would draw, and length of the 1001-point interpolating spline."""
+    m, k, _ = contours.shape
+    contours = contours.contiguous().float()
+    dev = contours.device
+    ar = torch.empty((m,), dtype=torch.int32, device=dev) if area else None
+    ln = torch.empty((m,), dtype=torch.float32, device=dev) if length else None
+    with _Prof("masks"):
+        L.check(L.load().cu_contour_measures(m, k, height, width, L.ptr(contours), int(round_landmarks), L.ptr(ar), L.ptr(ln),
+                                             L.stream_ptr()), "cu_contour_measures")
+    return ar, ln
+
+
 def mask_entropy(packed: Tensor, frames: int, width: int, mean: bool = True, entropy: bool = True):
     """packed (F*S, H, 8) int32, frame-major -> (mean (F, H, W) f32 | None, entropy (F, H, W) f32 | None)  (cu_mask_entropy)."""
     ms, h, _ = packed.shape

@@ -435,6 +435,15 @@ int cu_skew_rvs(int M, int S, const float* mu, const float* sigma, const float* 
  * ---------------------------------------------------------------------------------------------------------------- */
 int cu_contour_masks(int M, int K, int H, int W, const float* contours, int round_landmarks, int mode, uint32_t* packed,
                      uint8_t* bytes, void* stream);
+/* Clinical measures of M contours in ONE launch (reference contour_uncertainty/utils/clinical.py:11-89):
+ *   area [M] int32   = pixels of the filled mask cu_contour_masks(mode 0) draws = EchoMeasure.structure_area(mask, LV)
+ *                      (`lv_area`, reference vital/vital/utils/image/measure.py:21-40), the operand of lv_FAC / compute_FAC;
+ *   length [M] float = length of the open polyline through contour_spline(contour, n = 1001) (reference utils/contour.py:9-25),
+ *                      the operand of `perimeter` / `global_longitudinal_strain` / `compute_gls`; the raw landmark polyline
+ *                      when the spline fit fails (duplicate consecutive landmarks, K < 4), like the reference's `except`.
+ * Either output may be NULL.  Same limits as cu_contour_masks (K <= 32, H, W <= 256). */
+int cu_contour_measures(int M, int K, int H, int W, const float* contours, int round_landmarks, int32_t* area, float* length,
+                        void* stream);
 int cu_mask_entropy(int F, int S, int H, int W, const uint32_t* packed, float* mean, float* entropy, void* stream);
 /* Weighted form for the skew-normal uncertainty map (reference contour_uncertainty/utils/skew_umap.py:74-79): mean =
  * sum_s weights[s] * mask_s (weights [S], normalised by the caller), entropy = natural-log binary entropy of the mean. */

@@ -486,13 +486,71 @@ def gen_vital_unet():
     np.savez_compressed(OUT / "vital_unet.npz", **out)
 
 
+def gen_ckpt():
+    """A Lightning-1.8-layout checkpoint of the REFERENCE's module structure.
+
+    The reference tasks hold ``self.model = UNet(...)`` and, for dsnt-skew, ``self.skew_block = model.confidence_net(2K)``
+    (reference task/regression/dsnt/dsnt_skew.py:34); Lightning itself is not importable here, so the LightningModule shell is
+    a plain ``nn.Module`` with those two attributes -- the reference's own ``UNet`` / ``ConfidenceNet`` classes inside, hence
+    the reference's ``state_dict`` names, order and shapes -- stepped once with ``torch.optim.Adam`` (reference
+    vital/vital/config/task/optim/adam.yaml).  Written:
+      * ref_ckpt_tiny.ckpt      2-stage dsnt-al task (109 k parameters): the real file, state_dict + optimizer_states;
+      * ref_ckpt_structure.json names / shapes / dtypes of the 8-stage dsnt-skew task's state_dict and the layout of its Adam
+        state (too large to commit as tensors)."""
+    import json
+    from contour_uncertainty.models.nnUnet.unet2 import UNet
+
+    class Shell(torch.nn.Module):
+        def __init__(self, n_stages, skew):
+            super().__init__()
+            self.model = UNet((1, 0, 0), (21, 0, 0), [256, 256], [[3, 3]] * n_stages, [[1, 1]] + [[2, 2]] * (n_stages - 1),
+                              bottleneck_out=skew)
+            if skew:
+                self.skew_block = self.model.confidence_net(42)
+
+    def one_step(shell, size):
+        opt = torch.optim.Adam(shell.parameters(), lr=1e-3, weight_decay=1e-3)
+        x = torch.rand(2, 1, size, size, generator=torch.Generator().manual_seed(3))
+        out = shell.model(x)
+        loss = out[0].square().mean() + (shell.skew_block(out[1]).square().mean() if hasattr(shell, "skew_block") else 0.0) \
+            if isinstance(out, tuple) else out.square().mean()
+        loss.backward()
+        opt.step()
+        return opt
+
+    torch.manual_seed(5)
+    tiny = Shell(2, False)
+    opt = one_step(tiny, 16)
+    ckpt = {"epoch": 3, "global_step": 17, "pytorch-lightning_version": "1.8.0", "state_dict": tiny.state_dict(), "loops": {},
+            "callbacks": {}, "optimizer_states": [opt.state_dict()], "lr_schedulers": [], "hparams_name": "kwargs",
+            "hyper_parameters": {"covar": True, "mse_weight": 1, "log_penalty_weight": 1, "t_a": 25, "t_e": 1}}
+    torch.save(ckpt, str(OUT / "ref_ckpt_tiny.ckpt"))
+    x = torch.rand(1, 1, 16, 16, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        np.savez_compressed(OUT / "ref_ckpt_tiny_io.npz", x=npy(x), logits=npy(tiny.model(x)))
+    torch.manual_seed(6)
+    full = Shell(8, True)
+    opt = one_step(full, 256)
+    osd = opt.state_dict()
+    structure = {
+        "state_dict": [[k, list(v.shape), str(v.dtype)] for k, v in full.state_dict().items()],
+        "optimizer_param_groups": [{k: (v if k != "params" else len(v)) for k, v in g.items()} for g in osd["param_groups"]],
+        "optimizer_state_keys": sorted({k for st in osd["state"].values() for k in st}),
+        "optimizer_state_count": len(osd["state"]),           # parameters that received a gradient
+        "optimizer_state_ids": sorted(int(k) for k in osd["state"]),
+        "parameter_order": [n for n, _ in full.named_parameters()],
+        "step_dtype": str(next(iter(osd["state"].values()))["step"].dtype),
+    }
+    (OUT / "ref_ckpt_structure.json").write_text(json.dumps(structure, indent=0))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dsnt", "nll", "unet_small", "unet_full", "step", "psm", "skew_grid", "umap", "drop", "skew_mode",
-                             "vital_unet"]
+                             "vital_unet", "ckpt"]
     for w in which:
         print("generating", w, flush=True)
         {"dsnt": gen_dsnt, "nll": gen_nll, "unet_small": gen_unet_small, "unet_full": gen_unet_full,
          "step": gen_step, "psm": gen_psm, "skew_grid": gen_skew_grid, "umap": gen_umap, "drop": gen_drop, "skew_mode": gen_skew_mode,
-         "vital_unet": gen_vital_unet}[w]()
+         "vital_unet": gen_vital_unet, "ckpt": gen_ckpt}[w]()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)

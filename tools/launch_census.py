@@ -57,7 +57,7 @@ def main():
     for ev in prof.events():
         if ev.device_type != torch.autograd.DeviceType.CPU or not ev.name.startswith("aten::"):
             continue
-        if not any(k.device_type == torch.autograd.DeviceType.CUDA for k in getattr(ev, "kernels", [])):
+        if not getattr(ev, "kernels", []):
             continue
         if ev.cpu_children and any(c.name.startswith("aten::") and getattr(c, "kernels", []) for c in ev.cpu_children):
             continue

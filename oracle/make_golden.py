@@ -544,13 +544,26 @@ def gen_ckpt():
     (OUT / "ref_ckpt_structure.json").write_text(json.dumps(structure, indent=0))
 
 
+def gen_clinical():
+    """aleatoric / epistemic split of a Monte-Carlo metric (reference results/clinical/utils.py: importable, NumPy only)"""
+    from contour_uncertainty.results.clinical.utils import aleatoric_epistemic_uncertainty
+    rng = np.random.default_rng(12)
+    out = {}
+    for i, (te, ta, nan_frac) in enumerate(((1, 25, 0.0), (5, 40, 0.1), (3, 1024, 0.02))):
+        mc = rng.normal(0.45, 0.08, size=(te, ta))
+        mc[rng.random(mc.shape) < nan_frac] = np.nan
+        out[f"mc{i}"] = mc
+        out[f"res{i}"] = np.array(aleatoric_epistemic_uncertainty(mc), dtype=np.float64)
+    np.savez_compressed(OUT / "clinical.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dsnt", "nll", "unet_small", "unet_full", "step", "psm", "skew_grid", "umap", "drop", "skew_mode",
-                             "vital_unet", "ckpt"]
+                             "vital_unet", "ckpt", "clinical"]
     for w in which:
         print("generating", w, flush=True)
         {"dsnt": gen_dsnt, "nll": gen_nll, "unet_small": gen_unet_small, "unet_full": gen_unet_full,
          "step": gen_step, "psm": gen_psm, "skew_grid": gen_skew_grid, "umap": gen_umap, "drop": gen_drop, "skew_mode": gen_skew_mode,
-         "vital_unet": gen_vital_unet, "ckpt": gen_ckpt}[w]()
+         "vital_unet": gen_vital_unet, "ckpt": gen_ckpt, "clinical": gen_clinical}[w]()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)

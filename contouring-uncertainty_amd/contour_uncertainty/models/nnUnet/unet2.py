@@ -109,7 +109,7 @@ class _UNetFn(torch.autograd.Function):
             # autograd is a stride-0 zero tensor of their shape that only cu_hip.head.dsnt_nll knows how to read
             slot.head = ectx.head
             n, _, h, w_ = x.shape
-            logits = torch.zeros((), dtype=torch.float32, device=x.device).expand(n, module.num_classes, h, w_)
+            logits = _ops.zero_placeholder((n, module.num_classes, h, w_), torch.float32, x.device)
         elif slot is not None:
             slot.fused = False
         if module.bottleneck_out:
@@ -398,7 +398,7 @@ class _ConfidenceFn(torch.autograd.Function):
         ctx.ectx = None
         if side is not None:
             slot.feats_grad = gin
-            gin = torch.zeros((), dtype=gin.dtype, device=gin.device).expand(gin.shape)
+            gin = _ops.zero_placeholder(gin.shape, gin.dtype, gin.device)
         return (None, None, None, gin) + tuple(G[n] for n in module._pnames)
 
 

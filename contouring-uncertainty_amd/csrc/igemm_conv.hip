@@ -1348,8 +1348,13 @@ __global__ __launch_bounds__(256) void ksplit_finish_norm_kernel(const float* __
         if (pl == 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (ep.dbeta) unsafeAtomicAdd(ep.dbeta + c + e, s[2 * e]);
-                if (ep.dgamma) unsafeAtomicAdd(ep.dgamma + c + e, s[2 * e + 1]);
+                if (ep.mode == 5) {      // per-image planes [N][C], sole writer: plain stores (cu_norm_param_grads_batch adds the images)
+                    if (ep.dbeta) ep.dbeta[si + e] = s[2 * e];
+                    if (ep.dgamma) ep.dgamma[si + e] = s[2 * e + 1];
+                } else {
+                    if (ep.dbeta) unsafeAtomicAdd(ep.dbeta + c + e, s[2 * e]);
+                    if (ep.dgamma) unsafeAtomicAdd(ep.dgamma + c + e, s[2 * e + 1]);
+                }
             }
         }
 #pragma unroll
@@ -1669,7 +1674,7 @@ extern "C" int cu_conv_gemm_ex(const cu_conv_desc* d, const void* src0, const fl
         fin1 = d->D0 == d->CO ? 0 : (size_t)d->N * d->OH * d->OW * d->DC1;
         // a fused norm finish (epilogue modes 3 / 4) is worth a two-way split of its own on 8x8 maps (480 workgroups): the
         // finish pass replaces a norm launch instead of adding one
-        const bool norm_fin = ep && stats_done && (ep->mode == 3 || ep->mode == 4) && d->OH * d->OW <= 64 &&
+        const bool norm_fin = ep && stats_done && (ep->mode == 3 || ep->mode == 4 || ep->mode == 5) && d->OH * d->OW <= 64 &&
                               !cu_env_set("CU_CONV_NO_NORMFIN8");
         const int max_wgs = cu_env_int("CU_CONV_KSPLIT_WGS", 128);
         if (ws && !wres && whole && !d->out_nchw_f32 && nchunks >= 4 && (wgs <= max_wgs || (norm_fin && wgs <= 512)) &&
@@ -1690,7 +1695,7 @@ extern "C" int cu_conv_gemm_ex(const cu_conv_desc* d, const void* src0, const fl
         }
     }
     // modes 3 / 4 of the epilogue: the finish pass of a tiny map also does the layer's InstanceNorm + LeakyReLU
-    const bool fin_norm = ep && stats_done && (ep->mode == 3 || ep->mode == 4) && a.ksplit > 1 && fin1 == 0 &&
+    const bool fin_norm = ep && stats_done && (ep->mode == 3 || ep->mode == 4 || ep->mode == 5) && a.ksplit > 1 && fin1 == 0 &&
                           d->OH * d->OW <= 64 && d->DC0 % 32 == 0 && ep->stats &&
                           (ep->mode == 3 ? (ep->act_out && !d->accum0) : (ep->z != nullptr));
     auto finish = [&]() -> int {

@@ -369,6 +369,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgKArgs p) {
 //     [4 pieces]: 64-byte rows, so the 4 rows of a transpose read fall on 4 distinct bank quarters without padding or
 //     swizzle, and a wave's block (cblk / nblk) simply selects its plane.
 constexpr int DMA_IMG_BYTES = 78 * 1024;      // per image; two of them per workgroup
+constexpr int WGRAD_TWO_DEFAULT = 0;          // round 4 A/B: profiles/r04_wgrad_two_per_cu.txt
 
 // NW = 8 waves: two waves per SIMD own the SAME 32x32 block and split the k-steps; while one is blocked issuing its
 // DMA instructions (the queue drains at L2 speed, ~4 us per tile) the other keeps the MFMA pipe busy.  The k-split
@@ -381,7 +382,10 @@ constexpr int DMA_IMG_BYTES = 78 * 1024;      // per image; two of them per work
 // shift planes [N][C0], slope0) is applied to the staged source image IN PLACE in LDS, once per staged element, between the
 // barrier that publishes the tile and a second one that hands it to the k-loop.  The image's scale / shift rows arrive by one
 // more LDS-DMA instruction per tile (1-KiB table beside each image); out-of-image halo pixels stay zero.  One image per tile.
-template <int NBLK, int CBLK, int NTAPS, int NW, bool PC = false, bool ROWK = false, bool XF = false>
+// IMGB = bytes of one LDS image.  The default fills the CU with ONE workgroup; the thin layers (32-row dW blocks at 256^2 / 128^2,
+// HBM-bound) also have a half-size form with four waves -- IMGB = 39 KiB, 170 VGPRs -- of which TWO workgroups share a CU: one
+// stages (its waves blocked in the LDS-DMA queue) while the other runs its k-loop (round 4).
+template <int NBLK, int CBLK, int NTAPS, int NW, bool PC = false, bool ROWK = false, bool XF = false, int IMGB = DMA_IMG_BYTES>
 __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs p) {
     constexpr int TN = 32 * NBLK, TC = 32 * CBLK;
     constexpr int NWC = PC ? NW / 2 : NW;              // waves that compute
@@ -389,10 +393,10 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     constexpr int NWB = NBLK * CBLK, KSPLIT = NWC / NWB;
     constexpr int NTHR = 64 * NWI, BLK_B = NTHR * 16;  // issuing threads; bytes of one staging round
     constexpr int ROW_B = 64;                          // one pixel of one 32-channel plane
-    __shared__ __attribute__((aligned(16))) unsigned char img2[2 * DMA_IMG_BYTES + (XF ? 3072 : 0)];
+    __shared__ __attribute__((aligned(16))) unsigned char img2[2 * IMGB + (XF ? 3072 : 0)];
     unsigned char* imgA = img2;
-    unsigned char* imgB = img2 + DMA_IMG_BYTES;
-    unsigned char* xtab = img2 + 2 * DMA_IMG_BYTES;     // XF: table of image A, table of image B, dump kilobyte
+    unsigned char* imgB = img2 + IMGB;
+    unsigned char* xtab = img2 + 2 * IMGB;     // XF: table of image A, table of image B, dump kilobyte
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool producer = PC && wave >= NWC, issuer = !PC || producer;
     const int tid = PC ? (threadIdx.x & (NTHR - 1)) : threadIdx.x;      // index among the issuing threads
@@ -721,7 +725,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_wgrad_dma_kernel(const WgKArgs 
     if constexpr (KSPLIT > 1) {
         float* red = reinterpret_cast<float*>(img2);
         constexpr int REG_F = NTAPS * 16 * 64;            // floats of one wave's accumulators
-        static_assert((size_t)(KSPLIT / 2) * NWB * REG_F * 4 <= 2 * (size_t)DMA_IMG_BYTES, "reduction scratch exceeds the images");
+        static_assert((size_t)(KSPLIT / 2) * NWB * REG_F * 4 <= 2 * (size_t)IMGB, "reduction scratch exceeds the images");
 #pragma unroll
         for (int sp = KSPLIT / 2; sp >= 1; sp >>= 1) {
             __syncthreads();
@@ -776,10 +780,11 @@ static int parts_setup(WgKArgs& a, int nblk, int cblk, int ntn, int kparts) {
     return 0;
 }
 
-template <int NBLK, int CBLK, int NTAPS, int NW, bool PC = false, bool ROWK = false, bool XF = false>
+template <int NBLK, int CBLK, int NTAPS, int NW, bool PC = false, bool ROWK = false, bool XF = false, int IMGB = DMA_IMG_BYTES>
 int launch_dma(WgKArgs& a, hipStream_t st) {
-    CU_CHECK_ARG((size_t)(a.s_iters + a.z_iters) * 1024 * (PC ? NW / 2 : NW) <= (size_t)DMA_IMG_BYTES, "cu_conv_wgrad: tile image exceeds %d bytes", DMA_IMG_BYTES);
-    auto k = igemm_wgrad_dma_kernel<NBLK, CBLK, NTAPS, NW, PC, ROWK, XF>;
+    CU_CHECK_ARG((size_t)(a.s_iters + a.z_iters) * 1024 * (PC ? NW / 2 : NW) <= (size_t)IMGB, "cu_conv_wgrad: tile image exceeds %d bytes", IMGB);
+    auto k = igemm_wgrad_dma_kernel<NBLK, CBLK, NTAPS, NW, PC, ROWK, XF, IMGB>;
+    constexpr int PER_CU = IMGB < DMA_IMG_BYTES ? 2 : 1;          // workgroups that share a CU
     const int CI = a.C0 + a.C1;
     a.ctiles = cdiv(CI, 32 * CBLK);
     const int ntn = cdiv(a.CO, 32 * NBLK);
@@ -788,6 +793,7 @@ int launch_dma(WgKArgs& a, hipStream_t st) {
         int want = cdiv(256, a.ctiles * ntn);
         a.splits = want < 1 ? 1 : want;
     }
+    a.splits *= PER_CU;              // (an explicit split count is a count of CUs: cu_hip.engine's cap for the second stream)
     if (a.splits > a.ntiles) a.splits = a.ntiles;
     if (a.nparts_out) {
         const int rc = parts_setup(a, NBLK, CBLK, ntn, 1);
@@ -984,6 +990,24 @@ static int wgrad_impl(const cu_wgrad_desc* d, const void* src0, const float* sca
             const bool rowk = a.twl >= 4;
             if (nb == 4) return rowk ? launch_dma<4, 1, 9, 8, true, true>(a, st) : launch_dma<4, 1, 9, 8, true, false>(a, st);
             return rowk ? launch_dma<2, 1, 9, 8, true, true>(a, st) : launch_dma<2, 1, 9, 8, true, false>(a, st);
+        }
+        // ---- thin layers (32-row dW blocks over >= 2^20 loop pixels: 256^2 x 32 -> 32, 32 + 32 -> 32): two half-size workgroups
+        //      of four waves per CU (see the kernel's IMGB).  CU_WGRAD_TWO = 0 / 1 in the tuning build
+        if (d->ntaps == 9 && d->IS == 1 && d->ZS == 1 && !wn && plain && px_total >= (1l << 20) &&
+            cu_env_int("CU_WGRAD_TWO", WGRAD_TWO_DEFAULT)) {
+            constexpr int HALF = 39 * 1024;
+            for (int BM = 256;; BM >>= 1) {
+                CU_CHECK_ARG(BM >= 16, "cu_conv_wgrad: patches do not fit in LDS");
+                const int rc = geometry(BM);
+                if (rc) return rc;
+                a.s_iters = cdiv(a.s_halo * spp, 256);
+                a.z_iters = cdiv(a.z_halo * zpp, 256);
+                if ((size_t)(a.s_iters + a.z_iters) * 4096 <= (size_t)HALF) break;
+            }
+            a.src0_bytes = (unsigned)b0; a.src1_bytes = (unsigned)b1; a.z_bytes = (unsigned)bz;
+            a.pc_early = a.pc_items = a.s_iters + a.z_iters;
+            if (wc) return launch_dma<1, 2, 9, 4, false, false, false, HALF>(a, st);
+            return launch_dma<1, 1, 9, 4, false, false, false, HALF>(a, st);
         }
         const int issue_w = pc ? 4 : dma_nw;
         for (int BM = (d->IS > 1 || d->ZS > 1) ? 64 : 256;; BM >>= 1) {

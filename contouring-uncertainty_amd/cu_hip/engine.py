@@ -158,6 +158,11 @@ class UNetEngine:
         # fusions: bit-identical gradients run to run, at a fraction of the speed
         self.deterministic = os.environ.get("CONTOUR_DETERMINISTIC", "0") == "1"
         self._det_ws: Optional[Tensor] = None
+        # True: on maps of <= 1024 pixels the norm backward leaves dgamma / dbeta as per-image planes (no same-address atomics:
+        # 17 of 31 us of the 16^2 x 480 launch) and ONE launch at the end of the backward adds the images for every layer
+        self.param_parts = os.environ.get("CONTOUR_PARAM_PARTS", "1") == "1"
+        self._pg_items: list = []
+        self._pg_table = None
         self._given_sums: Dict[str, Tensor] = {}       # layer prefix -> norm-backward sums gathered by the producer of its g
         self._producer: Dict[int, str] = {}            # id(Act) of a layer's output -> its prefix (valid for one step)
         # Dropout2d(p=0.5) between conv and norm in the listed ConvLayers (reference unet2.py:129-136,302: the last
@@ -533,7 +538,7 @@ class UNetEngine:
             # the first layer's whole backward from dL/da: z recomputed from the image, dz never stored (cu_conv_c1_bwd)
             n, oh, ow, co = g.shape
             with self._wgrad_stream(g, ctx.img):
-                sums = torch.zeros((n, co, 2), dtype=torch.float32, device=g.device)
+                sums = self._arena["bwd"].take(2 * n * co, g.device).view(n, co, 2)     # (zeroed with the pass's arena)
                 dw9 = self._dwk((9, co), g.device)
                 ops.conv_c1_bwd(ctx.img, self._opcache[prefix][1], P[f"{prefix}.conv.bias"], rec.out.stats,
                                 P[f"{prefix}.norm.weight"], self.slope, g, sums, dw9, G[f"{prefix}.norm.weight"],
@@ -548,8 +553,13 @@ class UNetEngine:
                                    G[f"{prefix}.norm.bias"], given)
         elif self.fused_norm:
             ws = self._arena["bwd"].take(ops.resident_ws_floats(g.shape[0], g.shape[3]), g.device)
-            ops.instnorm_bwd_fused(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
-                                   G[f"{prefix}.norm.bias"], ws, mode=self._norm_mode())
+            parts = self._pgrad_parts(G, prefix, g.shape[0], g.shape[1] * g.shape[2], g.shape[3], g.device)
+            if parts is not None:
+                ops.instnorm_bwd_fused(g, rec.out, P[f"{prefix}.norm.weight"], parts[0], parts[1], ws,
+                                       mode=self._norm_mode() | ops.NORM_PARAM_PARTS)
+            else:
+                ops.instnorm_bwd_fused(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
+                                       G[f"{prefix}.norm.bias"], ws, mode=self._norm_mode())
         else:
             ops.instnorm_lrelu_bwd(g, rec.out, P[f"{prefix}.norm.weight"], G[f"{prefix}.norm.weight"],
                                    G[f"{prefix}.norm.bias"], None)
@@ -620,6 +630,29 @@ class UNetEngine:
                     ops.conv_gemm([gz], wd, None, grid=(sh // 2, sw // 2), in_stride=1, taps=taps, dsts=dsts,
                                   dst_cols=cols, out_stride=2, out_off=(py, px), accum=acc)
 
+    def _pgrad_parts(self, G, prefix: str, n: int, hw: int, c: int, device):
+        """(dgamma planes, dbeta planes), each (N, C) and zero, for a layer whose norm backward may leave per-image parameter
+        gradients (``ops.norm_param_parts_ok``), registered for the batched sum at the end of the pass; else None."""
+        # (with a gradient exchange attached, a layer's "gradients final" report covers its norm parameters too: they must be
+        #  final when the layer reports, not at the end of the pass)
+        if not self.param_parts or self.deterministic or self.grad_ready_hook is not None or not ops.norm_param_parts_ok(n, hw):
+            return None
+        buf = self._arena["bwd"].take(2 * n * c, device)
+        gp, bp = buf[:n * c], buf[n * c:2 * n * c]
+        self._pg_items.append((gp, bp, G[f"{prefix}.norm.weight"], G[f"{prefix}.norm.bias"], n, c))
+        return gp, bp
+
+    def _pgrad_finish(self, device):
+        """one launch: dgamma / dbeta of every registered layer += sum of its per-image planes"""
+        items, self._pg_items = self._pg_items, []
+        if not items:
+            return
+        key = tuple((a.data_ptr(), b.data_ptr(), g_.data_ptr(), d_.data_ptr(), n, c) for a, b, g_, d_, n, c in items)
+        if self._pg_table is None or self._pg_table[0] != key:
+            table, max_c = ops.pgrad_table(items, device)
+            self._pg_table = (key, table, max_c)
+        ops.norm_param_grads_batch(self._pg_table[1], len(items), self._pg_table[2])
+
     def _small_norm_bwd(self, P, G, ctx: UNetCtx, src: Optional[Act], n: int, hw: int, c: int):
         """(target layer, ``norm_bwd_full`` argument) when the input-gradient launch that differentiates ``src`` may carry
         the norm backward of the layer that produced it (maps of <= 64 pixels), else None."""
@@ -630,7 +663,10 @@ class UNetEngine:
         rec = ctx.convs.get(tgt)
         if rec is None or rec.drop_mask is not None or rec.out.stats is None or rec.first:
             return None
-        return tgt, (rec.out, P[f"{tgt}.norm.weight"], G[f"{tgt}.norm.weight"], G[f"{tgt}.norm.bias"])
+        parts = self._pgrad_parts(G, tgt, n, hw, c, rec.out.z.device)
+        if parts is not None:      # (planes of a launch that does not take the epilogue stay zero: adding them changes nothing)
+            return tgt, (rec.out, P[f"{tgt}.norm.weight"], parts[0], parts[1], True)
+        return tgt, (rec.out, P[f"{tgt}.norm.weight"], G[f"{tgt}.norm.weight"], G[f"{tgt}.norm.bias"], False)
 
     def _convT_bwd(self, P, G, ctx: UNetCtx, rec: _UpRec, du: Tensor, d_in: Tensor, accum: int):
         w = P[f"{rec.prefix}.weight"]
@@ -670,6 +706,7 @@ class UNetEngine:
                 self._side_keep.clear()
                 self._given_sums.clear()
                 self._bwd_done.clear()
+                self._pg_items = []
                 self._dw9_ws = None
                 hook = getattr(self.grad_ready_hook, "__self__", None)
                 if hook is not None and hasattr(hook, "abort"):
@@ -701,6 +738,7 @@ class UNetEngine:
         self._arena["bwd"].begin(last.z.device)
         self._given_sums.clear()
         self._bwd_done.clear()
+        self._pg_items = []
         # the previous backward joined the reduction stream into this one: its "buffer read" events are history (and must not
         # be waited for inside a hipGraph capture, which they precede)
         self._red_done = [None, None]
@@ -775,6 +813,7 @@ class UNetEngine:
         g_c1 = torch.empty_like(c1.out.z)
         self._conv_layer_bwd(P, G, ctx, "input_block.conv2", g, [(g_c1, 0)])
         self._conv_layer_bwd(P, G, ctx, "input_block.conv1", g_c1, None)
+        self._pgrad_finish(g.device)
         self._join_wgrad(g.device)
 
 

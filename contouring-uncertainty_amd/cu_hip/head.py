@@ -111,13 +111,13 @@ class _DsntNllFn(torch.autograd.Function):
             # dL/d(mu, Sigma) go to the UNet's backward, which runs cu_head_fused_bwd (no dL/dlogits anywhere)
             ctx.slot.put_head(aux, (gmu * scale).contiguous(), (gsigma * scale).contiguous(), ctx.covar)
             shape = (gmu.shape[0], gmu.shape[1]) + tuple(ctx.map_hw)
-            dl = torch.zeros((), dtype=torch.float32, device=gmu.device).expand(shape)
+            dl = ops.zero_placeholder(shape, torch.float32, gmu.device)
             return dl, None, ((galpha * scale) if ctx.has_alpha else None), None, None, None, None
         with ops.L.device_guard(logits):
             if ctx.slot is not None:
                 ctx.slot.put(ops.dsnt_head_bwd_nhwc(logits, aux, (gmu * scale).contiguous(), (gsigma * scale).contiguous(),
                                                     ctx.covar, ctx.slot.dtype))
-                dl = torch.zeros((), dtype=logits.dtype, device=logits.device).expand(logits.shape)
+                dl = ops.zero_placeholder(logits.shape, logits.dtype, logits.device)
             else:
                 dl = ops.dsnt_head_bwd(logits, aux, (gmu * scale).contiguous(), (gsigma * scale).contiguous(), ctx.covar)
         dalpha = (galpha * scale) if ctx.has_alpha else None

@@ -92,6 +92,20 @@ def pending_wait():
         _PENDING.clear()
 
 
+_ZERO: Dict[tuple, Tensor] = {}
+
+
+def zero_placeholder(shape, dtype, device) -> Tensor:
+    """A stride-0 all-zero tensor of ``shape``: autograd's stand-in for a gradient that travels through a side channel
+    (``cu_hip.head.GradSlot``).  One cached scalar per (dtype, device): a fresh ``torch.zeros(())`` is a fill launch every time,
+    and the step made three or four of them."""
+    key = (dtype, str(device))
+    z = _ZERO.get(key)
+    if z is None:
+        z = _ZERO[key] = torch.zeros((), dtype=dtype, device=device)
+    return z.expand(shape)
+
+
 def _taps(desc, dys, dxs, ws, zys=None, zxs=None):
     desc.ntaps = len(dys)
     for i, (a, b, c) in enumerate(zip(dys, dxs, ws)):
@@ -197,8 +211,9 @@ def conv_gemm(srcs: Sequence[Act], w: Tensor, bias: Optional[Tensor], *, grid: T
         ep = L.ConvEpilogue(3, None, None, L.ptr(stats), float(slope), L.ptr(gamma), L.ptr(beta), float(eps), L.ptr(a), None,
                             None)
     elif norm_bwd_full is not None:
-        tgt, gamma, dgamma, dbeta = norm_bwd_full
-        ep = L.ConvEpilogue(4, None, L.ptr(tgt.z), L.ptr(tgt.stats), float(tgt.slope), L.ptr(gamma), None, 0.0, None,
+        tgt, gamma, dgamma, dbeta = norm_bwd_full[:4]
+        parts = len(norm_bwd_full) > 4 and norm_bwd_full[4]        # dgamma / dbeta are per-image planes [N][C] (mode 5)
+        ep = L.ConvEpilogue(5 if parts else 4, None, L.ptr(tgt.z), L.ptr(tgt.stats), float(tgt.slope), L.ptr(gamma), None, 0.0, None,
                             L.ptr(dgamma), L.ptr(dbeta))
     with _Prof("igemm_conv", flops, note, nbytes, exec_flops):
         rc = lib.cu_conv_gemm_ex(d, L.ptr(t0), L.ptr(sc0), L.ptr(sh0), L.ptr(t1), L.ptr(sc1), L.ptr(sh1), L.ptr(w),
@@ -374,6 +389,34 @@ def _resident_ws(n: int, c: int, device) -> Tensor:
 
 NORM_WS_CLEAN = 16     # include/contour_hip.h: CU_NORM_WS_CLEAN
 NORM_DETERMINISTIC = 32    # CU_NORM_DETERMINISTIC: one workgroup per image, fixed summation order
+NORM_PARAM_PARTS = 64      # CU_NORM_PARAM_PARTS: dgamma / dbeta are per-image planes [N][C] (maps of <= 1024 pixels)
+
+
+def norm_param_parts_ok(n: int, hw: int) -> bool:
+    """shapes whose backward kernels can leave per-image parameter-gradient planes (cu_instnorm_bwd_fused / epilogue mode 5)"""
+    return hw <= 1024 and n > 1
+
+
+_PGRAD_ITEM = None
+
+
+def pgrad_table(items, device) -> Tuple[Tensor, int]:
+    """items: [(dgamma_parts, dbeta_parts, dgamma, dbeta, N, C)] -> (device table of cu_pgrad_item, max C)"""
+    global _PGRAD_ITEM
+    import numpy as np
+    if _PGRAD_ITEM is None:
+        _PGRAD_ITEM = np.dtype([("gp", "<u8"), ("bp", "<u8"), ("g", "<u8"), ("b", "<u8"), ("N", "<i4"), ("C", "<i4")])
+        assert _PGRAD_ITEM.itemsize == 40
+    arr = np.zeros(len(items), dtype=_PGRAD_ITEM)
+    for i, (gp, bp, g, b, n, c) in enumerate(items):
+        arr[i] = (gp.data_ptr(), bp.data_ptr(), g.data_ptr(), b.data_ptr(), n, c)
+    return torch.from_numpy(arr.view(np.uint8)).to(device), max(it[5] for it in items)
+
+
+def norm_param_grads_batch(table: Tensor, n_items: int, max_c: int):
+    """dgamma[c] += sum_n parts[n][c] for every listed layer in one launch (cu_norm_param_grads_batch)"""
+    with _Prof("instnorm_bwd"):
+        L.check(L.load().cu_norm_param_grads_batch(L.ptr(table), n_items, max_c, L.stream_ptr()), "cu_norm_param_grads_batch")
 
 
 def resident_ws_floats(n: int, c: int) -> int:

@@ -106,6 +106,8 @@ int cu_conv_gemm_stats(const cu_conv_desc* d,
  *                     act_out = LeakyReLU(z*scale + shift) (dst0's layout and type).  gamma / beta / eps / slope given.
  *   mode 4 (input gradient): dst0 = dL/dz of the layer whose activation this launch differentiates (NOT dL/da): its norm
  *                     backward from z, stats (read), gamma, slope; dgamma / dbeta [C] += (atomics, may be NULL).
+ *   mode 5            = mode 4 with dgamma / dbeta as PER-IMAGE planes [N][C], written (not accumulated) by the one workgroup
+ *                     that owns an (image, channel): no same-address atomics; cu_norm_param_grads_batch adds the images.
  * *done = 1 when the launch took this form, else nothing of it happened (dst0 holds the plain result). */
 typedef struct {
     int mode;
@@ -228,6 +230,19 @@ int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, const void* 
 /* + CU_NORM_DETERMINISTIC: two-pass kernels with one workgroup per image (fixed summation order, every sum has a single
  * adder) and, in the backward, dgamma / dbeta summed over the images by a finish pass: bit-identical results run to run. */
 #define CU_NORM_DETERMINISTIC 32
+/* + CU_NORM_PARAM_PARTS (cu_instnorm_bwd_fused on maps of <= 1024 pixels, two-pass form): dgamma / dbeta are per-image planes
+ * [N][C] that the launch WRITES (one workgroup owns an (image, channel): no atomics, fixed result); the caller adds the
+ * images with cu_norm_param_grads_batch -- every layer of a backward pass in one launch. */
+#define CU_NORM_PARAM_PARTS 64
+typedef struct {
+    const float* dgamma_parts;     /* [N][C] or NULL */
+    const float* dbeta_parts;      /* [N][C] or NULL */
+    float* dgamma;                 /* [C] += sum over the images, in image order */
+    float* dbeta;
+    int N, C;
+} cu_pgrad_item;
+/* items: DEVICE array of n_items entries; max_c >= every item's C. */
+int cu_norm_param_grads_batch(const cu_pgrad_item* items, int n_items, int max_c, void* stream);
 /* out == NULL (cu_instnorm_fwd_fused with the two-pass kernels, cu_instnorm_fwd_given): statistics only -- the layer's
  * consumers then normalise + activate while they stage the raw tensor (scale / shift of cu_conv_gemm / cu_conv_wgrad). */
 size_t cu_instnorm_resident_ws_floats(int N, int C);

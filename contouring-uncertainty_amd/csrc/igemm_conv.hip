@@ -1679,9 +1679,9 @@ extern "C" int cu_conv_gemm_ex(const cu_conv_desc* d, const void* src0, const fl
         const int max_wgs = cu_env_int("CU_CONV_KSPLIT_WGS", 128);
         if (ws && !wres && whole && !d->out_nchw_f32 && nchunks >= 4 && (wgs <= max_wgs || (norm_fin && wgs <= 512)) &&
             a.ntiles <= grid_x && !cu_env_set("CU_CONV_NO_KSPLIT")) {
-            int want = (int)(512 / wgs);
+            int want = (int)(cu_env_int("CU_CONV_KSPLIT_TARGET", 512) / wgs);      // workgroups the split aims at (tuning knob)
             if (norm_fin && want < 2) want = 2;
-            if (want > 8) want = 8;
+            if (want > cu_env_int("CU_CONV_KSPLIT_MAX", 8)) want = cu_env_int("CU_CONV_KSPLIT_MAX", 8);
             if (want > nchunks / 2) want = nchunks / 2;
             while (want > 1 && (size_t)want * (fin0 + fin1) > ws_floats) --want;
             if (want > 1) {

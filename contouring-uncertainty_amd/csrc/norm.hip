@@ -609,16 +609,19 @@ __global__ __launch_bounds__(NT) void bwd_small_kernel(T* __restrict__ g, const 
 // application, so both tensors are read ONCE (the two-pass form above re-reads them and, with 256 threads per (image, 64
 // channels), leaves a CU 4 waves to hide the latency behind: 30 us at 16^2 x 480 and 48 us at 32^2 x 256 for 10 / 20 us of
 // traffic).  16 x 16: 512 threads x 4 rows; 32 x 32: 1024 threads x 8 rows.  bf16 only (16-byte pieces of 8 channels).
-template <int NR, int THREADS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS / 256, THREADS / 256))) void bwd_small_res_kernel(bf16_t* __restrict__ g, const bf16_t* __restrict__ z,
+template <int NR, int THREADS, int SGT = SG>
+__global__ __launch_bounds__(THREADS) void bwd_small_res_kernel(bf16_t* __restrict__ g, const bf16_t* __restrict__ z,
                                                                 const float* __restrict__ stats, const float* __restrict__ gamma,
                                                                 float slope, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                 int N, int HW, int C, int pstride) {
-    constexpr int PIECE = 8, ROWS = THREADS / SG, NW = THREADS / 64;
-    __shared__ float part[NW][SG][2 * PIECE];
+    // SGT = 16-byte pieces (8 channels each) per workgroup: 8 at 16 x 16; 4 at 32 x 32, where 1024 threads x 4 rows keep the
+    // register count of 512 threads x 8 rows under the 256 an 8-wave workgroup may use (1024 threads x 8 rows x 8 pieces spilled: 616 bytes
+    // of scratch, 97 us instead of 48; 1024 threads x 4 rows x 4 pieces still 116 bytes)
+    constexpr int PIECE = 8, ROWS = THREADS / SGT, NW = THREADS / 64;
+    __shared__ float part[NW][SGT][2 * PIECE];
     const int n = blockIdx.x;
-    const int pl = threadIdx.x & (SG - 1), prow = threadIdx.x / SG;
-    const int piece = blockIdx.y * SG + pl;
+    const int pl = threadIdx.x & (SGT - 1), prow = threadIdx.x / SGT;
+    const int piece = blockIdx.y * SGT + pl;
     const bool active = piece * PIECE < C;
     const size_t NC = (size_t)N * C;
     const size_t sidx = (size_t)n * C + (active ? piece : 0) * PIECE;
@@ -665,11 +668,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
 #pragma unroll
         for (int e = 0; e < PIECE; ++e) {
             float v = acc[a][e];
+            if constexpr (SGT <= 4) v += __shfl_xor(v, 4, 64);
             v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
             acc[a][e] = v;
         }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane < SG) {
+    if (lane < SGT) {
 #pragma unroll
         for (int e = 0; e < PIECE; ++e) { part[wave][lane][2 * e] = acc[0][e]; part[wave][lane][2 * e + 1] = acc[1][e]; }
     }
@@ -1210,13 +1214,14 @@ static int launch_bwd(int nimg, int N, int HW, int C, void* g, const void* z, co
     if (HW <= 1024 && !det) {       // small feature maps: one fused launch
         dim3 sgrid(nimg, cdiv(C / PIECE, SG));
         if constexpr (sizeof(T) == 2) {
+            const dim3 sgrid4(nimg, cdiv(C / PIECE, 4));
             // 16 x 16 and 32 x 32 maps in bf16: the register-resident form (both tensors read once)
             if (!dbias && (HW == 256 || HW == 1024) && !cu_env_set("CU_NORM_NO_SMALL_RES")) {
                 if (HW == 256)
                     hipLaunchKernelGGL((bwd_small_res_kernel<4, 512>), sgrid, dim3(512), 0, st, (bf16_t*)g, (const bf16_t*)z, stats,
                                        gamma, slope, dgamma, dbeta, N, HW, C, pstride);
                 else
-                    hipLaunchKernelGGL((bwd_small_res_kernel<8, 1024>), sgrid, dim3(1024), 0, st, (bf16_t*)g, (const bf16_t*)z, stats,
+                    hipLaunchKernelGGL((bwd_small_res_kernel<8, 512, 4>), sgrid4, dim3(512), 0, st, (bf16_t*)g, (const bf16_t*)z, stats,
                                        gamma, slope, dgamma, dbeta, N, HW, C, pstride);
                 CU_LAUNCH_CHECK();
                 return 0;
@@ -1453,24 +1458,39 @@ extern "C" int cu_instnorm_bwd_fused(int dtype, int N, int HW, int C, void* g, c
 // channel) in planes [N][C] instead of adding them into dgamma[c] / dbeta[c] with 64 same-address atomics per channel (17 of
 // 31 us of the 16^2 x 480 launch); this kernel adds the images in order: deterministic, one launch per step.
 namespace {
-__global__ __launch_bounds__(256) void norm_param_grads_batch_kernel(const cu_pgrad_item* __restrict__ items) {
+__global__ __launch_bounds__(256) void norm_param_grads_batch_kernel(const cu_pgrad_item* __restrict__ items, char* base) {
+    // workgroup = (layer, 32 channels); thread = (channel, one of 8 image groups): the groups' loads are independent (a
+    // single thread walking the 64 images serially took 60 us for the step's 28 layers), the groups are added in order
+    __shared__ float red[2][8][32];
     const cu_pgrad_item it = items[blockIdx.x];
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= it.C) return;
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = blockIdx.y * 32 + cl;
+    if (blockIdx.y * 32 >= it.C) return;
     float sg = 0.f, sb = 0.f;
-    for (int n = 0; n < it.N; ++n) {
-        if (it.dgamma_parts) sg += it.dgamma_parts[(size_t)n * it.C + c];
-        if (it.dbeta_parts) sb += it.dbeta_parts[(size_t)n * it.C + c];
+    if (c < it.C) {
+        const int per = (it.N + 7) / 8, n0 = grp * per, n1 = min(it.N, n0 + per);
+        for (int n = n0; n < n1; ++n) {
+            if (it.dgamma_parts) sg += it.dgamma_parts[(size_t)n * it.C + c];
+            if (it.dbeta_parts) sb += it.dbeta_parts[(size_t)n * it.C + c];
+        }
     }
-    if (it.dgamma && it.dgamma_parts) it.dgamma[c] += sg;
-    if (it.dbeta && it.dbeta_parts) it.dbeta[c] += sb;
+    red[0][grp][cl] = sg;
+    red[1][grp][cl] = sb;
+    __syncthreads();
+    if (grp == 0 && c < it.C) {
+        float tg = 0.f, tb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { tg += red[0][k][cl]; tb += red[1][k][cl]; }
+        if (it.dgamma_parts) reinterpret_cast<float*>(base + it.dgamma_off)[c] += tg;
+        if (it.dbeta_parts) reinterpret_cast<float*>(base + it.dbeta_off)[c] += tb;
+    }
 }
 }  // namespace
 
-extern "C" int cu_norm_param_grads_batch(const cu_pgrad_item* items, int n_items, int max_c, void* stream) {
+extern "C" int cu_norm_param_grads_batch(const cu_pgrad_item* items, int n_items, int max_c, float* grad_base, void* stream) {
     CU_CHECK_ARG(items && n_items > 0 && max_c > 0, "cu_norm_param_grads_batch: bad argument");
-    hipLaunchKernelGGL(norm_param_grads_batch_kernel, dim3(n_items, cdiv(max_c, 256)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), items);
+    hipLaunchKernelGGL(norm_param_grads_batch_kernel, dim3(n_items, cdiv(max_c, 32)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), items, reinterpret_cast<char*>(grad_base));
     CU_LAUNCH_CHECK();
     return 0;
 }

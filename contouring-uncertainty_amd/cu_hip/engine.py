@@ -647,11 +647,16 @@ class UNetEngine:
         items, self._pg_items = self._pg_items, []
         if not items:
             return
-        key = tuple((a.data_ptr(), b.data_ptr(), g_.data_ptr(), d_.data_ptr(), n, c) for a, b, g_, d_, n, c in items)
+        # the destinations are views of the step's flat gradient buffer, which is NEW every step: the table stores their offsets
+        # from its base, so it is built once (a table rebuilt per step is a pageable host-to-device copy that makes the host wait
+        # for everything enqueued before it: measured +1.4 ms per step)
+        st0 = items[0][2].untyped_storage()
+        base = st0.data_ptr() if all(t.untyped_storage().data_ptr() == st0.data_ptr() for it in items for t in it[2:4]) else 0
+        key = tuple((a.data_ptr(), b.data_ptr(), g_.data_ptr() - base, d_.data_ptr() - base, n, c) for a, b, g_, d_, n, c in items)
         if self._pg_table is None or self._pg_table[0] != key:
-            table, max_c = ops.pgrad_table(items, device)
+            table, max_c = ops.pgrad_table(items, device, base)
             self._pg_table = (key, table, max_c)
-        ops.norm_param_grads_batch(self._pg_table[1], len(items), self._pg_table[2])
+        ops.norm_param_grads_batch(self._pg_table[1], len(items), self._pg_table[2], base)
 
     def _small_norm_bwd(self, P, G, ctx: UNetCtx, src: Optional[Act], n: int, hw: int, c: int):
         """(target layer, ``norm_bwd_full`` argument) when the input-gradient launch that differentiates ``src`` may carry

@@ -73,7 +73,7 @@ _SIGS = {
     "cu_instnorm_fwd_given": (C.c_int, [C.c_int] * 4 + [_P] * 3 + [C.c_float, C.c_float] + [_P] * 5),
     "cu_instnorm_bwd_given": (C.c_int, [C.c_int] * 4 + [_P] * 4 + [C.c_float] + [_P] * 4),
     "cu_instnorm_bwd_fused": (C.c_int, [C.c_int] * 4 + [_P] * 4 + [C.c_float] + [_P] * 3 + [C.c_int, _P]),
-    "cu_norm_param_grads_batch": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "cu_norm_param_grads_batch": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "cu_channel_scale": (C.c_int, [C.c_int] * 4 + [_P] * 3),
     "cu_maxpool2_fwd": (C.c_int, [C.c_int] * 5 + [_P] * 4),
     "cu_maxpool2_bwd": (C.c_int, [C.c_int] * 5 + [_P] * 4),

@@ -400,8 +400,9 @@ def norm_param_parts_ok(n: int, hw: int) -> bool:
 _PGRAD_ITEM = None
 
 
-def pgrad_table(items, device) -> Tuple[Tensor, int]:
-    """items: [(dgamma_parts, dbeta_parts, dgamma, dbeta, N, C)] -> (device table of cu_pgrad_item, max C)"""
+def pgrad_table(items, device, base_ptr: int = 0) -> Tuple[Tensor, int]:
+    """items: [(dgamma_parts, dbeta_parts, dgamma, dbeta, N, C)] -> (device table of cu_pgrad_item, max C); the destinations are
+    stored as byte offsets from ``base_ptr`` (0 = absolute addresses)"""
     global _PGRAD_ITEM
     import numpy as np
     if _PGRAD_ITEM is None:
@@ -409,14 +410,16 @@ def pgrad_table(items, device) -> Tuple[Tensor, int]:
         assert _PGRAD_ITEM.itemsize == 40
     arr = np.zeros(len(items), dtype=_PGRAD_ITEM)
     for i, (gp, bp, g, b, n, c) in enumerate(items):
-        arr[i] = (gp.data_ptr(), bp.data_ptr(), g.data_ptr(), b.data_ptr(), n, c)
+        arr[i] = (gp.data_ptr(), bp.data_ptr(), g.data_ptr() - base_ptr, b.data_ptr() - base_ptr, n, c)
     return torch.from_numpy(arr.view(np.uint8)).to(device), max(it[5] for it in items)
 
 
-def norm_param_grads_batch(table: Tensor, n_items: int, max_c: int):
+def norm_param_grads_batch(table: Tensor, n_items: int, max_c: int, base_ptr: int = 0):
     """dgamma[c] += sum_n parts[n][c] for every listed layer in one launch (cu_norm_param_grads_batch)"""
+    import ctypes as _C
     with _Prof("instnorm_bwd"):
-        L.check(L.load().cu_norm_param_grads_batch(L.ptr(table), n_items, max_c, L.stream_ptr()), "cu_norm_param_grads_batch")
+        L.check(L.load().cu_norm_param_grads_batch(L.ptr(table), n_items, max_c, _C.c_void_p(base_ptr) if base_ptr else None,
+                                                   L.stream_ptr()), "cu_norm_param_grads_batch")
 
 
 def resident_ws_floats(n: int, c: int) -> int:

@@ -237,12 +237,14 @@ int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, const void* 
 typedef struct {
     const float* dgamma_parts;     /* [N][C] or NULL */
     const float* dbeta_parts;      /* [N][C] or NULL */
-    float* dgamma;                 /* [C] += sum over the images, in image order */
-    float* dbeta;
+    uint64_t dgamma_off;           /* BYTE offset of dgamma [C] from grad_base (+= sum over the images, in image order) */
+    uint64_t dbeta_off;
     int N, C;
 } cu_pgrad_item;
-/* items: DEVICE array of n_items entries; max_c >= every item's C. */
-int cu_norm_param_grads_batch(const cu_pgrad_item* items, int n_items, int max_c, void* stream);
+/* items: DEVICE array of n_items entries; max_c >= every item's C.  grad_base: the buffer the offsets refer to (a training
+ * step writes every gradient into ONE flat buffer that is new each step: the table then stays valid from step to step and
+ * only this pointer changes); NULL = the offsets are absolute addresses. */
+int cu_norm_param_grads_batch(const cu_pgrad_item* items, int n_items, int max_c, float* grad_base, void* stream);
 /* out == NULL (cu_instnorm_fwd_fused with the two-pass kernels, cu_instnorm_fwd_given): statistics only -- the layer's
  * consumers then normalise + activate while they stage the raw tensor (scale / shift of cu_conv_gemm / cu_conv_wgrad). */
 size_t cu_instnorm_resident_ws_floats(int N, int C);

@@ -1679,7 +1679,11 @@ extern "C" int cu_conv_gemm_ex(const cu_conv_desc* d, const void* src0, const fl
         const int max_wgs = cu_env_int("CU_CONV_KSPLIT_WGS", 128);
         if (ws && !wres && whole && !d->out_nchw_f32 && nchunks >= 4 && (wgs <= max_wgs || (norm_fin && wgs <= 512)) &&
             a.ntiles <= grid_x && !cu_env_set("CU_CONV_NO_KSPLIT")) {
-            int want = (int)(cu_env_int("CU_CONV_KSPLIT_TARGET", 512) / wgs);      // workgroups the split aims at (tuning knob)
+            // workgroups the split aims at: 512; 256 on 4x4 maps, where the partial-tile traffic of a deeper split costs more than
+            // the extra workgroups bring (profiles/r04_small_map_sweep.txt: 34.7 -> 28.6 us, 48.3 -> 40.1 us per ConvLayer; 8x8 and
+            // 2x2 maps are indifferent or worse)
+            const int ks_target = (long)d->PH * d->PW == 16 ? 256 : 512;
+            int want = (int)(cu_env_int("CU_CONV_KSPLIT_TARGET", ks_target) / wgs);
             if (norm_fin && want < 2) want = 2;
             if (want > cu_env_int("CU_CONV_KSPLIT_MAX", 8)) want = cu_env_int("CU_CONV_KSPLIT_MAX", 8);
             if (want > nchunks / 2) want = nchunks / 2;

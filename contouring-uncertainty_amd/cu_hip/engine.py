@@ -192,6 +192,12 @@ class UNetEngine:
         self.side_wgrad = os.environ.get("CONTOUR_SIDE_WGRAD", "1") != "0"
         self._side: Optional[torch.cuda.Stream] = None
         self._side_keep: List[Tensor] = []
+        # weight-gradient launches may trail the input-gradient chain by `wgrad_lag` layers (round 4 experiment): issued at once,
+        # the weight gradient of a level runs beside the input gradient of the SAME level -- both HBM-bound at 256^2 / 128^2,
+        # both MFMA-bound in the middle -- so they mostly take turns; lagging them puts an HBM-bound launch beside an
+        # MFMA-bound one.  The operands are kept alive by the queue; the data is final when the launch is queued.
+        self.wgrad_lag = int(os.environ.get("CONTOUR_WGRAD_LAG", "0"))
+        self._lagq: list = []
 
     # ------------------------------------------------------------------------------------------ operand copies
     def _operands(self, name: str, w: Tensor, kind: str, cop: Optional[int] = None):
@@ -457,7 +463,31 @@ class UNetEngine:
         self._side_keep.extend(reads)
         return torch.cuda.stream(self._side)
 
+    def _wgrad_task(self, reads, fn):
+        """run ``fn`` (a weight-gradient launch + its slab sums) on the weight-gradient stream: now, or ``wgrad_lag`` tasks later"""
+        if not self.wgrad_lag or not self.side_wgrad or not reads[0].is_cuda or torch.cuda.is_current_stream_capturing():
+            with self._wgrad_stream(*reads):
+                fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self._lagq.append((ev, reads, fn))
+        while len(self._lagq) > self.wgrad_lag:
+            self._run_lagged()
+
+    def _run_lagged(self):
+        ev, reads, fn = self._lagq.pop(0)
+        dev = reads[0].device
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(dev)
+        self._side.wait_event(ev)
+        self._side_keep.extend(reads)
+        with torch.cuda.stream(self._side):
+            fn()
+
     def _join_wgrad(self, device):
+        while self._lagq:
+            self._run_lagged()
         ops.pending_wait()                  # (a side task nobody consumed inside this backward: its results are gradients)
         if self._side is not None and self._side_keep:
             torch.cuda.current_stream(device).wait_stream(self._side)
@@ -583,9 +613,10 @@ class UNetEngine:
         ci = w.shape[1]
         if not (rec.stride == 1 and len(rec.srcs) == 1 and self._raw_ok(rec.srcs[0], ci, co)):
             rec.srcs = [ops.materialized(s_) for s_ in rec.srcs]
-        with self._wgrad_stream(g, *[s_.z for s_ in rec.srcs]):
-            self._wgrad(rec.srcs, g, (9, co, ci), G[f"{prefix}.conv.weight"], "conv", prefix, grid=(oh, ow),
-                        in_stride=rec.stride, z_stride=1, taps=TAPS3_W, n_cols=co)
+        srcs_w, stride_w = rec.srcs, rec.stride
+        self._wgrad_task([g] + [s_.z for s_ in srcs_w] + [s_.a for s_ in srcs_w if s_.a is not None],
+                         lambda: self._wgrad(srcs_w, g, (9, co, ci), G[f"{prefix}.conv.weight"], "conv", prefix, grid=(oh, ow),
+                                             in_stride=stride_w, z_stride=1, taps=TAPS3_W, n_cols=co))
         if dsrc is None:
             return
         _, wd = self._operands(f"{prefix}.conv.weight", w, "conv")
@@ -677,10 +708,10 @@ class UNetEngine:
         w = P[f"{rec.prefix}.weight"]
         ci, co = w.shape[0], w.shape[1]
         n, h, w_, _ = rec.src.z.shape
-        with self._wgrad_stream(du, rec.src.z):
-            taps = [(0, 0, dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)]
-            self._wgrad([rec.src], du, (4, co, ci), G[f"{rec.prefix}.weight"], "convT", rec.prefix, grid=(h, w_),
-                        in_stride=1, z_stride=2, taps=taps, n_cols=co)
+        taps = [(0, 0, dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)]
+        self._wgrad_task([du, rec.src.z] + ([rec.src.a] if rec.src.a is not None else []),
+                         lambda: self._wgrad([rec.src], du, (4, co, ci), G[f"{rec.prefix}.weight"], "convT", rec.prefix,
+                                             grid=(h, w_), in_stride=1, z_stride=2, taps=taps, n_cols=co))
         _, wd = self._operands(f"{rec.prefix}.weight", w, "convT")
         full = self._small_norm_bwd(P, G, ctx, rec.src, n, h * w_, ci)
         got = ops.conv_gemm([Act(du, None, 1.0)], wd, None, grid=(h, w_), in_stride=2,
@@ -709,6 +740,7 @@ class UNetEngine:
             finally:
                 self._red_done = [None, None]
                 self._side_keep.clear()
+                self._lagq.clear()
                 self._given_sums.clear()
                 self._bwd_done.clear()
                 self._pg_items = []

@@ -639,7 +639,7 @@ class UNetEngine:
             got = ops.conv_gemm([gz], wd, None, grid=(sh, sw), in_stride=1, taps=TAPS3_D, dsts=dsts, dst_cols=cols,
                                 accum=acc, norm_bwd=nb, norm_bwd_full=full[1] if full else None)
             if got and full:
-                self._bwd_done.add(full[0])
+                self._norm_bwd_taken(full)
             elif got:
                 self._given_sums[tgt] = nb[1]
         elif ONE_PASS_S2_DGRAD and self.dtype == torch.bfloat16 and len(dsts) == 1 and cols[0] % 32 == 0:
@@ -653,7 +653,7 @@ class UNetEngine:
                                 accum=acc, n_cols=4 * cols[0], parity_cols=cols[0], parity_taps=S2_PARITY_TAPS,
                                 norm_bwd_full=full[1] if full else None)
             if got and full:
-                self._bwd_done.add(full[0])
+                self._norm_bwd_taken(full)
         else:
             for py in range(2):
                 for px in range(2):
@@ -661,16 +661,21 @@ class UNetEngine:
                     ops.conv_gemm([gz], wd, None, grid=(sh // 2, sw // 2), in_stride=1, taps=taps, dsts=dsts,
                                   dst_cols=cols, out_stride=2, out_off=(py, px), accum=acc)
 
-    def _pgrad_parts(self, G, prefix: str, n: int, hw: int, c: int, device):
+    def _pgrad_parts(self, G, prefix: str, n: int, hw: int, c: int, device, register: bool = True):
         """(dgamma planes, dbeta planes), each (N, C) and zero, for a layer whose norm backward may leave per-image parameter
-        gradients (``ops.norm_param_parts_ok``), registered for the batched sum at the end of the pass; else None."""
+        gradients (``ops.norm_param_parts_ok``), registered for the batched sum at the end of the pass; else None.
+        ``register=False`` returns (planes, planes, item) and leaves the registration to the caller: a layer must be in the
+        batch ONCE (its work items read-modify-write the same gradient without atomics)."""
         # (with a gradient exchange attached, a layer's "gradients final" report covers its norm parameters too: they must be
         #  final when the layer reports, not at the end of the pass)
         if not self.param_parts or self.deterministic or self.grad_ready_hook is not None or not ops.norm_param_parts_ok(n, hw):
             return None
         buf = self._arena["bwd"].take(2 * n * c, device)
         gp, bp = buf[:n * c], buf[n * c:2 * n * c]
-        self._pg_items.append((gp, bp, G[f"{prefix}.norm.weight"], G[f"{prefix}.norm.bias"], n, c))
+        item = (gp, bp, G[f"{prefix}.norm.weight"], G[f"{prefix}.norm.bias"], n, c)
+        if not register:
+            return gp, bp, item
+        self._pg_items.append(item)
         return gp, bp
 
     def _pgrad_finish(self, device):
@@ -681,6 +686,7 @@ class UNetEngine:
         # the destinations are views of the step's flat gradient buffer, which is NEW every step: the table stores their offsets
         # from its base, so it is built once (a table rebuilt per step is a pageable host-to-device copy that makes the host wait
         # for everything enqueued before it: measured +1.4 ms per step)
+        assert len({it[2].data_ptr() for it in items}) == len(items), "a layer twice in one batch: its two work items would race"
         st0 = items[0][2].untyped_storage()
         base = st0.data_ptr() if all(t.untyped_storage().data_ptr() == st0.data_ptr() for it in items for t in it[2:4]) else 0
         key = tuple((a.data_ptr(), b.data_ptr(), g_.data_ptr() - base, d_.data_ptr() - base, n, c) for a, b, g_, d_, n, c in items)
@@ -699,10 +705,17 @@ class UNetEngine:
         rec = ctx.convs.get(tgt)
         if rec is None or rec.drop_mask is not None or rec.out.stats is None or rec.first:
             return None
-        parts = self._pgrad_parts(G, tgt, n, hw, c, rec.out.z.device)
-        if parts is not None:      # (planes of a launch that does not take the epilogue stay zero: adding them changes nothing)
-            return tgt, (rec.out, P[f"{tgt}.norm.weight"], parts[0], parts[1], True)
-        return tgt, (rec.out, P[f"{tgt}.norm.weight"], G[f"{tgt}.norm.weight"], G[f"{tgt}.norm.bias"], False)
+        parts = self._pgrad_parts(G, tgt, n, hw, c, rec.out.z.device, register=False)
+        if parts is not None:      # registered by _norm_bwd_taken only if the launch takes the epilogue: the layer's own norm
+            #                        backward registers planes of its own otherwise, and two items of one layer would race
+            return tgt, (rec.out, P[f"{tgt}.norm.weight"], parts[0], parts[1], True), parts[2]
+        return tgt, (rec.out, P[f"{tgt}.norm.weight"], G[f"{tgt}.norm.weight"], G[f"{tgt}.norm.bias"], False), None
+
+    def _norm_bwd_taken(self, full):
+        """the input-gradient launch carried the norm backward of layer ``full[0]``"""
+        self._bwd_done.add(full[0])
+        if full[2] is not None:
+            self._pg_items.append(full[2])
 
     def _convT_bwd(self, P, G, ctx: UNetCtx, rec: _UpRec, du: Tensor, d_in: Tensor, accum: int):
         w = P[f"{rec.prefix}.weight"]
@@ -718,7 +731,7 @@ class UNetEngine:
                             taps=[(dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)], dsts=[d_in], dst_cols=[ci],
                             accum=[accum], norm_bwd_full=full[1] if full else None)
         if got and full:
-            self._bwd_done.add(full[0])
+            self._norm_bwd_taken(full)
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, P: Dict[str, Tensor], G: Dict[str, Tensor], ctx: UNetCtx, dlogits: Optional[Tensor],

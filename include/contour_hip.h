@@ -243,7 +243,8 @@ typedef struct {
 } cu_pgrad_item;
 /* items: DEVICE array of n_items entries; max_c >= every item's C.  grad_base: the buffer the offsets refer to (a training
  * step writes every gradient into ONE flat buffer that is new each step: the table then stays valid from step to step and
- * only this pointer changes); NULL = the offsets are absolute addresses. */
+ * only this pointer changes); NULL = the offsets are absolute addresses.  A destination may appear in ONE item only: the
+ * work items of a launch read-modify-write their destinations without atomics. */
 int cu_norm_param_grads_batch(const cu_pgrad_item* items, int n_items, int max_c, float* grad_base, void* stream);
 /* out == NULL (cu_instnorm_fwd_fused with the two-pass kernels, cu_instnorm_fwd_given): statistics only -- the layer's
  * consumers then normalise + activate while they stage the raw tensor (scale / shift of cu_conv_gemm / cu_conv_wgrad). */

@@ -17,7 +17,7 @@
 // The skew-normal sampler (SkewPosteriorShapeModelSampler, psm_skew.py:45-158,162-503) and the ED/ES sequence samplers
 // (sequence_sampler.py:13-160, psm_skew_sequence.py:21-166) share the same per-frame algebra (psm_frame_setup below):
 //   cu_psm_setup          gains / conditional covariances of every level into a global per-frame record;
-//   cu_psm_sample_skew    one workgroup per (frame, sample): anchors by rvs_fast, every other point by inverse-CDF
+//   cu_psm_sample_skew    one WAVE per (frame, sample), four samples of a frame per workgroup: anchors by rvs_fast, every other point by inverse-CDF
 //                         sampling of  skew-pdf(prediction) x N(mu_c, cov_c)  on the 256x256 pixel grid
 //                         (`numerical_sampling`), evaluated on the fly - no pdf grid ever touches HBM;
 //   cu_psm_condition      conditional mean of a 1-level record given sampled contours (+ product-of-Gaussians merge):
@@ -295,6 +295,7 @@ struct SkewArgs {
     const float* prior_mu; const float* prior_cov;      // optional extra Gaussian factor per point: [F][S][K][2], [F][S][K][3]
     const float* eps; const float* u; float* out;
     int F, S, K, n_init, n_levels, grid, use_initial_pdf;
+    int merged_window;                                  // window of the PRODUCT of the Gaussian factors (grid_sample)
     int init_pts[8];
     int sample_level[MAXLV];
     unsigned long long skew_bits;                       // bit k: point k is drawn from the skew grid product
@@ -302,30 +303,30 @@ struct SkewArgs {
     unsigned long long seed;
 };
 
-// inclusive scan of one double per thread over the block; buf holds 2*ST doubles; returns this thread's prefix
-__device__ __forceinline__ double block_scan(double v, double* buf, int tid, double& total) {
-    int src = 0;
-    buf[tid] = v;
-    __syncthreads();
+// ---- one WAVE per sample (round 4) -----------------------------------------------------------------------------------
+// The first version gave a sample a whole 256-thread workgroup: thread = grid row, two 256-wide Hillis-Steele scans through LDS
+// and ~22 barriers per drawn point, with the window of non-zero cells (30-70 rows for the PSM's tight conditionals) keeping one
+// or two of the four waves busy.  Now a workgroup holds FOUR samples of one frame (the frame record is staged once for the
+// four), each wave runs its sample on its own: scans and reductions are wave shuffles, the contour lives in a register per
+// lane (lane i = flat coordinate i), and after the staging barrier there is no workgroup synchronisation at all.
+__device__ __forceinline__ double wave_scan(double v, int lane) {         // inclusive prefix over the 64 lanes
 #pragma unroll
-    for (int off = 1; off < ST; off <<= 1) {
-        double t = buf[src * ST + tid];
-        if (tid >= off) t += buf[src * ST + tid - off];
-        buf[(src ^ 1) * ST + tid] = t;
-        src ^= 1;
-        __syncthreads();
+    for (int off = 1; off < 64; off <<= 1) {
+        const double t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
     }
-    total = buf[src * ST + ST - 1];
-    return buf[src * ST + tid];
+    return v;
 }
 
 // Draw one grid cell from  pA(x,y) * pB(x,y) [* pC(x,y)]  on the grid x grid lattice of pixel coordinates
 // linspace(0, 255, grid) (numerical_sampling, psm_skew.py:45-158): inverse CDF in the flat order of torch's
 // meshgrid(indexing='ij') (x major).  Cells where the Gaussian factor(s) are exactly 0 in f32 are skipped: they carry
 // no mass in the reference's table either.  Returns false when the table has no mass (the reference's multinomial
-// raises and it falls back to mu_c, psm_skew.py:135-154).
+// raises and it falls back to mu_c, psm_skew.py:135-154).  All arguments are wave-uniform; so are the results.
+// Window of nx rows x ny cells: k = 64 / nx (a power of two) lanes share a row when the window is narrow, each summing every
+// k-th cell of it; wider windows take ceil(nx / 64) passes of one lane per row (grid <= 256: at most 4).
 __device__ bool grid_sample(const Skew2& A, const Gauss2& B, const Gauss2* Cg, float covBxx, float covByy, float covCxx,
-                            float covCyy, int grid, float u, double* buf, int tid, float& sx, float& sy) {
+                            float covCyy, int grid, float u, int lane, float& sx, float& sy, bool merged_window) {
     const float step = 255.f / (float)(grid - 1), istep = (float)(grid - 1) / 255.f;
     // window where exp(lc - q/2) can be non-zero in f32 (smallest denormal = exp(-103.3)); q >= d1^2 / Sigma_xx
     float L = 2.f * (104.f + fmaxf(B.lc, 0.f));
@@ -337,49 +338,114 @@ __device__ bool grid_sample(const Skew2& A, const Gauss2& B, const Gauss2* Cg, f
         x0 = fmaxf(x0, Cg->mx - rx); x1 = fminf(x1, Cg->mx + rx);
         y0 = fmaxf(y0, Cg->my - ry); y1 = fminf(y1, Cg->my + ry);
     }
+    if (merged_window) {
+        // The Gaussian factors multiply to c N(x; mu_f, P^-1), P = sum of the inverse covariances, and the skew factor
+        // 2 (Phi + 1e-7) is at most 2.0000002: in the reference's f32 table p1 * p2 [* p3] (psm_skew.py:96-107) a cell is exactly
+        // 0 -- below the smallest denormal, exp(-103.28) -- where
+        //     sum lc_i + log 2 - (r0 + (x - mu_f)^T P (x - mu_f)) / 2 < -103.28,     r0 = sum q_i(mu_f)
+        // (one unit of slack in the exponent for the f32 evaluation).  The bounding box of that ellipse is never larger than the
+        // window of the conditional Gaussian alone and much smaller when the prediction is the tighter factor.
+        float Pa = A.g.qa + B.qa, Pb = A.g.qb + B.qb, Pc = A.g.qc + B.qc;                 // P = [[Pa, Pb/2], [Pb/2, Pc]]
+        float hx = A.g.qa * A.g.mx + 0.5f * A.g.qb * A.g.my + B.qa * B.mx + 0.5f * B.qb * B.my;
+        float hy = 0.5f * A.g.qb * A.g.mx + A.g.qc * A.g.my + 0.5f * B.qb * B.mx + B.qc * B.my;
+        float lcs = A.g.lc + B.lc;
+        if (Cg) {
+            Pa += Cg->qa; Pb += Cg->qb; Pc += Cg->qc;
+            hx += Cg->qa * Cg->mx + 0.5f * Cg->qb * Cg->my;
+            hy += 0.5f * Cg->qb * Cg->mx + Cg->qc * Cg->my;
+            lcs += Cg->lc;
+        }
+        const float det = Pa * Pc - 0.25f * Pb * Pb, idet = 1.f / det;
+        const float fx = (Pc * hx - 0.5f * Pb * hy) * idet, fy = (Pa * hy - 0.5f * Pb * hx) * idet;
+        auto quad = [&](const Gauss2& g) {
+            const float d1 = fx - g.mx, d2 = fy - g.my;
+            return g.qa * d1 * d1 + g.qb * d1 * d2 + g.qc * d2 * d2;
+        };
+        float r0 = quad(A.g) + quad(B);
+        if (Cg) r0 += quad(*Cg);
+        const float Lf = 2.f * (lcs + 0.7f + 104.3f) - r0;
+        if (!(det > 0.f) || !(Lf == Lf)) {
+            // (degenerate algebra: keep the window of the conditional Gaussian)
+        } else if (Lf <= 0.f) {
+            x1 = x0 - 1.f;                                        // no cell carries mass
+        } else {
+            const float rfx = sqrtf(Lf * Pc * idet), rfy = sqrtf(Lf * Pa * idet);
+            x0 = fmaxf(x0, fx - rfx); x1 = fminf(x1, fx + rfx);
+            y0 = fmaxf(y0, fy - rfy); y1 = fminf(y1, fy + rfy);
+        }
+    }
     const int xlo = max(0, (int)ceilf(x0 * istep)), xhi = min(grid - 1, (int)floorf(x1 * istep));
     const int ylo = max(0, (int)ceilf(y0 * istep)), yhi = min(grid - 1, (int)floorf(y1 * istep));
+    if (xlo > xhi || ylo > yhi) return false;
+    const int nx = xhi - xlo + 1, ny = yhi - ylo + 1;
     auto cell = [&](int ix, int iy) -> double {
         const float x = ix * step, y = iy * step;
         double v = (double)skew_pdf(A, x, y) * (double)gauss_pdf(B, x, y);
         if (Cg) v *= (double)gauss_pdf(*Cg, x, y);
         return v;
     };
-    double rs = 0.0;
-    if (tid >= xlo && tid <= xhi)
-        for (int iy = ylo; iy <= yhi; ++iy) rs += cell(tid, iy);
-    double total;
-    const double cum = block_scan(rs, buf, tid, total);
-    if (!(total > 0.0) || !(total < 1e300) || xlo > xhi || ylo > yhi) { __syncthreads(); return false; }
+    int k = 1;                                   // lanes per row
+    while (2 * k * nx <= 64) k <<= 1;
+    const int rpp = 64 / k;                      // rows per pass
+    const int sub = lane & (k - 1), rl = lane / k;
+    double rs[4], cum[4];                        // row sum / inclusive prefix of the lane's row in pass p (lanes with sub == 0)
+    double carry = 0.0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        rs[p] = 0.0; cum[p] = 0.0;
+        if (p * rpp >= nx) continue;             // (uniform)
+        const int ri = p * rpp + rl;
+        double acc = 0.0;
+        if (ri < nx)
+            for (int iy = ylo + sub; iy <= yhi; iy += k) acc += cell(xlo + ri, iy);
+        for (int off = 1; off < k; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        rs[p] = (sub == 0 && ri < nx) ? acc : 0.0;
+        cum[p] = carry + wave_scan(rs[p], lane);
+        carry = __shfl(cum[p], 63, 64);
+    }
+    const double total = carry;
+    if (!(total > 0.0) || !(total < 1e300)) return false;
     const double T = (double)u * total;
-    int r = __syncthreads_count(cum <= T);
-    r = min(max(r, xlo), xhi);
-    // prefix before row r: rows below xlo carry nothing
-    __shared__ double base_s;
-    if (tid == r) base_s = cum - rs;
-    __syncthreads();
-    const double base = base_s;
-    const double v = (tid >= ylo && tid <= yhi) ? cell(r, tid) : 0.0;
-    double tot2;
-    const double cum2 = block_scan(v, buf, tid, tot2);
-    int j = __syncthreads_count(base + cum2 <= T);
-    j = min(max(j, ylo), yhi);
-    sx = r * step; sy = j * step;
+    int r = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (p * rpp >= nx) continue;
+        const bool mine = sub == 0 && p * rpp + rl < nx;
+        r += __popcll(__ballot(mine && cum[p] <= T));
+    }
+    r = min(r, nx - 1);
+    // prefix before row r, from the lane that owns it
+    const int pr = r / rpp, lr = (r - pr * rpp) * k;
+    double mb = 0.0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) mb = p == pr ? cum[p] - rs[p] : mb;
+    const double base = __shfl(mb, lr, 64);
+    int j = 0;
+    double carry2 = 0.0;
+    for (int p = 0; p * 64 < ny; ++p) {
+        const int iy = ylo + p * 64 + lane;
+        const double v = iy <= yhi ? cell(xlo + r, iy) : 0.0;
+        const double c2 = carry2 + wave_scan(v, lane);
+        carry2 = __shfl(c2, 63, 64);
+        j += __popcll(__ballot(iy <= yhi && base + c2 <= T));
+    }
+    j = min(j, ny - 1);
+    sx = (xlo + r) * step; sy = (ylo + j) * step;
     return true;
 }
 
+constexpr int SPW = ST / 64;        // samples per workgroup
+
 __global__ __launch_bounds__(ST) void psm_skew_kernel(const SkewArgs p) {
-    extern __shared__ __attribute__((aligned(16))) double lds_d[];
-    const int s = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x * SPW + wave;
     const int K = p.K, P = 2 * K;
-    double* buf = lds_d;                                       // [2][ST] scan buffers
-    float* rec = reinterpret_cast<float*>(buf + 2 * ST);       // frame record: m | covc | G
-    float* ct = rec + p.rec_stride;                            // [P] contour, pixel units
-    float* mcl = ct + MAXP;                                    // [2*MAXT] conditional means of the current level
+    float* rec = lds_f;                                        // frame record: m | covc | G
     __shared__ int goff[MAXLV];
     __shared__ Skew2 skA[MAXP / 2];
-    __shared__ Gauss2 gsC[MAXP / 2];
-    __shared__ float cvC[MAXP / 2][2];
+    __shared__ Gauss2 gsC[SPW][MAXP / 2];
+    __shared__ float cvC[SPW][MAXP / 2][2];
 
     const float* grec = p.rec + (size_t)f * p.rec_stride;
     for (int i = tid; i < p.rec_stride; i += ST) rec[i] = grec[i];
@@ -389,7 +455,7 @@ __global__ __launch_bounds__(ST) void psm_skew_kernel(const SkewArgs p) {
     const float* mu_f = p.mu_pred + (size_t)f * P;
     const float* cv_f = p.cov_pred + (size_t)f * K * 3;
     const float* al_f = p.alpha + (size_t)f * P;
-    const size_t sidx = (size_t)f * p.S + s;
+    const size_t sidx = (size_t)f * p.S + min(s, p.S - 1);
     if (tid < K) {
         const float a = cv_f[3 * tid], b = cv_f[3 * tid + 1], c = cv_f[3 * tid + 2];
         Skew2 k;
@@ -399,12 +465,12 @@ __global__ __launch_bounds__(ST) void psm_skew_kernel(const SkewArgs p) {
         k.z1 = (al1 * (b + sd) - al2 * c) * ist;               // alpha^T Sigma^-1/2, Sigma^-1/2 = [[b+s,-c],[-c,a+s]]/(s t)
         k.z2 = (al2 * (a + sd) - al1 * c) * ist;
         skA[tid] = k;
-        if (p.prior_mu) {
-            const float* pm = p.prior_mu + (sidx * K + tid) * 2;
-            const float* pc = p.prior_cov + (sidx * K + tid) * 3;
-            gsC[tid] = make_gauss(pm[0], pm[1], pc[0], pc[1], pc[2]);
-            cvC[tid][0] = pc[0]; cvC[tid][1] = pc[1];
-        }
+    }
+    if (p.prior_mu && lane < K) {                              // the extra Gaussian factor is per SAMPLE: one table per wave
+        const float* pm = p.prior_mu + (sidx * K + lane) * 2;
+        const float* pc = p.prior_cov + (sidx * K + lane) * 3;
+        gsC[wave][lane] = make_gauss(pm[0], pm[1], pc[0], pc[1], pc[2]);
+        cvC[wave][lane][0] = pc[0]; cvC[wave][lane][1] = pc[1];
     }
     if (tid == 0) {
         int off = 0;
@@ -414,6 +480,7 @@ __global__ __launch_bounds__(ST) void psm_skew_kernel(const SkewArgs p) {
         }
     }
     __syncthreads();
+    if (s >= p.S) return;                                      // (no workgroup barrier below)
     auto normals = [&](int pt, int j, float& e0, float& e1) {
         if (p.eps) { e0 = p.eps[(sidx * K + pt) * 3 + 2 * j]; e1 = j ? 0.f : p.eps[(sidx * K + pt) * 3 + 1]; }
         else normal2(p.seed ^ ((sidx * 64ull + pt) * 4ull + j) * 0x9E3779B97F4A7C15ull, e0, e1);
@@ -421,11 +488,17 @@ __global__ __launch_bounds__(ST) void psm_skew_kernel(const SkewArgs p) {
     auto uniform = [&](int pt) -> float {
         return p.u ? p.u[sidx * K + pt] : uniform01(p.seed ^ ((sidx * 64ull + pt) * 4ull + 3ull) * 0x9E3779B97F4A7C15ull);
     };
+    float ct = 0.f;                                            // lane i < P: flat coordinate i of the contour, pixel units
+    auto set_point = [&](int pt, float x, float y) {           // (x, y wave-uniform)
+        ct = lane == 2 * pt ? x : (lane == 2 * pt + 1 ? y : ct);
+    };
+    const Gauss2* gC = gsC[wave];
 
     // ---- anchors
     if (!p.use_initial_pdf) {
-        if (tid < p.n_init) {      // BivariateSkewNormal.rvs_fast (bivariateskewnormal.py:159-191)
-            const int pt = p.init_pts[tid];
+        float ax = 0.f, ay = 0.f;
+        if (lane < p.n_init) {      // BivariateSkewNormal.rvs_fast (bivariateskewnormal.py:159-191)
+            const int pt = p.init_pts[lane];
             const float a = cv_f[3 * pt], b = cv_f[3 * pt + 1], c = cv_f[3 * pt + 2];
             const float al1 = al_f[2 * pt], al2 = al_f[2 * pt + 1] * p.alpha_y_sign;
             const float sa1 = a * al1 + c * al2, sa2 = c * al1 + b * al2;
@@ -439,22 +512,19 @@ __global__ __launch_bounds__(ST) void psm_skew_kernel(const SkewArgs p) {
             normals(pt, 1, e2, dummy);
             float x1 = l21 * e0 + l22 * e1, x2 = l31 * e0 + l32 * e1 + l33 * e2;
             if (e0 <= 0.f) { x1 = -x1; x2 = -x2; }
-            ct[2 * pt] = x1 + mu_f[2 * pt];
-            ct[2 * pt + 1] = x2 + mu_f[2 * pt + 1];
+            ax = x1 + mu_f[2 * pt];
+            ay = x2 + mu_f[2 * pt + 1];
         }
+        for (int i = 0; i < p.n_init; ++i) set_point(p.init_pts[i], __shfl(ax, i, 64), __shfl(ay, i, 64));
     } else {                       // numerical_sample of the supplied pdfs (psm_skew.py:450-466): skew x prior
         for (int i = 0; i < p.n_init; ++i) {
             const int pt = p.init_pts[i];
             float sx, sy;
-            const bool ok = grid_sample(skA[pt], gsC[pt], nullptr, cvC[pt][0], cvC[pt][1], 0.f, 0.f, p.grid, uniform(pt),
-                                        buf, tid, sx, sy);
-            if (tid == 0) {
-                ct[2 * pt] = ok ? sx : gsC[pt].mx;
-                ct[2 * pt + 1] = ok ? sy : gsC[pt].my;
-            }
+            const bool ok = grid_sample(skA[pt], gC[pt], nullptr, cvC[wave][pt][0], cvC[wave][pt][1], 0.f, 0.f, p.grid,
+                                        uniform(pt), lane, sx, sy, p.merged_window != 0);
+            set_point(pt, ok ? sx : gC[pt].mx, ok ? sy : gC[pt].my);
         }
     }
-    __syncthreads();
 
     // ---- levels
     for (int l = 0; l < p.n_levels; ++l) {
@@ -463,36 +533,32 @@ __global__ __launch_bounds__(ST) void psm_skew_kernel(const SkewArgs p) {
         const int* gi = tb + 2;
         const int* tp = tb + 2 + MAXG;
         const float* Gl = G + goff[l];
-        if (tid < 2 * nt) {
-            const int pt = tp[tid >> 1], row = 2 * pt + (tid & 1);
-            float acc = m[row];
-            for (int j = 0; j < ng; ++j) {
-                const int gj = gi[j];
-                acc += Gl[tid * ng + j] * ((ct[gj] - p.smean[gj]) / p.sscale[gj] - m[gj]);
-            }
-            mcl[tid] = acc * p.sscale[row] + p.smean[row];
+        // conditional means of the level's points: lane < 2 nt owns one coordinate (2 nt <= 2 MAXT = 64)
+        const bool own = lane < 2 * nt;
+        const int row = own ? 2 * tp[lane >> 1] + (lane & 1) : 0;
+        float acc = m[row];
+        for (int j = 0; j < ng; ++j) {
+            const int gj = gi[j];
+            const float cg = __shfl(ct, gj, 64);
+            if (own) acc += Gl[lane * ng + j] * ((cg - p.smean[gj]) / p.sscale[gj] - m[gj]);
         }
-        __syncthreads();
+        const float mcl = acc * p.sscale[row] + p.smean[row];
         if (!p.sample_level[l]) {
-            if (tid < 2 * nt) ct[2 * tp[tid >> 1] + (tid & 1)] = mcl[tid];
-            __syncthreads();
+            for (int q = 0; q < nt; ++q) set_point(tp[q], __shfl(mcl, 2 * q, 64), __shfl(mcl, 2 * q + 1, 64));
             continue;
         }
         for (int q = 0; q < nt; ++q) {
             const int pt = tp[q];
-            const float mcx = mcl[2 * q], mcy = mcl[2 * q + 1];
+            const float mcx = __shfl(mcl, 2 * q, 64), mcy = __shfl(mcl, 2 * q + 1, 64);
             const float* cc = covc + pt * 4;
             if ((p.skew_bits >> pt) & 1ull) {
                 // p2 = exp(MultivariateNormal(mu_c, cov_c).log_prob): the Cholesky factor reads the lower triangle
                 const Gauss2 B = make_gauss(mcx, mcy, cc[0], cc[3], cc[2]);
                 float sx, sy;
-                const bool ok = grid_sample(skA[pt], B, p.prior_mu ? &gsC[pt] : nullptr, cc[0], cc[3], cvC[pt][0],
-                                            cvC[pt][1], p.grid, uniform(pt), buf, tid, sx, sy);
-                if (tid == 0) {
-                    ct[2 * pt] = ok ? sx : mcx;
-                    ct[2 * pt + 1] = ok ? sy : mcy;
-                }
-            } else if (tid == 0) {   // Gaussian point: product-of-Gaussians merge + draw (psm.py:424-440, 387-421)
+                const bool ok = grid_sample(skA[pt], B, p.prior_mu ? &gC[pt] : nullptr, cc[0], cc[3], cvC[wave][pt][0],
+                                            cvC[wave][pt][1], p.grid, uniform(pt), lane, sx, sy, p.merged_window != 0);
+                set_point(pt, ok ? sx : mcx, ok ? sy : mcy);
+            } else {                 // Gaussian point: product-of-Gaussians merge + draw (psm.py:424-440, 387-421)
                 const float a1 = cv_f[3 * pt], b1 = cv_f[3 * pt + 1], c1 = cv_f[3 * pt + 2];
                 const float s1[2][2] = {{a1, c1}, {c1, b1}};
                 const float sc[2][2] = {{cc[0], cc[1]}, {cc[2], cc[3]}};
@@ -504,13 +570,11 @@ __global__ __launch_bounds__(ST) void psm_skew_kernel(const SkewArgs p) {
                 const float l11 = sqrtf(sf[0][0]), l21 = sf[1][0] / l11, l22 = sqrtf(fmaxf(sf[1][1] - l21 * l21, 0.f));
                 float e0, e1;
                 normals(pt, 0, e0, e1);
-                ct[2 * pt] = mfx + l11 * e0;
-                ct[2 * pt + 1] = mfy + l21 * e0 + l22 * e1;
+                set_point(pt, mfx + l11 * e0, mfy + l21 * e0 + l22 * e1);
             }
         }
-        __syncthreads();
     }
-    if (tid < P) p.out[sidx * P + tid] = ct[tid];
+    if (lane < P) p.out[sidx * P + lane] = ct;
 }
 
 // ---- conditional mean of a 1-level record given sampled contours (+ merge with the predictions) ----------------------
@@ -647,13 +711,14 @@ extern "C" int cu_psm_sample_skew(int F, int S, int K, const float* mu_pred, con
     a.eps = eps; a.u = u; a.out = out; a.F = F; a.S = S; a.K = K; a.n_init = n_init; a.n_levels = n_levels;
     a.grid = grid; a.use_initial_pdf = use_initial_pdf; a.skew_bits = skew_bits; a.alpha_y_sign = alpha_y_sign;
     a.seed = seed;
+    a.merged_window = cu_env_int("CU_PSM_MERGED_WINDOW", 1);
     for (int i = 0; i < n_init; ++i) a.init_pts[i] = init_pts[i];
     for (int l = 0; l < n_levels; ++l) a.sample_level[l] = sample_level[l];
-    const size_t lds = sizeof(double) * 2 * ST + sizeof(float) * ((size_t)rec_stride + MAXP + 2 * MAXT);
+    const size_t lds = sizeof(float) * (size_t)rec_stride;
     auto k = psm_skew_kernel;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     CU_CHECK_ARG(e == hipSuccess, "cu_psm_sample_skew: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k, dim3(S, F), dim3(ST), lds, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(k, dim3((S + SPW - 1) / SPW, F), dim3(ST), lds, reinterpret_cast<hipStream_t>(stream), a);
     CU_LAUNCH_CHECK();
     return 0;
 }

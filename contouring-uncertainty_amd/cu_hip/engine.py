@@ -174,7 +174,9 @@ class UNetEngine:
         # tests: keep the last forward's context in ``_last_ctx`` (every layer's raw output, statistics and activation) WITHOUT
         # changing which kernels run -- ``debug`` switches the fused first layer / head / small-map paths off, this does not
         self.keep_ctx = False
-        self._prep_state = None     # (pointer key, item table, blocks, names) of the batched operand preparation
+        self._prep_state = None     # (pointer key, item tables, early names, names, copies) of the batched operand preparation
+        self._prep_pending = None   # (event, stream that must wait for it, names it does not cover): see _prep_all
+        self.prep_overlap = os.environ.get("CONTOUR_PREP_OVERLAP", "1") != "0"
         self._dwk_ws = None                         # partial-tile scratch of the weight gradients (two buffers)
         self._red: Optional[torch.cuda.Stream] = None      # stream of the partial tiles' sums / un-preparations
         self._red_done = [None, None]
@@ -201,6 +203,10 @@ class UNetEngine:
 
     # ------------------------------------------------------------------------------------------ operand copies
     def _operands(self, name: str, w: Tensor, kind: str, cop: Optional[int] = None):
+        pend = self._prep_pending
+        if pend is not None and name not in pend[2]:        # first use of a copy that the weight-gradient stream refreshes
+            pend[1].wait_event(pend[0])
+            self._prep_pending = None
         key = (w.data_ptr(), w._version, ops.PARAM_EPOCH[0])
         hit = self._opcache.get(name)
         if hit is not None and hit[0] == key and hit[1].dtype == self.dtype:
@@ -209,9 +215,13 @@ class UNetEngine:
         self._opcache[name] = (key, wf, wd)
         return wf, wd
 
+    _PREP_EARLY = ("input_block.", "downsamples.0.")
+
     def _prep_all(self, P: Dict[str, Tensor]):
-        """Refresh the bf16/f32 operand copies of EVERY conv / transposed-conv weight in one launch when the parameters
-        changed since the last call (optimizer step, load_state_dict, ...)."""
+        """Refresh the bf16/f32 operand copies of EVERY conv / transposed-conv weight when the parameters changed since the last
+        call (optimizer step, load_state_dict, ...): one launch for the two top encoder levels on the current stream and one for
+        all the other layers on the weight-gradient stream, beside the first layers of the forward pass (the big copies --
+        480 x 480 x 9 -- belong to layers the pass reaches a millisecond later; ``_operands`` makes the pass wait for them)."""
         names = [k for k, v in P.items() if v.dim() == 4 and v.shape[1] > 1 and
                  (k.endswith(".conv.weight") or k.endswith("transp_conv.weight"))]
         if not names:
@@ -219,23 +229,44 @@ class UNetEngine:
         ptr_key = (self.dtype, tuple((k, P[k].data_ptr(), tuple(P[k].shape)) for k in names))
         st = self._prep_state
         if st is None or st[0] != ptr_key:
-            entries, bufs = [], {}
-            for k in names:
-                w = P[k]
-                kind = "convT" if k.endswith("transp_conv.weight") else "conv"
-                cop = 32 if k == "output_block.conv.weight" else None
-                t, co, ci, _, _ = ops._layout(w.shape, kind)
-                cp = cop or co
-                wf = torch.empty((t, cp, ci), dtype=self.dtype, device=w.device)
-                wd = torch.empty((t, ci, cp), dtype=self.dtype, device=w.device)
-                bufs[k] = (wf, wd)
-                entries.append((w.detach(), wf, wd, kind, cop))
-            table, blocks = ops.prep_table(entries, P[names[0]].device)
-            st = self._prep_state = (ptr_key, table, blocks, names, bufs)
+            bufs, groups = {}, []
+            overlap = self.prep_overlap and self.side_wgrad and P[names[0]].is_cuda
+            early = [k for k in names if k.startswith(self._PREP_EARLY)] if overlap else names
+            for grp in (early, [k for k in names if k not in early]):
+                entries = []
+                for k in grp:
+                    w = P[k]
+                    kind = "convT" if k.endswith("transp_conv.weight") else "conv"
+                    cop = 32 if k == "output_block.conv.weight" else None
+                    t, co, ci, _, _ = ops._layout(w.shape, kind)
+                    cp = cop or co
+                    wf = torch.empty((t, cp, ci), dtype=self.dtype, device=w.device)
+                    wd = torch.empty((t, ci, cp), dtype=self.dtype, device=w.device)
+                    bufs[k] = (wf, wd)
+                    entries.append((w.detach(), wf, wd, kind, cop))
+                if entries:
+                    table, blocks = ops.prep_table(entries, P[names[0]].device)
+                    groups.append((table, blocks, len(entries)))
+                else:
+                    groups.append(None)
+            st = self._prep_state = (ptr_key, groups, set(early), names, bufs)
         ver_key = (ops.PARAM_EPOCH[0], tuple(P[k]._version for k in names))
         if getattr(self, "_prep_ver", None) == (ptr_key, ver_key):
             return
-        ops.weight_prep_batch(st[1], len(names), st[2], self.dtype)
+        first, late = st[1]
+        if first is not None:
+            ops.weight_prep_batch(first[0], first[2], first[1], self.dtype)
+        if late is not None:
+            dev = P[names[0]].device
+            main = torch.cuda.current_stream(dev)
+            if self._side is None or self._side.device != dev:
+                self._side = torch.cuda.Stream(dev)
+            self._side.wait_stream(main)         # the optimizer's update, and every earlier reader of the copies
+            with torch.cuda.stream(self._side):
+                ops.weight_prep_batch(late[0], late[2], late[1], self.dtype)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            self._prep_pending = (ev, main, st[2])
         self._prep_ver = (ptr_key, ver_key)
         for k in names:
             wf, wd = st[4][k]

@@ -309,6 +309,8 @@ struct SkewArgs {
 // or two of the four waves busy.  Now a workgroup holds FOUR samples of one frame (the frame record is staged once for the
 // four), each wave runs its sample on its own: scans and reductions are wave shuffles, the contour lives in a register per
 // lane (lane i = flat coordinate i), and after the staging barrier there is no workgroup synchronisation at all.
+constexpr float NARROW_HALF = 36.f;     // grid_sample: the narrow box holds the cells within exp(-36) of the product's peak
+
 __device__ __forceinline__ double wave_scan(double v, int lane) {         // inclusive prefix over the 64 lanes
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -326,7 +328,7 @@ __device__ __forceinline__ double wave_scan(double v, int lane) {         // inc
 // Window of nx rows x ny cells: k = 64 / nx (a power of two) lanes share a row when the window is narrow, each summing every
 // k-th cell of it; wider windows take ceil(nx / 64) passes of one lane per row (grid <= 256: at most 4).
 __device__ bool grid_sample(const Skew2& A, const Gauss2& B, const Gauss2* Cg, float covBxx, float covByy, float covCxx,
-                            float covCyy, int grid, float u, int lane, float& sx, float& sy, bool merged_window) {
+                            float covCyy, int grid, float u, int lane, float& sx, float& sy, int merged_window) {
     const float step = 255.f / (float)(grid - 1), istep = (float)(grid - 1) / 255.f;
     // window where exp(lc - q/2) can be non-zero in f32 (smallest denormal = exp(-103.3)); q >= d1^2 / Sigma_xx
     float L = 2.f * (104.f + fmaxf(B.lc, 0.f));
@@ -338,6 +340,8 @@ __device__ bool grid_sample(const Skew2& A, const Gauss2& B, const Gauss2* Cg, f
         x0 = fmaxf(x0, Cg->mx - rx); x1 = fminf(x1, Cg->mx + rx);
         y0 = fmaxf(y0, Cg->my - ry); y1 = fminf(y1, Cg->my + ry);
     }
+    bool narrow_ok = false;
+    float n_fx = 0.f, n_fy = 0.f, n_rx = 0.f, n_ry = 0.f, n_lcs = 0.f, n_r0 = 0.f;
     if (merged_window) {
         // The Gaussian factors multiply to c N(x; mu_f, P^-1), P = sum of the inverse covariances, and the skew factor
         // 2 (Phi + 1e-7) is at most 2.0000002: in the reference's f32 table p1 * p2 [* p3] (psm_skew.py:96-107) a cell is exactly
@@ -372,65 +376,101 @@ __device__ bool grid_sample(const Skew2& A, const Gauss2& B, const Gauss2* Cg, f
             const float rfx = sqrtf(Lf * Pc * idet), rfy = sqrtf(Lf * Pa * idet);
             x0 = fmaxf(x0, fx - rfx); x1 = fminf(x1, fx + rfx);
             y0 = fmaxf(y0, fy - rfy); y1 = fminf(y1, fy + rfy);
+            if (merged_window > 1 && Lf > 2.f * NARROW_HALF) {
+                narrow_ok = true;
+                n_fx = fx; n_fy = fy; n_lcs = lcs; n_r0 = r0;
+                n_rx = sqrtf(2.f * NARROW_HALF * Pc * idet) + step;      // (+ one cell: the f32 centre and radii)
+                n_ry = sqrtf(2.f * NARROW_HALF * Pa * idet) + step;
+            }
         }
     }
-    const int xlo = max(0, (int)ceilf(x0 * istep)), xhi = min(grid - 1, (int)floorf(x1 * istep));
-    const int ylo = max(0, (int)ceilf(y0 * istep)), yhi = min(grid - 1, (int)floorf(y1 * istep));
-    if (xlo > xhi || ylo > yhi) return false;
-    const int nx = xhi - xlo + 1, ny = yhi - ylo + 1;
+    const int wxlo = max(0, (int)ceilf(x0 * istep)), wxhi = min(grid - 1, (int)floorf(x1 * istep));
+    const int wylo = max(0, (int)ceilf(y0 * istep)), wyhi = min(grid - 1, (int)floorf(y1 * istep));
+    if (wxlo > wxhi || wylo > wyhi) return false;
     auto cell = [&](int ix, int iy) -> double {
         const float x = ix * step, y = iy * step;
         double v = (double)skew_pdf(A, x, y) * (double)gauss_pdf(B, x, y);
         if (Cg) v *= (double)gauss_pdf(*Cg, x, y);
         return v;
     };
-    int k = 1;                                   // lanes per row
-    while (2 * k * nx <= 64) k <<= 1;
-    const int rpp = 64 / k;                      // rows per pass
-    const int sub = lane & (k - 1), rl = lane / k;
-    double rs[4], cum[4];                        // row sum / inclusive prefix of the lane's row in pass p (lanes with sub == 0)
-    double carry = 0.0;
+    // Inverse CDF over the window [xlo, xhi] x [ylo, yhi].  delta > 0: the window is a NARROW box and delta bounds the mass of
+    // the cells left out; the draw is accepted (certain = true) only if no prefix it was compared with lies within delta of the
+    // threshold -- then the full window selects the same cell (see below).
+    auto draw = [&](int xlo, int xhi, int ylo, int yhi, double delta, int& r_out, int& j_out, bool& certain) -> bool {
+        const int nx = xhi - xlo + 1, ny = yhi - ylo + 1;
+        int k = 1;                                   // lanes per row
+        while (2 * k * nx <= 64) k <<= 1;
+        const int rpp = 64 / k;                      // rows per pass
+        const int sub = lane & (k - 1), rl = lane / k;
+        double rs[4], cum[4];                        // row sum / inclusive prefix of the lane's row in pass p (lanes with sub == 0)
+        double carry = 0.0;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        rs[p] = 0.0; cum[p] = 0.0;
-        if (p * rpp >= nx) continue;             // (uniform)
-        const int ri = p * rpp + rl;
-        double acc = 0.0;
-        if (ri < nx)
-            for (int iy = ylo + sub; iy <= yhi; iy += k) acc += cell(xlo + ri, iy);
-        for (int off = 1; off < k; off <<= 1) acc += __shfl_xor(acc, off, 64);
-        rs[p] = (sub == 0 && ri < nx) ? acc : 0.0;
-        cum[p] = carry + wave_scan(rs[p], lane);
-        carry = __shfl(cum[p], 63, 64);
-    }
-    const double total = carry;
-    if (!(total > 0.0) || !(total < 1e300)) return false;
-    const double T = (double)u * total;
-    int r = 0;
+        for (int p = 0; p < 4; ++p) {
+            rs[p] = 0.0; cum[p] = 0.0;
+            if (p * rpp >= nx) continue;             // (uniform)
+            const int ri = p * rpp + rl;
+            double acc = 0.0;
+            if (ri < nx)
+                for (int iy = ylo + sub; iy <= yhi; iy += k) acc += cell(xlo + ri, iy);
+            for (int off = 1; off < k; off <<= 1) acc += __shfl_xor(acc, off, 64);
+            rs[p] = (sub == 0 && ri < nx) ? acc : 0.0;
+            cum[p] = carry + wave_scan(rs[p], lane);
+            carry = __shfl(cum[p], 63, 64);
+        }
+        const double total = carry;
+        if (!(total > 0.0) || !(total < 1e300)) return false;
+        const double T = (double)u * total;
+        const double band = delta > 0.0 ? delta + 1e-12 * total : -1.0;     // (+ the rounding of the double sums)
+        bool near = T <= band;                       // the rows before the window have prefix <= delta
+        int r = 0;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        if (p * rpp >= nx) continue;
-        const bool mine = sub == 0 && p * rpp + rl < nx;
-        r += __popcll(__ballot(mine && cum[p] <= T));
-    }
-    r = min(r, nx - 1);
-    // prefix before row r, from the lane that owns it
-    const int pr = r / rpp, lr = (r - pr * rpp) * k;
-    double mb = 0.0;
+        for (int p = 0; p < 4; ++p) {
+            if (p * rpp >= nx) continue;
+            const bool mine = sub == 0 && p * rpp + rl < nx;
+            r += __popcll(__ballot(mine && cum[p] <= T));
+            near = near || (mine && fabs(cum[p] - T) <= band);
+        }
+        r = min(r, nx - 1);
+        // prefix before row r, from the lane that owns it
+        const int pr = r / rpp, lr = (r - pr * rpp) * k;
+        double mb = 0.0;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) mb = p == pr ? cum[p] - rs[p] : mb;
-    const double base = __shfl(mb, lr, 64);
-    int j = 0;
-    double carry2 = 0.0;
-    for (int p = 0; p * 64 < ny; ++p) {
-        const int iy = ylo + p * 64 + lane;
-        const double v = iy <= yhi ? cell(xlo + r, iy) : 0.0;
-        const double c2 = carry2 + wave_scan(v, lane);
-        carry2 = __shfl(c2, 63, 64);
-        j += __popcll(__ballot(iy <= yhi && base + c2 <= T));
+        for (int p = 0; p < 4; ++p) mb = p == pr ? cum[p] - rs[p] : mb;
+        const double base = __shfl(mb, lr, 64);
+        int j = 0;
+        double carry2 = 0.0;
+        for (int p = 0; p * 64 < ny; ++p) {
+            const int iy = ylo + p * 64 + lane;
+            const double v = iy <= yhi ? cell(xlo + r, iy) : 0.0;
+            const double c2 = carry2 + wave_scan(v, lane);
+            carry2 = __shfl(c2, 63, 64);
+            j += __popcll(__ballot(iy <= yhi && base + c2 <= T));
+            near = near || (iy <= yhi && fabs(base + c2 - T) <= band);
+        }
+        j = min(j, ny - 1);
+        r_out = xlo + r; j_out = ylo + j;
+        certain = __ballot(near) == 0;
+        return true;
+    };
+    int r = 0, j = 0;
+    bool certain = false;
+    if (narrow_ok) {
+        // Narrow box first.  N = bounding box of the ellipse (x - mu_f)^T P (x - mu_f) <= 2 NARROW_HALF: a cell of the full window W
+        // outside N is outside the ellipse, so it is at most vmax = 2.0000002 exp(sum lc_i - r0 / 2 - NARROW_HALF), and the mass
+        // left out is at most delta = |W| vmax.  With total_W = total_N + tail, 0 <= tail <= delta: the threshold u total moves up
+        // by at most delta, and so does every prefix (the mass before a cell in the flat order gains the part of the tail that
+        // precedes it).  A comparison `prefix <= threshold` can therefore only change if prefix_N is within delta of threshold_N;
+        // when none is -- rows, the cells of the selected row, and the empty prefix of the rows before N -- the full window draws
+        // the same cell.  Otherwise (u within ~1e-11 of a cell boundary) the full window is evaluated.
+        const double vmax = 2.0000002 * exp((double)n_lcs - 0.5 * (double)n_r0 - (double)NARROW_HALF);
+        const double delta = (double)(wxhi - wxlo + 1) * (double)(wyhi - wylo + 1) * vmax;
+        const int nxlo = max(wxlo, (int)ceilf((n_fx - n_rx) * istep)), nxhi = min(wxhi, (int)floorf((n_fx + n_rx) * istep));
+        const int nylo = max(wylo, (int)ceilf((n_fy - n_ry) * istep)), nyhi = min(wyhi, (int)floorf((n_fy + n_ry) * istep));
+        if (nxlo <= nxhi && nylo <= nyhi && delta > 0.0)
+            if (!draw(nxlo, nxhi, nylo, nyhi, delta, r, j, certain)) certain = false;
     }
-    j = min(j, ny - 1);
-    sx = (xlo + r) * step; sy = (ylo + j) * step;
+    if (!certain && !draw(wxlo, wxhi, wylo, wyhi, 0.0, r, j, certain)) return false;
+    sx = r * step; sy = j * step;
     return true;
 }
 
@@ -521,7 +561,7 @@ __global__ __launch_bounds__(ST) void psm_skew_kernel(const SkewArgs p) {
             const int pt = p.init_pts[i];
             float sx, sy;
             const bool ok = grid_sample(skA[pt], gC[pt], nullptr, cvC[wave][pt][0], cvC[wave][pt][1], 0.f, 0.f, p.grid,
-                                        uniform(pt), lane, sx, sy, p.merged_window != 0);
+                                        uniform(pt), lane, sx, sy, p.merged_window);
             set_point(pt, ok ? sx : gC[pt].mx, ok ? sy : gC[pt].my);
         }
     }
@@ -556,7 +596,7 @@ __global__ __launch_bounds__(ST) void psm_skew_kernel(const SkewArgs p) {
                 const Gauss2 B = make_gauss(mcx, mcy, cc[0], cc[3], cc[2]);
                 float sx, sy;
                 const bool ok = grid_sample(skA[pt], B, p.prior_mu ? &gC[pt] : nullptr, cc[0], cc[3], cvC[wave][pt][0],
-                                            cvC[wave][pt][1], p.grid, uniform(pt), lane, sx, sy, p.merged_window != 0);
+                                            cvC[wave][pt][1], p.grid, uniform(pt), lane, sx, sy, p.merged_window);
                 set_point(pt, ok ? sx : mcx, ok ? sy : mcy);
             } else {                 // Gaussian point: product-of-Gaussians merge + draw (psm.py:424-440, 387-421)
                 const float a1 = cv_f[3 * pt], b1 = cv_f[3 * pt + 1], c1 = cv_f[3 * pt + 2];
@@ -711,7 +751,7 @@ extern "C" int cu_psm_sample_skew(int F, int S, int K, const float* mu_pred, con
     a.eps = eps; a.u = u; a.out = out; a.F = F; a.S = S; a.K = K; a.n_init = n_init; a.n_levels = n_levels;
     a.grid = grid; a.use_initial_pdf = use_initial_pdf; a.skew_bits = skew_bits; a.alpha_y_sign = alpha_y_sign;
     a.seed = seed;
-    a.merged_window = cu_env_int("CU_PSM_MERGED_WINDOW", 1);
+    a.merged_window = cu_env_int("CU_PSM_MERGED_WINDOW", 2);     // 0: conditional Gaussian's window, 1: + product, 2: + narrow box first
     for (int i = 0; i < n_init; ++i) a.init_pts[i] = init_pts[i];
     for (int l = 0; l < n_levels; ++l) a.sample_level[l] = sample_level[l];
     const size_t lds = sizeof(float) * (size_t)rec_stride;

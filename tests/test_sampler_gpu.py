@@ -321,3 +321,57 @@ def test_sequence_skew_sampler_matches_oracle(golden_dir):
     assert float((d < 0.05).double().mean()) >= 0.75 and float(d.max()) < 8.0, (d,)
     o = smp(mu.cuda(), cov.cuda(), alpha.cuda(), n=4)
     assert o.shape == (2, 4, 21, 2) and torch.isfinite(o).all()
+
+
+def test_skew_sampler_falls_back_to_the_conditional_mean_when_the_f32_table_has_no_mass(golden_dir):
+    """psm_skew.py:96-107,135-154: the reference multiplies its f32 tables; when prediction and PSM conditional disagree by
+    ~14 sigma every product underflows, torch.multinomial raises and the point becomes mu_c.  The kernel evaluates the cells in
+    double (nothing underflows there), so the window of the product decides: cells below the f32 denormal range are skipped and an
+    empty window is the reference's fallback.  Teacher-forced on the kernel's own earlier picks, wide anisotropic prediction
+    covariances (profiles/r04_sampler_wave_per_sample.txt: the round 1-3 kernel drew from 1e-50-mass tables here)."""
+    from contour_uncertainty.sampler.posterior_shape_model.psm_skew import SkewPosteriorShapeModelSampler
+    psm = dict(np.load(golden_dir / "camus-cont_psm_11_no_std.npz"))
+    F, n = 8, 48
+    g = torch.Generator().manual_seed(100)
+    idx = torch.randint(0, psm["X_val"].shape[0], (F,), generator=g)
+    mu = torch.stack([torch.tensor(psm["X_val"][i] + psm["scaler_mean"]).float().reshape(21, 2) for i in idx.tolist()])
+    a = torch.randn(F, 21, 2, 2, generator=g)
+    cov = a @ a.transpose(-1, -2) * 40.0 + torch.eye(2) * 2.0
+    alpha = torch.randn(F, 21, 2, generator=g) * 2.0
+    eps = torch.randn(F, n, 21, 3, generator=g)
+    u = torch.rand(F, n, 21, generator=g)
+    smp = SkewPosteriorShapeModelSampler(golden_dir / "camus-cont_psm_11_no_std.npz")
+    out = smp.sample_batch(mu.cuda(), cov.cuda(), alpha.cuda(), n=n, eps=eps, u=u).cpu()
+    fell_back = drew = 0
+    with _F64():
+        orc = S.SkewPSMSamplerOracle(psm, dtype=torch.float64)
+        al = alpha.double() * torch.tensor([1.0, -1.0])
+        for b in (2, 5):
+            pca_mu, Q = S.pca(orc.X_train, orc.transform(mu[b].double()).reshape(-1, 1))
+            pdfs = [torch.exp(S.skew_logpdf(orc.grid_points, mu[b, j].double(), cov[b, j].double(), al[b, j])).float()
+                    for j in range(21)]
+            for i in range(n):
+                contour = out[b, i].double()
+                sampled = list(orc.initial_points)
+                known = torch.zeros(21, 2)
+                known[sampled] = contour[sampled]
+                for points in orc.points_order:
+                    sampled.sort()
+                    if len(sampled) == 21:
+                        break
+                    mu_c, cov_c = orc.compute_psm(known, sampled, 1, pca_mu, Q)
+                    for j in points:
+                        if j not in orc.skew_indices:
+                            continue
+                        mass = float((pdfs[j] * S.mvn_pdf(orc.grid_points, mu_c[j], cov_c[j]).float()).sum())
+                        on_grid = bool((contour[j] == contour[j].round()).all())
+                        if mass == 0.0:
+                            fell_back += 1
+                            assert float((contour[j] - mu_c[j]).abs().max()) < 5e-3, (b, i, j, contour[j], mu_c[j])
+                        elif mass > 1e-30:
+                            drew += 1
+                            assert on_grid, (b, i, j, contour[j], mass)
+                    for j in points:
+                        known[j] = contour[j]
+                    sampled.extend(points)
+    assert fell_back >= 3 and drew > 20 * fell_back, (fell_back, drew)

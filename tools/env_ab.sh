@@ -1,4 +1,4 @@
-# usage: bash tools/_ab.sh ENVVAR "vals..." ; alternating bench runs on one box
+# usage: bash tools/env_ab.sh ENVVAR "vals..." ; alternating bench runs on one box
 V=$1; shift
 F="--no-cpu-baseline --no-parity --no-roofline --steps 200 --warmup 30"
 for rep in 1 2 3; do for val in $@; do

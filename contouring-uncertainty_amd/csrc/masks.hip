@@ -50,23 +50,29 @@ __device__ __forceinline__ Row fill_both(const Row& r, const Row& m) {
     return row_or(up, dn);
 }
 
-// thread c gathers column c of a bitmap stored as rows of 8 x u32 in LDS (bit x of row y = pixel (y, x)); rows >= nrows
-// must hold zeros or be masked by the caller
-__device__ __forceinline__ Row gather_column(const unsigned* bm, int c) {
-    Row o;
-    const unsigned* src = bm + (c >> 5);
-    const unsigned sh = c & 31;
+// transpose of a 256 x 256 bitmap stored as rows of 8 x u32 in LDS (bit x of row y = pixel (y, x)): dst row x, bit y = src row
+// y, bit x.  All MT = 256 threads; the caller puts a barrier before (src complete) and after (dst complete).  A 32-lane half
+// wave holds a 32 x 32 bit block, lane i = row i, and transposes it with five exchange steps (rows i and i ^ j swap their
+// off-diagonal j x j blocks: __shfl_xor stays inside the half wave); 64 blocks = 8 rounds of the 8 half waves.  (The first
+// version had thread c gather column c bit by bit: 256 LDS reads + extracts per thread and transposition, three to seven
+// transpositions per mask -- most of the kernel's time.)
+template <int J, unsigned L> __device__ __forceinline__ unsigned tstep(unsigned x, int i) {
+    const unsigned other = (unsigned)__shfl_xor((int)x, J, 64);
+    return (i & J) ? ((x & ~L) | ((other & ~L) >> J)) : ((x & L) | ((other & L) << J));
+}
+__device__ __forceinline__ void transpose_bitmap(const unsigned* src, unsigned* dst, int tid) {
+    const int half = tid >> 5, i = tid & 31;           // 8 half waves
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        unsigned lo = 0, hi = 0;
-#pragma unroll
-        for (int y = 0; y < 32; ++y) {
-            lo |= __builtin_amdgcn_ubfe(src[(64 * q + y) * 8], sh, 1u) << y;
-            hi |= __builtin_amdgcn_ubfe(src[(64 * q + 32 + y) * 8], sh, 1u) << y;
-        }
-        o.w[q] = (u64)lo | ((u64)hi << 32);
+    for (int t = 0; t < 8; ++t) {
+        const int b = t * 8 + half, by = b >> 3, bx = b & 7;
+        unsigned x = src[(32 * by + i) * 8 + bx];
+        x = tstep<16, 0x0000ffffu>(x, i);
+        x = tstep<8, 0x00ff00ffu>(x, i);
+        x = tstep<4, 0x0f0f0f0fu>(x, i);
+        x = tstep<2, 0x33333333u>(x, i);
+        x = tstep<1, 0x55555555u>(x, i);
+        dst[(32 * bx + i) * 8 + by] = x;
     }
-    return o;
 }
 __device__ __forceinline__ double bcast(double v, int lane) {      // lane is wave-uniform
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
@@ -295,8 +301,10 @@ __global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, c
         store_row(bmA, tid, freeR);
     }
     __syncthreads();
+    transpose_bitmap(bmA, bmB, tid);
+    __syncthreads();
     Row freeC{{0, 0, 0, 0}};
-    if (tid < W) freeC = row_and(gather_column(bmA, tid), hmask);
+    if (tid < W) freeC = row_and(load_row(bmB, tid), hmask);
     __syncthreads();
     // rows >= H of bmA and rows >= W of bmB stay zero from here on (threads >= H / >= W store empty rows)
     for (int iter = 0; iter < ((dbg & 2) ? 0 : 64); ++iter) {
@@ -307,10 +315,14 @@ __global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, c
         if (iter > 0 && !grew) break;
         store_row(bmA, tid, reach);
         __syncthreads();
-        Row col = fill_both(row_and(gather_column(bmA, tid), freeC), freeC);
-        store_row(bmB, tid, col);
+        transpose_bitmap(bmA, bmB, tid);
         __syncthreads();
-        reach = row_and(gather_column(bmB, tid), freeR);
+        Row col = fill_both(row_and(load_row(bmB, tid), freeC), freeC);
+        store_row(bmB, tid, col);            // (a thread's own row: the only one it read)
+        __syncthreads();
+        transpose_bitmap(bmB, bmA, tid);
+        __syncthreads();
+        reach = row_and(load_row(bmA, tid), freeR);
     }
     // ---- mask = everything the flood did not reach
     if (tid < H) {

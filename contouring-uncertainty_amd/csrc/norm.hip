@@ -1207,7 +1207,7 @@ static int launch_apply(int nimg, int N, int HW, int C, const void* z, const flo
 template <typename T>
 static int launch_bwd(int nimg, int N, int HW, int C, void* g, const void* z, const float* stats, const float* gamma,
                       float slope, float* dgamma, float* dbeta, float* dbias, float* ws, hipStream_t st, bool clean = false,
-                      bool det = false, int pstride = 0) {
+                      bool det = false, int pstride = 0, bool small_res = false) {
     constexpr int PIECE = Elem<T>::PIECE;
     const RowMap rm = row_map(C, PIECE);
     CU_CHECK_ARG(!pstride || (HW <= 1024 && !det), "CU_NORM_PARAM_PARTS is served on maps of <= 1024 pixels (got %d)", HW);
@@ -1215,8 +1215,13 @@ static int launch_bwd(int nimg, int N, int HW, int C, void* g, const void* z, co
         dim3 sgrid(nimg, cdiv(C / PIECE, SG));
         if constexpr (sizeof(T) == 2) {
             const dim3 sgrid4(nimg, cdiv(C / PIECE, 4));
-            // 16 x 16 and 32 x 32 maps in bf16: the register-resident form (both tensors read once)
-            if (!dbias && (HW == 256 || HW == 1024) && !cu_env_set("CU_NORM_NO_SMALL_RES")) {
+            // 16 x 16 and 32 x 32 maps in bf16: the register-resident form (both tensors read once): CU_NORM_SMALL_RES.  Alone it
+            // takes 32-35 us instead of 48 (32 x 32) and 20 instead of 30 (16 x 16); inside the training step, beside the weight-
+            // gradient stream, its 512-thread x 214-VGPR workgroups (one per CU) cost more than they save: 12.45 vs 12.40 ms per
+            // step over six alternating pairs (profiles/r04_norm_small_res_in_step.txt) -- the engine does not ask for it.
+            // (tuning build: CU_NORM_SMALL_RES_MASK = 1: 16 x 16, 2: 32 x 32, 3: both, whatever the caller asked)
+            const int res_mask = cu_env_int("CU_NORM_SMALL_RES_MASK", small_res ? 3 : 0);
+            if (!dbias && ((HW == 256 && (res_mask & 1)) || (HW == 1024 && (res_mask & 2)))) {
                 if (HW == 256)
                     hipLaunchKernelGGL((bwd_small_res_kernel<4, 512>), sgrid, dim3(512), 0, st, (bf16_t*)g, (const bf16_t*)z, stats,
                                        gamma, slope, dgamma, dbeta, N, HW, C, pstride);
@@ -1412,7 +1417,8 @@ extern "C" int cu_instnorm_bwd_fused(int dtype, int N, int HW, int C, void* g, c
     const bool clean = (mode & CU_NORM_WS_CLEAN) != 0;       // the caller hands over a zeroed workspace: no memset launch
     const bool det = (mode & CU_NORM_DETERMINISTIC) != 0;
     const bool parts = (mode & CU_NORM_PARAM_PARTS) != 0;    // dgamma / dbeta are per-image planes [N][C] (maps of <= 1024 pixels)
-    mode &= ~(CU_NORM_WS_CLEAN | CU_NORM_DETERMINISTIC | CU_NORM_PARAM_PARTS);
+    const bool small_res = (mode & CU_NORM_SMALL_RES) != 0;  // register-resident kernels at 16 x 16 / 32 x 32 (bf16)
+    mode &= ~(CU_NORM_WS_CLEAN | CU_NORM_DETERMINISTIC | CU_NORM_PARAM_PARTS | CU_NORM_SMALL_RES);
     CU_CHECK_ARG(mode >= 0 && mode <= 2, "cu_instnorm_bwd_fused: mode %d", mode);
     CU_CHECK_ARG(!parts || (HW <= 1024 && !det && mode != 1), "cu_instnorm_bwd_fused: CU_NORM_PARAM_PARTS needs a map of <= 1024 pixels, "
                  "not the resident or the deterministic form");
@@ -1441,8 +1447,8 @@ extern "C" int cu_instnorm_bwd_fused(int dtype, int N, int HW, int C, void* g, c
         float* dgp = parts && dgamma ? dgamma + (size_t)n0 * C : dgamma;          // per-image planes follow the image group
         float* dbp = parts && dbeta ? dbeta + (size_t)n0 * C : dbeta;
         const int rc = dtype == CU_BF16
-            ? launch_bwd<bf16_t>(ni, N, HW, C, gp, zp, sp, gamma, slope, dgp, dbp, nullptr, ws + (size_t)n0 * C * 2, st, clean, det, parts ? C : 0)
-            : launch_bwd<float>(ni, N, HW, C, gp, zp, sp, gamma, slope, dgp, dbp, nullptr, ws + (size_t)n0 * C * 2, st, clean, det, parts ? C : 0);
+            ? launch_bwd<bf16_t>(ni, N, HW, C, gp, zp, sp, gamma, slope, dgp, dbp, nullptr, ws + (size_t)n0 * C * 2, st, clean, det, parts ? C : 0, small_res)
+            : launch_bwd<float>(ni, N, HW, C, gp, zp, sp, gamma, slope, dgp, dbp, nullptr, ws + (size_t)n0 * C * 2, st, clean, det, parts ? C : 0, small_res);
         if (rc) return rc;
     }
     if (det && (dgamma || dbeta)) {

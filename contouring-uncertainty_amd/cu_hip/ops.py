@@ -390,6 +390,7 @@ def _resident_ws(n: int, c: int, device) -> Tensor:
 NORM_WS_CLEAN = 16     # include/contour_hip.h: CU_NORM_WS_CLEAN
 NORM_DETERMINISTIC = 32    # CU_NORM_DETERMINISTIC: one workgroup per image, fixed summation order
 NORM_PARAM_PARTS = 64      # CU_NORM_PARAM_PARTS: dgamma / dbeta are per-image planes [N][C] (maps of <= 1024 pixels)
+NORM_SMALL_RES = 128       # CU_NORM_SMALL_RES: register-resident 16x16 / 32x32 backward (opt-in: slower beside the weight-gradient stream)
 
 
 def norm_param_parts_ok(n: int, hw: int) -> bool:

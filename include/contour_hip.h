@@ -234,6 +234,10 @@ int cu_instnorm_lrelu_bwd(int dtype, int N, int HW, int C, void* g, const void* 
  * [N][C] that the launch WRITES (one workgroup owns an (image, channel): no atomics, fixed result); the caller adds the
  * images with cu_norm_param_grads_batch -- every layer of a backward pass in one launch. */
 #define CU_NORM_PARAM_PARTS 64
+/* + CU_NORM_SMALL_RES (cu_instnorm_bwd_fused, bf16, maps of 16 x 16 and 32 x 32): the register-resident form -- g and z read once,
+ * a workgroup of 512 threads owns whole (image, 32- or 64-channel) planes.  Faster as a lone launch (20 / 33 us against 30 / 48 at
+ * batch 64), slower inside a step whose weight gradients run beside it (profiles/r04_norm_small_res_in_step.txt): opt-in. */
+#define CU_NORM_SMALL_RES 128
 typedef struct {
     const float* dgamma_parts;     /* [N][C] or NULL */
     const float* dbeta_parts;      /* [N][C] or NULL */

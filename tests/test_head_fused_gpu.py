@@ -240,9 +240,12 @@ def _worst(ga, gb):
 @pytest.mark.parametrize("skew,stages", [(False, 4), (True, 6)])
 def test_training_step_fused_head_equals_unfused(skew, stages):
     """the training step through UNet.fused_head() (placeholder logits) against the same step with the switch off: same
-    loss and logs; parameter gradients within the step's own run-to-run spread (the default mode's f32 atomics can flip a
-    LeakyReLU decision at the 2x2 / 4x4 levels and the network amplifies that: tens of percent at 6 stages and random
-    initialisation; ~9 % at 4 stages).  The tight comparisons are the kernel-level tests above."""
+    loss and logs, same parameter gradients.  Run to run the default mode is not bit-reproducible (f32 atomics in the
+    statistics), and at 6 stages / random initialisation one flipped LeakyReLU decision at the 2x2 level moves EVERY gradient
+    by 13-38 % -- the runs fall into a few clusters, whatever the switch (tools output in profiles/r04_fused_step_clusters.txt:
+    a fused and an unfused run 1.7 % apart, two fused runs 18 % apart).  A wiring error of the fused path would separate the
+    two modes in every pair; so: up to five runs per mode, and SOME fused run must agree with SOME unfused run to 3 %.
+    The tight comparisons are the kernel-level tests above."""
     from contour_uncertainty.data.synthetic import synthetic_batch
     torch.manual_seed(0)
     task = _task(stages=stages, skew=skew)
@@ -250,8 +253,6 @@ def test_training_step_fused_head_equals_unfused(skew, stages):
     batch = {"img": img.to(DEV), "contour": contour.to(DEV)}
     logs1, g1 = _grads(task, batch, True)
     logs0, g0 = _grads(task, batch, False)
-    _, g0b = _grads(task, batch, False)
-    _, g1b = _grads(task, batch, True)
     assert set(logs1) == set(logs0)
     for k in logs0:
         assert abs(logs1[k] - logs0[k]) <= 5e-4 * max(1.0, abs(logs0[k])), (k, logs1[k], logs0[k])
@@ -259,8 +260,13 @@ def test_training_step_fused_head_equals_unfused(skew, stages):
     for n in g0:
         if float(g0[n].norm()) < 1e-12:
             assert float(g1[n].norm()) < 1e-10, n
-    floor = max(_worst(g0b, g0), _worst(g1b, g1))
-    assert _worst(g1, g0) <= max(3e-2, 2.0 * floor), (_worst(g1, g0), floor)
+    fused, unfused = [g1], [g0]
+    best = _worst(g1, g0)
+    while best > 3e-2 and len(fused) < 5:
+        fused.append(_grads(task, batch, True)[1])
+        unfused.append(_grads(task, batch, False)[1])
+        best = min(_worst(a, b) for a in fused for b in unfused)
+    assert best <= 3e-2, (best, len(fused))
     # the fused forward really was taken: its head handle exists only then
     task.model.engine.fused_head = True
     with task.model.fused_head():

@@ -1049,3 +1049,33 @@ def test_wide_conv_gathers_the_norm_statistics(case):
     out = ops.instnorm_fwd_given(z, gamma, beta, 0.01, sums, b)
     refa = F.leaky_relu(F.instance_norm(nchw(z).float(), weight=gamma, bias=beta, eps=1e-5), 0.01)
     assert rel_err(nchw(out.a), refa) < tol(dtype)
+
+
+@pytest.mark.parametrize("size,c,n", [(16, 480, 6), (32, 256, 5), (16, 64, 3), (32, 96, 2)])
+@pytest.mark.parametrize("parts", [False, True])
+def test_instnorm_bwd_small_resident_form_equals_the_default(size, c, n, parts):
+    """CU_NORM_SMALL_RES (register-resident 16x16 / 32x32 backward, bf16; opt-in since round 4: faster alone, slower inside the
+    step) against the default two-pass small-map kernel: same dz, same dgamma / dbeta -- summed over the images by atomics or
+    left as per-image planes for cu_norm_param_grads_batch (CU_NORM_PARAM_PARTS)."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(31)
+    z = torch.randn(n, size, size, c, device=DEV, generator=g).to(torch.bfloat16)
+    gin = torch.randn(n, size, size, c, device=DEV, generator=g).to(torch.bfloat16)
+    gamma = torch.rand(c, device=DEV, generator=g) + 0.5
+    beta = torch.randn(c, device=DEV, generator=g) * 0.2
+    act = ops.instnorm_fwd_fused(z, gamma, beta, 0.01, 1e-5)
+    res = []
+    for flag in (0, ops.NORM_SMALL_RES):
+        dz = gin.clone()
+        if parts:
+            planes = torch.zeros(2, n, c, device=DEV)
+            ops.instnorm_bwd_fused(dz, act, gamma, planes[0], planes[1], mode=2 | ops.NORM_PARAM_PARTS | flag)
+            dg, db = planes[0].sum(0), planes[1].sum(0)
+        else:
+            dg, db = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+            ops.instnorm_bwd_fused(dz, act, gamma, dg, db, mode=2 | flag)
+        res.append((dz.float(), dg, db))
+    torch.cuda.synchronize()
+    (dz0, dg0, db0), (dz1, dg1, db1) = res
+    assert rel_err(dz1, dz0) < 8e-3                       # both round dz to bf16 once; the sums differ in the last f32 bits
+    assert rel_err(dg1, dg0) < 1e-5 and rel_err(db1, db0) < 1e-5

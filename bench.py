@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import contextlib
 import os
 import sys
 import time
@@ -353,16 +354,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        out = step(i)
-    fence()
-    if rank == 0:
-        print(f"[bench] warm-up done, timing {args.steps} steps ...", file=sys.stderr, flush=True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
-    fence()
-    dt = time.perf_counter() - t0
+    # experiment knob (profiles/r04_stream_priority.txt): run the step's main stream at another HIP stream priority
+    main_ctx = contextlib.nullcontext()
+    if os.environ.get("CONTOUR_MAIN_PRIORITY"):
+        main_ctx = torch.cuda.stream(torch.cuda.Stream(dev, priority=int(os.environ["CONTOUR_MAIN_PRIORITY"])))
+    with main_ctx:
+        for i in range(args.warmup):
+            out = step(i)
+        fence()
+        if rank == 0:
+            print(f"[bench] warm-up done, timing {args.steps} steps ...", file=sys.stderr, flush=True)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = step(i)
+        fence()
+        dt = time.perf_counter() - t0
     loss = float(out["loss"].detach())
     if world > 1:
         t = torch.tensor([dt], device=dev)

@@ -193,6 +193,7 @@ class UNetEngine:
         # only meet in dz, and each family's prologue / atomics tail is filled by the other's workgroups
         self.side_wgrad = os.environ.get("CONTOUR_SIDE_WGRAD", "1") != "0"
         self._side: Optional[torch.cuda.Stream] = None
+        self._side_priority = int(os.environ.get("CONTOUR_SIDE_PRIORITY", "0"))
         self._side_keep: List[Tensor] = []
         # weight-gradient launches may trail the input-gradient chain by `wgrad_lag` layers (round 4 experiment): issued at once,
         # the weight gradient of a level runs beside the input gradient of the SAME level -- both HBM-bound at 256^2 / 128^2,
@@ -260,7 +261,7 @@ class UNetEngine:
             dev = P[names[0]].device
             main = torch.cuda.current_stream(dev)
             if self._side is None or self._side.device != dev:
-                self._side = torch.cuda.Stream(dev)
+                self._side = torch.cuda.Stream(dev, priority=self._side_priority)
             self._side.wait_stream(main)         # the optimizer's update, and every earlier reader of the copies
             with torch.cuda.stream(self._side):
                 ops.weight_prep_batch(late[0], late[2], late[1], self.dtype)
@@ -489,7 +490,7 @@ class UNetEngine:
             return contextlib.nullcontext()
         dev = reads[0].device
         if self._side is None or self._side.device != dev:
-            self._side = torch.cuda.Stream(dev)     # (a higher / lower stream priority changed nothing: 15.4-15.6 ms)
+            self._side = torch.cuda.Stream(dev, priority=self._side_priority)     # (priorities: profiles/r04_stream_priority.txt)
         self._side.wait_stream(torch.cuda.current_stream(dev))
         self._side_keep.extend(reads)
         return torch.cuda.stream(self._side)
@@ -510,7 +511,7 @@ class UNetEngine:
         ev, reads, fn = self._lagq.pop(0)
         dev = reads[0].device
         if self._side is None or self._side.device != dev:
-            self._side = torch.cuda.Stream(dev)
+            self._side = torch.cuda.Stream(dev, priority=self._side_priority)
         self._side.wait_event(ev)
         self._side_keep.extend(reads)
         with torch.cuda.stream(self._side):

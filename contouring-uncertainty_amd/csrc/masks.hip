@@ -100,29 +100,35 @@ __device__ __forceinline__ Row low_bits(int n) {      // bits [0, n)
     return r;
 }
 
-__global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, const float* __restrict__ contours,
+__global__ __launch_bounds__(MT) void contour_mask_kernel(int M, int K, int H, int W, const float* __restrict__ contours,
                                                           int round_landmarks, int mode, unsigned* __restrict__ packed,
                                                           unsigned char* __restrict__ bytes, int dbg,
                                                           int* __restrict__ area_out = nullptr,
                                                           float* __restrict__ length_out = nullptr) {
+    // A workgroup takes CPW = 4 consecutive contours (round 4): the spline set-up is a serial chain on ONE wave (chord lengths,
+    // a 21-step banded elimination and back-substitution with f64 divisions: ~10 us of latency), so the four waves run the four
+    // set-ups side by side; drawing, filling and output then take the contours one after the other with all 256 threads.
+    constexpr int CPW = MT / 64;
     __shared__ unsigned bmA[MT * 8];        // the drawn curve, then the reached background (rows)
     __shared__ unsigned bmB[MT * 8];        // transposed bitmaps
-    __shared__ double px[MAXK], py[MAXK], u[MAXK], t[MAXK + 4], cx[MAXK], cy[MAXK];
-    __shared__ int fallback;
+    __shared__ double px_s[CPW][MAXK], py_s[CPW][MAXK], u_s[CPW][MAXK], t_s[CPW][MAXK + 4], cx_s[CPW][MAXK], cy_s[CPW][MAXK];
+    __shared__ int fallback_s[CPW];
     const int tid = threadIdx.x;
-    const size_t m = blockIdx.x;
-    const float* pts = contours + m * K * 2;
-    for (int i = tid; i < MT * 8; i += MT) bmA[i] = 0u;
-    if (tid < K) {
-        float x = pts[2 * tid], y = pts[2 * tid + 1];
+    const size_t base = (size_t)blockIdx.x * CPW;
+    const int sc = tid >> 6, sl = tid & 63;                  // set-up: wave sc works on contour base + sc, lane sl
+    const bool shas = base + sc < (size_t)M;
+    double *px = px_s[sc], *py = py_s[sc], *u = u_s[sc], *t = t_s[sc], *cx = cx_s[sc], *cy = cy_s[sc];
+    if (shas && sl < K) {
+        const float* pts = contours + (base + sc) * K * 2;
+        float x = pts[2 * sl], y = pts[2 * sl + 1];
         if (round_landmarks) { x = rintf(x); y = rintf(y); }      // numpy round: half to even
-        px[tid] = x; py[tid] = y;
+        px[sl] = x; py[sl] = y;
     }
     __syncthreads();
 
-    // ---- FITPACK interpolation set-up by wave 0, lane i = landmark i (K <= 32)
-    if (tid < 64) {
-        const int i = tid;
+    // ---- FITPACK interpolation set-up, one wave per contour, lane i = landmark i (K <= 32)
+    if (shas) {
+        const int i = sl;
         double d = 1.0;
         if (i >= 1 && i < K) d = sqrt((px[i] - px[i - 1]) * (px[i] - px[i - 1]) + (py[i] - py[i - 1]) * (py[i] - py[i - 1]));
         const int bad = (K < 4 || __ballot(!(d > 0.0)) != 0) ? 1 : 0;
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, c
             if (i == j) ui = tot;
         }
         ui = i == K - 1 ? 1.0 : ui / tot;
-        if (i == 0) fallback = bad | (dbg & 1);
+        if (i == 0) fallback_s[sc] = bad | (dbg & 1);
         if (!bad) {
             if (i < K) u[i] = ui;
             if (i < 4) { t[i] = 0.0; t[K + i] = 1.0; }
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, c
     }
     __syncthreads();
     // non-zero cubic B-splines at x: span l (t[l] <= x < t[l+1], clamped to [3, K-1]), values N[0..3] of B_{l-3..l}
-    auto basis = [&](double x, double (&N)[4]) -> int {
+    auto basis_t = [&](const double* t, double x, double (&N)[4]) -> int {
         int l = 3;
         while (l < K - 1 && x >= t[l + 1]) ++l;
         N[0] = 1.0; N[1] = N[2] = N[3] = 0.0;
@@ -161,10 +167,11 @@ __global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, c
         }
         return l - 3;
     };
-    // collocation solve in wave 0: lane i holds row i of the band, B[d] = A(i, i - 3 + d).  Gaussian elimination without
+    auto basis = [&](double x, double (&N)[4]) -> int { return basis_t(t, x, N); };
+    // collocation solve, one wave per contour: lane i holds row i of the band, B[d] = A(i, i - 3 + d).  Gaussian elimination without
     // pivoting (the collocation matrix of an interpolating spline is totally positive); the pivot row travels by readlane.
-    if (tid < 64 && !fallback) {
-        const int i = tid;
+    if (shas && !fallback_s[sc]) {
+        const int i = sl;
         double B[7] = {0, 0, 0, 0, 0, 0, 0}, rx = 0.0, ry = 0.0;
         if (i < K) {
             double N[4];
@@ -198,6 +205,16 @@ __global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, c
     }
     __syncthreads();
 
+    for (int c = 0; c < CPW; ++c) {        // ---- the contours of the workgroup, one after the other, all threads
+    const size_t m = base + c;
+    if (m >= (size_t)M) break;
+    double *px = px_s[c], *py = py_s[c], *t = t_s[c], *cx = cx_s[c], *cy = cy_s[c];
+    const int fallback = fallback_s[c];
+    auto basis = [&](double x, double (&N)[4]) -> int { return basis_t(t, x, N); };
+    __syncthreads();                       // the previous contour's bitmaps have been read
+    for (int i = tid; i < MT * 8; i += MT) bmA[i] = 0u;
+    __syncthreads();
+
     // ---- clinical measure (cu_contour_measures): length of the open polyline through contour_spline's 1001 points
     // (reference utils/clinical.py:31-72 `perimeter` / `global_longitudinal_strain`; utils/contour.py:9-25: n = 1001, the raw
     // landmarks when splprep raises), summed in f64; per-thread partial sums combined in thread order (deterministic)
@@ -228,7 +245,7 @@ __global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, c
             for (int i = 0; i < MT; ++i) tot += lpart[i];
             length_out[m] = (float)tot;
         }
-        if (!packed && !bytes && !area_out) return;
+        if (!packed && !bytes && !area_out) continue;
     }
 
     // ---- draw: 1000 spline points (or the raw landmarks), upper clip, negative indices wrap once like numpy
@@ -284,7 +301,7 @@ __global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, c
                 o[i] = (bmA[y * 8 + (x >> 5)] >> (x & 31)) & 1u;
             }
         }
-        return;
+        continue;
     }
     // ---- binary_fill_holes: flood the background from outside the image (4-connectivity), bit-parallel
     const Row wmask = low_bits(W), hmask = low_bits(H);
@@ -367,6 +384,7 @@ __global__ __launch_bounds__(MT) void contour_mask_kernel(int K, int H, int W, c
             }
         }
     }
+    }      // contours of the workgroup
 }
 
 // mean over S samples of the packed masks of every frame and its binary entropy (base 2; 0 where the mean is 0 or 1).
@@ -450,7 +468,7 @@ extern "C" int cu_contour_masks(int M, int K, int H, int W, const float* contour
     CU_CHECK_ARG(M > 0 && K >= 2 && K <= MAXK && H > 0 && H <= MT && W > 0 && W <= MT, "cu_contour_masks: bad sizes M=%d K=%d H=%d W=%d", M, K, H, W);
     CU_CHECK_ARG(contours && (packed || bytes), "cu_contour_masks: null pointer");
     static const int dbg = cu_env_int("CU_MASKS_DBG", 0);      // timing aid (tools/masks_bench.py)
-    hipLaunchKernelGGL(contour_mask_kernel, dim3(M), dim3(MT), 0, reinterpret_cast<hipStream_t>(stream), K, H, W, contours,
+    hipLaunchKernelGGL(contour_mask_kernel, dim3((M + 3) / 4), dim3(MT), 0, reinterpret_cast<hipStream_t>(stream), M, K, H, W, contours,
                        round_landmarks, mode, packed, bytes, dbg);
     CU_LAUNCH_CHECK();
     return 0;
@@ -460,7 +478,7 @@ extern "C" int cu_contour_measures(int M, int K, int H, int W, const float* cont
                                    float* length, void* stream) {
     CU_CHECK_ARG(M > 0 && K >= 2 && K <= MAXK && H > 0 && H <= MT && W > 0 && W <= MT, "cu_contour_measures: bad sizes M=%d K=%d H=%d W=%d", M, K, H, W);
     CU_CHECK_ARG(contours && (area || length), "cu_contour_measures: null pointer");
-    hipLaunchKernelGGL(contour_mask_kernel, dim3(M), dim3(MT), 0, reinterpret_cast<hipStream_t>(stream), K, H, W, contours,
+    hipLaunchKernelGGL(contour_mask_kernel, dim3((M + 3) / 4), dim3(MT), 0, reinterpret_cast<hipStream_t>(stream), M, K, H, W, contours,
                        round_landmarks, 0, (unsigned*)nullptr, (unsigned char*)nullptr, 0, area, length);
     CU_LAUNCH_CHECK();
     return 0;

@@ -177,6 +177,8 @@ class UNetEngine:
         self._prep_state = None     # (pointer key, item tables, early names, names, copies) of the batched operand preparation
         self._prep_pending = None   # (event, stream that must wait for it, names it does not cover): see _prep_all
         self.prep_overlap = os.environ.get("CONTOUR_PREP_OVERLAP", "1") != "0"
+        self.c1_bwd_main = os.environ.get("CONTOUR_C1_BWD_MAIN", "1") != "0"
+        self.join_probe: Optional[list] = None      # tools: a list collects (main, side, reduction) events at the end of each backward
         self._dwk_ws = None                         # partial-tile scratch of the weight gradients (two buffers)
         self._red: Optional[torch.cuda.Stream] = None      # stream of the partial tiles' sums / un-preparations
         self._red_done = [None, None]
@@ -521,6 +523,14 @@ class UNetEngine:
         while self._lagq:
             self._run_lagged()
         ops.pending_wait()                  # (a side task nobody consumed inside this backward: its results are gradients)
+        if self.join_probe is not None:     # tools/join_slack.py: when does each stream finish its share of the pass?
+            evs = []
+            for st in (torch.cuda.current_stream(device), self._side, self._red):
+                ev = torch.cuda.Event(enable_timing=True) if st is not None else None
+                if ev is not None:
+                    ev.record(st)
+                evs.append(ev)
+            self.join_probe.append(evs)
         if self._side is not None and self._side_keep:
             torch.cuda.current_stream(device).wait_stream(self._side)
             if self._red is not None:
@@ -599,7 +609,10 @@ class UNetEngine:
         if rec.no_z:
             # the first layer's whole backward from dL/da: z recomputed from the image, dz never stored (cu_conv_c1_bwd)
             n, oh, ow, co = g.shape
-            with self._wgrad_stream(g, ctx.img):
+            # on the MAIN stream (round 4): this is the last work of the pass and the input-gradient chain has just ended, while the
+            # weight-gradient stream still holds the 256^2 weight gradient of the layer above -- behind it the two launches
+            # (94 + 134 us) were an exposed tail; beside it they are free (profiles/r04_c1_bwd_main.txt)
+            with (contextlib.nullcontext() if self.c1_bwd_main else self._wgrad_stream(g, ctx.img)):
                 sums = self._arena["bwd"].take(2 * n * co, g.device).view(n, co, 2)     # (zeroed with the pass's arena)
                 dw9 = self._dwk((9, co), g.device)
                 ops.conv_c1_bwd(ctx.img, self._opcache[prefix][1], P[f"{prefix}.conv.bias"], rec.out.stats,

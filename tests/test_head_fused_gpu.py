@@ -367,14 +367,25 @@ def test_skew_head_side_stream_with_gradient_accumulation():
         torch.cuda.synchronize()
         return total if not accumulate else {n: p.grad.detach().clone() for n, p in task.named_parameters() if n in names}
 
+    # Run to run this 6-stage step falls into a few clusters 13-38 % apart (one flipped LeakyReLU decision at the 2x2 level:
+    # profiles/r04_fused_step_clusters.txt) and ~1 % wide.  An accumulation error would be off by the size of a micro-batch's
+    # gradient in EVERY pairing; so: three reference realisations, up to four of the candidate, and some pair must agree to 3 %.
+    def worst(a, b):
+        return max(float((a[n] - b[n]).norm() / b[n].norm()) for n in names)
+
+    def agrees(make, refs, tol=3e-2, tries=4):
+        best = 1e9
+        for _ in range(tries):
+            cand = make()
+            best = min([best] + [worst(cand, r) for r in refs])
+            if best <= tol:
+                return True, best
+        return False, best
+
     for extra in (False, True):
-        ref = grads(False, False, extra)             # sum of single-batch gradients, everything on one stream
-        floor = max(float((grads(False, False, extra)[n] - ref[n]).norm() / ref[n].norm()) for n in names)
+        refs = [grads(False, False, extra) for _ in range(3)]      # sums of single-batch gradients, everything on one stream
         for side in (True, False):
-            acc = grads(side, True, extra)
-            for n in names:
-                err = float((acc[n] - ref[n]).norm() / ref[n].norm())
-                assert err <= max(2e-3, 3 * floor), (extra, side, n, err, floor)
-        one = grads(True, False, extra)              # side mode really on (p.grad None before every backward)
-        for n in names:
-            assert float((one[n] - ref[n]).norm() / ref[n].norm()) <= max(2e-3, 3 * floor), (extra, n)
+            ok, best = agrees(lambda: grads(side, True, extra), refs)
+            assert ok, (extra, side, best)
+        ok, best = agrees(lambda: grads(True, False, extra), refs)   # side mode really on (p.grad None before every backward)
+        assert ok, (extra, best)

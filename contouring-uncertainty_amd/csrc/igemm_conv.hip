@@ -1564,7 +1564,9 @@ extern "C" int cu_conv_gemm_ex(const cu_conv_desc* d, const void* src0, const fl
     else nb = 1;
     if (d->D0 != d->CO && d->D0 % (32 * nb) != 0) nb = (d->D0 % 64 == 0 && d->CO % 64 == 0) ? 2 : 1;
     if (!bf && nb > 2) nb = (d->CO % 64 == 0) ? 2 : 1;   // keep the f32 weight tile within LDS
-    { const int cap = cu_env_int("CU_CONV_NBMAX", 4);
+    // (round 4: 64-column tiles at most.  The 128-column ring tile wins as a lone launch (profiles/r03b_layers_conv_one_stream_ring2.txt);
+    //  inside the step the narrower one does, by a little: 12.133 -> 12.106 ms, five of five alternating pairs, profiles/r04_knob_sweep2.txt)
+    { const int cap = cu_env_int("CU_CONV_NBMAX", 2);
       while (nb > cap) nb = (nb == 4) ? 2 : (nb == 3 ? 1 : 1); }
     // small feature maps: few pixel tiles, and every workgroup walks all channel chunks one L2 round trip at a time --
     // narrower column tiles put more CUs on the same work (4x4 x 480 channels: 20 workgroups with 96 columns each)

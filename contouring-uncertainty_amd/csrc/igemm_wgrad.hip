@@ -983,7 +983,7 @@ static int wgrad_impl(const cu_wgrad_desc* d, const void* src0, const float* sca
             }
             a.src0_bytes = (unsigned)b0; a.src1_bytes = (unsigned)b1; a.z_bytes = (unsigned)bz;
             const int n = a.s_iters + a.z_iters;
-            static const int dpe = cu_env_int("CU_WGRAD_DPCE", 4), dpf = cu_env_int("CU_WGRAD_DPCF", 100);   // as the stride-1 form
+            static const int dpe = cu_env_int("CU_WGRAD_DPCE", 6), dpf = cu_env_int("CU_WGRAD_DPCF", 100);   // (6 early rounds: 12.133 -> 12.106 ms per step, profiles/r04_knob_sweep2.txt; the stride-1 form keeps 4)
             a.pc_early = dpe < n ? dpe : n;
             a.pc_items = a.pc_early + ((n - a.pc_early) * dpf + 99) / 100;
             if (a.pc_items > n) a.pc_items = n;

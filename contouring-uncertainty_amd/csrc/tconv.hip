@@ -431,9 +431,14 @@ int cu_tconv_try(const cu_conv_desc* d, const void* src0, const void* src1, cons
     // Measured at 256^2 x 32, batch 64 (tools/thin_bench.py, profiles/r02_thin_bench.txt): two ring slots and two workgroups
     // per CU beat three slots and one workgroup (32 -> 32: 129 vs 143 us forward, 130 vs 162 us input gradient); for the
     // two-destination input gradient the 4-row tile that would fit two workgroups loses to 8 rows x 3 slots (248 vs 237)
-    const int var = cu_env_int("CU_TCONV_VAR", 1);      // tuning knob: 0 = three slots, one workgroup per CU
+    // Round 4: INSIDE the training step the choice reverses -- three slots / one workgroup per CU: 12.26 against 12.43 ms per step
+    // over five alternating pairs (profiles/r04_knob_sweep.txt, r04_tconv_var_in_step.txt): two workgroups per CU take the LDS that
+    // the launches of the other streams beside them (weight gradients, operand copies) need.  The lone-launch winner stays behind
+    // the knob.
+    const int var = cu_env_int("CU_TCONV_VAR", 0);      // tuning knob: 1 = two slots, two workgroups per CU
     // (the norm-backward epilogue needs 146 registers: one workgroup per CU either way, so it takes the three-slot ring)
-    if (CI == 32 && d->CO == 32) return (var == 1 && !a.nz) ? launch_tc<1, 1, 8, 2, true>(a, st) : launch_tc<1, 1, 8, 3>(a, st);
+    // (the normalise-on-load form, XF, exists in the two-slot instance only)
+    if (CI == 32 && d->CO == 32) return ((var == 1 || a.xscale) && !a.nz) ? launch_tc<1, 1, 8, 2, true>(a, st) : launch_tc<1, 1, 8, 3>(a, st);
     if (CI == 32 && d->CO == 64) return launch_tc<1, 2, 8, 3>(a, st);
     if (CI == 64 && d->CO == 32) return launch_tc<2, 1, 8, 2>(a, st);
     return launch_tc<2, 2, 4, 2, true>(a, st);

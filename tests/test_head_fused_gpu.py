@@ -244,7 +244,7 @@ def test_training_step_fused_head_equals_unfused(skew, stages):
     statistics), and at 6 stages / random initialisation one flipped LeakyReLU decision at the 2x2 level moves EVERY gradient
     by 13-38 % -- the runs fall into a few clusters, whatever the switch (tools output in profiles/r04_fused_step_clusters.txt:
     a fused and an unfused run 1.7 % apart, two fused runs 18 % apart).  A wiring error of the fused path would separate the
-    two modes in every pair; so: up to five runs per mode, and SOME fused run must agree with SOME unfused run to 3 %.
+    two modes in every pair; so: up to eight runs per mode, and SOME fused run must agree with SOME unfused run to 3 %.
     The tight comparisons are the kernel-level tests above."""
     from contour_uncertainty.data.synthetic import synthetic_batch
     torch.manual_seed(0)
@@ -262,7 +262,7 @@ def test_training_step_fused_head_equals_unfused(skew, stages):
             assert float(g1[n].norm()) < 1e-10, n
     fused, unfused = [g1], [g0]
     best = _worst(g1, g0)
-    while best > 3e-2 and len(fused) < 5:
+    while best > 3e-2 and len(fused) < 8:
         fused.append(_grads(task, batch, True)[1])
         unfused.append(_grads(task, batch, False)[1])
         best = min(_worst(a, b) for a in fused for b in unfused)
@@ -367,25 +367,22 @@ def test_skew_head_side_stream_with_gradient_accumulation():
         torch.cuda.synchronize()
         return total if not accumulate else {n: p.grad.detach().clone() for n, p in task.named_parameters() if n in names}
 
-    # Run to run this 6-stage step falls into a few clusters 13-38 % apart (one flipped LeakyReLU decision at the 2x2 level:
-    # profiles/r04_fused_step_clusters.txt) and ~1 % wide.  An accumulation error would be off by the size of a micro-batch's
-    # gradient in EVERY pairing; so: three reference realisations, up to four of the candidate, and some pair must agree to 3 %.
-    def worst(a, b):
-        return max(float((a[n] - b[n]).norm() / b[n].norm()) for n in names)
+    # Run to run this 6-stage step falls into MANY clusters 10-30 % apart (LeakyReLU decisions at the 2x2 level, set off by the f32
+    # atomics of the statistics; two micro-batches multiply the states: tools/fused_step_clusters.py, profiles/r04_fused_step_
+    # clusters.txt) -- a comparison of two default-mode realisations says nothing.  The deterministic mode has no such noise
+    # (bit-identical runs, tests/test_deterministic_gpu.py) and leaves the stream logic under test untouched: the skew head's
+    # backward still goes to its side stream when the parameters have no gradient yet, and must not when they have.
+    for e in (task.model.engine, task.skew_block.engine):
+        e.deterministic = True
 
-    def agrees(make, refs, tol=3e-2, tries=4):
-        best = 1e9
-        for _ in range(tries):
-            cand = make()
-            best = min([best] + [worst(cand, r) for r in refs])
-            if best <= tol:
-                return True, best
-        return False, best
+    def worst(a, b):
+        return max((float((a[n] - b[n]).norm() / b[n].norm()), n) for n in names)
 
     for extra in (False, True):
-        refs = [grads(False, False, extra) for _ in range(3)]      # sums of single-batch gradients, everything on one stream
+        ref = grads(False, False, extra)             # sum of single-batch gradients, everything on one stream
+        assert worst(grads(False, False, extra), ref)[0] == 0.0          # (the mode is reproducible)
         for side in (True, False):
-            ok, best = agrees(lambda: grads(side, True, extra), refs)
-            assert ok, (extra, side, best)
-        ok, best = agrees(lambda: grads(True, False, extra), refs)   # side mode really on (p.grad None before every backward)
-        assert ok, (extra, best)
+            err = worst(grads(side, True, extra), ref)
+            assert err[0] <= 1e-4, (extra, side, err)
+        err = worst(grads(True, False, extra), ref)  # side mode really on (p.grad None before every backward)
+        assert err[0] <= 1e-4, (extra, err)

@@ -1140,7 +1140,7 @@ static int pick_chunk(int N, int HW, int rows, int* nchunks, bool det = false) {
         return cdiv(HW, rows) * rows;
     }
     // aim for ~2048 workgroups in total; every chunk a multiple of the rows handled per iteration
-    int want = cdiv(2048, N);
+    int want = cdiv(cu_env_int("CU_NORM_WGS", 2048), N);      // (tuning knob; 1024 / 4096 inside the step: profiles/r04_norm_wgs.txt)
     if (want < 1) want = 1;
     int chunk = cdiv(HW, want);
     // at least 16 pixels per thread: every workgroup ends in one atomic per channel and partial sum, and on the small

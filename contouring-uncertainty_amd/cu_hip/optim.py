@@ -43,6 +43,10 @@ class FusedAdam(torch.optim.Optimizer):
         # views in self.state are)
         self._flat: Dict[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.grad_scale = 1.0          # multiplies every gradient inside the kernel (1 / world after a SUM all-reduce)
+        # per parameter group: the launches of the last step (runs, flat moments, step count).  The next step replays them after
+        # checking that nothing moved -- same parameter list, same addresses, gradients laid out as before -- instead of
+        # re-deriving runs, step splits and moment views from 138 parameters (1.3 ms of host time per step; round 4)
+        self._plans: Dict[int, dict] = {}
 
     @staticmethod
     def _runs(params: List[torch.Tensor]):
@@ -86,18 +90,20 @@ class FusedAdam(torch.optim.Optimizer):
         return out
 
     def _moments(self, run: List[torch.Tensor]):
-        """(flat exp_avg, flat exp_avg_sq) of a run with every parameter's state entry a view into them."""
+        """(flat exp_avg, flat exp_avg_sq, step counts) of a run with every parameter's state entries views into them (the
+        ``step`` entries are 0-dim views of ONE host tensor per run: one increment per launch instead of one per parameter)."""
         first = run[0]
         n = sum(p.numel() for p in run)
         flat = self._flat.get(first)
-        ok = flat is not None and flat[0].numel() == n and flat[0].device == first.device
+        ok = flat is not None and flat[0].numel() == n and flat[0].device == first.device and flat[2].numel() == len(run)
         if ok:
             off = 0
-            base_m, base_v = flat[0].data_ptr(), flat[1].data_ptr()
-            for p in run:
+            base_m, base_v, base_s = flat[0].data_ptr(), flat[1].data_ptr(), flat[2].data_ptr()
+            for i, p in enumerate(run):
                 st = self.state.get(p)
                 if (st is None or "exp_avg" not in st or st["exp_avg"].data_ptr() != base_m + 4 * off
-                        or st["exp_avg_sq"].data_ptr() != base_v + 4 * off):
+                        or st["exp_avg_sq"].data_ptr() != base_v + 4 * off
+                        or not torch.is_tensor(st.get("step")) or st["step"].data_ptr() != base_s + 4 * i):
                     ok = False
                     break
                 off += p.numel()
@@ -106,19 +112,54 @@ class FusedAdam(torch.optim.Optimizer):
         # (re)build: keep whatever per-parameter state exists (fresh start: zeros)
         m = torch.zeros(n, dtype=torch.float32, device=first.device)
         v = torch.zeros(n, dtype=torch.float32, device=first.device)
+        steps = torch.zeros(len(run), dtype=torch.float32)
         off = 0
-        for p in run:
+        for i, p in enumerate(run):
             st = self.state[p]
             k = p.numel()
             if "exp_avg" in st:
                 m[off:off + k].copy_(st["exp_avg"].detach().reshape(-1).to(m))
                 v[off:off + k].copy_(st["exp_avg_sq"].detach().reshape(-1).to(v))
-            st["step"] = torch.tensor(float(_step_of(st)))
+            steps[i] = float(_step_of(st))
+            st["step"] = steps[i]
             st["exp_avg"] = m[off:off + k].view(p.shape)
             st["exp_avg_sq"] = v[off:off + k].view(p.shape)
             off += k
-        self._flat[first] = (m, v)
-        return m, v
+        self._flat[first] = (m, v, steps)
+        return m, v, steps
+
+    def _replay(self, plan, group, b1, b2, grad_scale) -> bool:
+        """Launch the planned runs if the plan still describes the group exactly; False = take the full path."""
+        if plan["params"] is not group["params"] or plan["n_params"] != len(group["params"]):
+            return False
+        for p in plan["idle"]:
+            if p.grad is not None:
+                return False
+        for first, n, m, v, step, offs, steps in plan["launches"]:
+            g0 = first.grad
+            if g0 is None:
+                return False
+            pbase, gbase = first.data_ptr(), g0.data_ptr()
+            gstore = g0.untyped_storage().data_ptr()
+            for p, off in offs:
+                g = p.grad
+                if (g is None or p.data_ptr() != pbase + 4 * off or g.data_ptr() != gbase + 4 * off
+                        or g.untyped_storage().data_ptr() != gstore or not g.is_contiguous()):
+                    return False
+        launches = []
+        for first, n, m, v, step, offs, steps in plan["launches"]:
+            step += 1
+            steps += 1
+            pflat = torch.as_strided(first.data, (n,), (1,))
+            gflat = torch.as_strided(first.grad, (n,), (1,))
+            if self.capturable:
+                ops.adam_step_dev(pflat, gflat, m, v, group["lr"], b1, b2, group["eps"], group["weight_decay"], self._steps_dev,
+                                  grad_scale)
+            else:
+                ops.adam_step(pflat, gflat, m, v, group["lr"], b1, b2, group["eps"], group["weight_decay"], step, grad_scale)
+            launches.append((first, n, m, v, step, offs, steps))
+        plan["launches"] = launches
+        return True
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = None):
@@ -129,16 +170,20 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
+            plan = self._plans.get(gi)
+            if plan is not None and self._replay(plan, group, b1, b2, grad_scale):
+                continue
+            self._plans.pop(gi, None)
+            built = []          # (first, n, m, v, step after this call, [(p, offset in floats)], step counts) per launch: next step's plan
             for mem_run in self._runs(group["params"]):
                 for run in self._split_by_step(mem_run):
                     first = run[0]
                     n = sum(p.numel() for p in run)
-                    m, v = self._moments(run)
+                    m, v, steps = self._moments(run)
                     step = _step_of(self.state[first]) + 1
-                    for p in run:
-                        self.state[p]["step"] += 1
+                    steps += 1
                     pflat = torch.as_strided(first.data, (n,), (1,))
                     gflat = torch.as_strided(first.grad, (n,), (1,))
                     if self.capturable:
@@ -149,6 +194,13 @@ class FusedAdam(torch.optim.Optimizer):
                     else:
                         ops.adam_step(pflat, gflat, m, v, group["lr"], b1, b2, group["eps"], group["weight_decay"], step,
                                       grad_scale)
+                    offs, off = [], 0
+                    for p in run:
+                        offs.append((p, off))
+                        off += p.numel()
+                    built.append((first, n, m, v, step, offs, steps))
+            self._plans[gi] = {"params": group["params"], "n_params": len(group["params"]), "launches": built,
+                               "idle": [p for p in group["params"] if p.grad is None]}
         if self.capturable and self._steps_dev is not None:
             ops.step_advance(self._steps_dev)
         return loss
@@ -160,6 +212,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         self._steps_dev = None
         self._flat.clear()
+        self._plans.clear()
 
     def hyper_key(self):
         """the scalars a captured step bakes into its launches (cu_hip.graph.CapturedStep re-captures when they change)"""
@@ -170,3 +223,4 @@ class FusedAdam(torch.optim.Optimizer):
         for st in self.state.values():
             if "step" in st:
                 st["step"] += k
+        self._plans.clear()

@@ -124,3 +124,60 @@ def test_state_layout_and_resume_cpu(monkeypatch):
 @pytest.mark.gpu
 def test_state_layout_and_resume_gpu():
     _run("cuda")
+
+
+def test_step_plan_is_replayed_and_invalidated_cpu(monkeypatch):
+    """Round 4: ``FusedAdam.step`` replays the launches of the previous step after checking that nothing moved (parameter list,
+    addresses, gradient layout, which parameters have gradients).  Same updates as torch.optim.Adam through every transition:
+    replay, gradients in separately allocated tensors (two launches instead of one), back to one flat buffer, a parameter whose
+    gradient disappears, a new hyper-parameter."""
+    from cu_hip import ops
+    from cu_hip.optim import FusedAdam
+    launches = []
+
+    def fake(p, g, m, v, lr, b1, b2, eps, wd, step, grad_scale=1.0):
+        launches.append((p.numel(), step))
+        _torch_adam_step(p, g, m, v, lr, b1, b2, eps, wd, step, grad_scale)
+    monkeypatch.setattr(ops, "adam_step", fake)
+    _, params = _flat_model("cpu")
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in params]
+    opt = FusedAdam(params, lr=1e-2, weight_decay=1e-3)
+    ropt = torch.optim.Adam(ref, lr=1e-2, weight_decay=1e-3)
+    full_paths = []
+    orig_runs = FusedAdam._runs
+    monkeypatch.setattr(FusedAdam, "_runs", staticmethod(lambda ps: (full_paths.append(1), orig_runs(ps))[1]))
+    n3 = sum(p.numel() for p in params[:3])
+
+    def both(it, mutate=None):
+        _set_grads(params, 30 + it, "cpu")
+        if mutate is not None:
+            mutate()
+        for p, r in zip(params, ref):
+            r.grad = None if p.grad is None else p.grad.detach().clone()
+        opt.step()
+        ropt.step()
+        for p, r in zip(params, ref):
+            assert torch.allclose(p, r, rtol=1e-5, atol=1e-6), it
+
+    both(0); both(1); both(2)
+    assert len(full_paths) == 1 and launches == [(n3, 1), (n3, 2), (n3, 3)]            # steps 2 and 3 were replays
+
+    def scatter():       # every gradient in a tensor of its own: the run structure changes
+        for p in params[:3]:
+            p.grad = p.grad.detach().clone()
+    both(3, scatter)
+    assert len(full_paths) == 2 and len(launches) > 4 and launches[-1][1] == 4
+    both(4)          # one flat gradient buffer again: the three-launch plan still describes it (each launch's layout holds)
+    assert len(full_paths) == 2 and [l[1] for l in launches[-3:]] == [5, 5, 5]
+    opt._plans.clear()                                                                 # (a fresh plan merges them again)
+    both(5)
+    assert len(full_paths) == 3 and launches[-1] == (n3, 6)
+
+    def drop():          # a parameter without a gradient this step (frozen layer): it must not move
+        params[2].grad = None
+    before = params[2].detach().clone()
+    both(6, drop)
+    assert len(full_paths) == 4 and torch.equal(params[2], before)
+    opt.param_groups[0]["lr"] = ropt.param_groups[0]["lr"] = 3e-3                      # hyper-parameters are read every step
+    both(7); both(8)
+    assert float(opt.state[params[0]]["step"]) == 9.0 and float(opt.state[params[2]]["step"]) == 8.0

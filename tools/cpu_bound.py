@@ -19,13 +19,17 @@ def step(i):
     opt.step()
 for i in range(3): step(i)
 torch.cuda.synchronize()
-K = 10
-t0 = time.perf_counter()
-for i in range(K): step(i)
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print(f"enqueue {1e3*(t1-t0)/K:.2f} ms/step, total {1e3*(t2-t0)/K:.2f} ms/step")
+K = 30
+best = None
+for rep in range(4):        # best of four: the host's share of a box varies
+    t0 = time.perf_counter()
+    for i in range(K): step(i)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    cur = (1e3*(t1-t0)/K, 1e3*(t2-t0)/K)
+    best = cur if best is None or cur[0] < best[0] else best
+print(f"enqueue {best[0]:.2f} ms/step, total {best[1]:.2f} ms/step (best of 4 x {K} steps)")
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for i in range(3): step(i)

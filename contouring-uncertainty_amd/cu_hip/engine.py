@@ -87,6 +87,24 @@ class UNetCtx:
     head: Optional[dict] = None          # fused head: {"act", "w_cls", "w_ch"} of the launch pair in head_fused.hip
 
 
+class _OnStream:
+    """``with`` block that makes ``stream`` current and puts ``prev`` back: torch.cuda.stream() without its device and
+    current-stream queries (6-8 us of the host's time per use, ~75 uses per backward pass: tools/bwd_host_profile.py).  The caller
+    knows the stream it is on."""
+    __slots__ = ("stream", "prev")
+
+    def __init__(self, stream, prev):
+        self.stream, self.prev = stream, prev
+
+    def __enter__(self):
+        torch.cuda.set_stream(self.stream)
+        return self.stream
+
+    def __exit__(self, *exc):
+        torch.cuda.set_stream(self.prev)
+        return False
+
+
 class _WsArena:
     """Bump allocator over one persistent float32 tensor, zeroed once per pass.  The first pass (size still unknown)
     hands out individually zeroed tensors and records the total; from the second pass on every take is a slice."""
@@ -178,6 +196,8 @@ class UNetEngine:
         self._prep_pending = None   # (event, stream that must wait for it, names it does not cover): see _prep_all
         self.prep_overlap = os.environ.get("CONTOUR_PREP_OVERLAP", "1") != "0"
         self.c1_bwd_main = os.environ.get("CONTOUR_C1_BWD_MAIN", "1") != "0"
+        self._main_stream = None     # the stream a backward pass runs on, looked up once per pass (None outside a pass)
+        self._on_side = False        # inside a weight-gradient task on the side stream
         self.join_probe: Optional[list] = None      # tools: a list collects (main, side, reduction) events at the end of each backward
         self._dwk_ws = None                         # partial-tile scratch of the weight gradients (two buffers)
         self._red: Optional[torch.cuda.Stream] = None      # stream of the partial tiles' sums / un-preparations
@@ -493,15 +513,21 @@ class UNetEngine:
         dev = reads[0].device
         if self._side is None or self._side.device != dev:
             self._side = torch.cuda.Stream(dev, priority=self._side_priority)     # (priorities: profiles/r04_stream_priority.txt)
-        self._side.wait_stream(torch.cuda.current_stream(dev))
+        main = self._main_stream if self._main_stream is not None else torch.cuda.current_stream(dev)
+        self._side.wait_stream(main)
         self._side_keep.extend(reads)
-        return torch.cuda.stream(self._side)
+        return _OnStream(self._side, main)
 
     def _wgrad_task(self, reads, fn):
         """run ``fn`` (a weight-gradient launch + its slab sums) on the weight-gradient stream: now, or ``wgrad_lag`` tasks later"""
         if not self.wgrad_lag or not self.side_wgrad or not reads[0].is_cuda or torch.cuda.is_current_stream_capturing():
-            with self._wgrad_stream(*reads):
-                fn()
+            ctx = self._wgrad_stream(*reads)
+            with ctx:
+                self._on_side = isinstance(ctx, _OnStream)
+                try:
+                    fn()
+                finally:
+                    self._on_side = False
             return
         ev = torch.cuda.Event()
         ev.record()
@@ -532,9 +558,10 @@ class UNetEngine:
                 evs.append(ev)
             self.join_probe.append(evs)
         if self._side is not None and self._side_keep:
-            torch.cuda.current_stream(device).wait_stream(self._side)
+            main = self._main_stream if self._main_stream is not None else torch.cuda.current_stream(device)
+            main.wait_stream(self._side)
             if self._red is not None:
-                torch.cuda.current_stream(device).wait_stream(self._red)
+                main.wait_stream(self._red)
         self._side_keep.clear()
 
     PARTS_FLOATS = 24 << 20       # 96 MiB: 256 slabs of a 64 x 64 x 9 block are 9.4 M floats; the library caps the splits
@@ -558,7 +585,7 @@ class UNetEngine:
         k = self._wg_count & 1
         self._wg_count += 1
         ws = self._parts_ws(z.device, k)
-        cur = torch.cuda.current_stream(z.device)
+        cur = self._side if self._on_side else torch.cuda.current_stream(z.device)
         # (inside a hipGraph capture the sums stay on the weight-gradient stream: ROCm 7.2's capture_end crashed on the
         # stream forked from a forked stream; CONTOUR_GRAPH_THIRD=1 re-enables it for experiments)
         third = self.side_wgrad and self._side is not None and cur == self._side and \
@@ -580,7 +607,7 @@ class UNetEngine:
             return
         ev = torch.cuda.Event()
         ev.record(cur)
-        with torch.cuda.stream(self._red):
+        with _OnStream(self._red, cur):
             self._red.wait_event(ev)
             ops.grad_unprep_parts(ws, slabs, shape[1], grad, kind, accumulate=True)
             self._ready(prefix)
@@ -785,8 +812,12 @@ class UNetEngine:
         dL/dlogits arrives as ``dlogits`` (N, K, H, W) float32 and / or as ``dl_nhwc`` (N, H, W, 32) in the engine's
         element type (``cu_dsnt_head_bwd_nhwc``); both given = their sum."""
         try:
+            self._main_stream = torch.cuda.current_stream(ctx.last.z.device) if ctx.last.z.is_cuda else None
             self._backward(P, G, ctx, dlogits, dfeats, dl_nhwc, head_grads)
+            self._main_stream = None
         except BaseException:
+            self._main_stream = None
+            self._on_side = False
             # an aborted step (launch error, OOM, KeyboardInterrupt, an exception from the DDP ready hook) must not leave
             # state behind that a later step would silently consume: join the weight-gradient stream, drop the epilogue
             # sums and the (possibly half-accumulated) first-layer accumulator

@@ -1336,7 +1336,7 @@ extern "C" int cu_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void
     if (det) mode = 2;
     const int np = rc_pick_np(HW, rm.rows);
     const int nch = cdiv(HW, rm.rows * np);
-    if (mode == 0) mode = (HW <= 256 && nch <= RC_MAX_CHUNKS && out) ? 1 : 2;      // measured crossover (see the kernels' header)
+    if (mode == 0) mode = (HW <= 256 && nch <= RC_MAX_CHUNKS && out && !cu_env_set("CU_NORM_NO_FWD_RESIDENT")) ? 1 : 2;      // measured crossover (see the kernels' header)
     if (mode == 1) {
         CU_CHECK_ARG(out != nullptr, "cu_instnorm_fwd_fused: the resident kernel always writes the activated tensor");
         CU_CHECK_ARG(nch <= RC_MAX_CHUNKS, "cu_instnorm_fwd_fused: %d chunks per image exceed %d", nch, RC_MAX_CHUNKS);
@@ -1425,7 +1425,7 @@ extern "C" int cu_instnorm_bwd_fused(int dtype, int N, int HW, int C, void* g, c
     if (det) mode = 2;
     const int np = rc_pick_np(HW, rm.rows);
     const int nch = cdiv(HW, rm.rows * np);
-    if (mode == 0) mode = (HW > 1024 && HW <= 4096 && nch <= RC_MAX_CHUNKS) ? 1 : 2;
+    if (mode == 0) mode = (HW > 1024 && HW <= 4096 && nch <= RC_MAX_CHUNKS && !cu_env_set("CU_NORM_NO_BWD_RESIDENT")) ? 1 : 2;
     if (mode == 1) {
         CU_CHECK_ARG(nch <= RC_MAX_CHUNKS, "cu_instnorm_bwd_fused: %d chunks per image exceed %d", nch, RC_MAX_CHUNKS);
         if (!clean) {

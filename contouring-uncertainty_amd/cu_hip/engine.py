@@ -196,6 +196,7 @@ class UNetEngine:
         self._prep_pending = None   # (event, stream that must wait for it, names it does not cover): see _prep_all
         self.prep_overlap = os.environ.get("CONTOUR_PREP_OVERLAP", "1") != "0"
         self.c1_bwd_main = os.environ.get("CONTOUR_C1_BWD_MAIN", "1") != "0"
+        self.red_stream = os.environ.get("CONTOUR_RED_STREAM", "1") != "0"       # slab sums on a third stream (else: weight-gradient stream)
         self._main_stream = None     # the stream a backward pass runs on, looked up once per pass (None outside a pass)
         self._on_side = False        # inside a weight-gradient task on the side stream
         self.join_probe: Optional[list] = None      # tools: a list collects (main, side, reduction) events at the end of each backward
@@ -588,7 +589,7 @@ class UNetEngine:
         cur = self._side if self._on_side else torch.cuda.current_stream(z.device)
         # (inside a hipGraph capture the sums stay on the weight-gradient stream: ROCm 7.2's capture_end crashed on the
         # stream forked from a forked stream; CONTOUR_GRAPH_THIRD=1 re-enables it for experiments)
-        third = self.side_wgrad and self._side is not None and cur == self._side and \
+        third = self.side_wgrad and self.red_stream and self._side is not None and cur == self._side and \
             (not torch.cuda.is_current_stream_capturing() or os.environ.get("CONTOUR_GRAPH_THIRD") == "1")
         if third:
             if self._red is None or self._red.device != z.device:

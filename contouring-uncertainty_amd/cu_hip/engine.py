@@ -208,6 +208,7 @@ class UNetEngine:
         # chain beside it finds free CUs (a weight-gradient workgroup owns its CU's whole LDS).  Measured, alternating runs
         # on one box: 14.10 / 14.17 ms at 192 against 14.40 / 14.34 ms at 256 (0 = the library's choice, 256)
         self._wgrad_wgs = int(os.environ.get("CONTOUR_WGRAD_WGS", "192"))
+        self._wgrad_wgs_thin = int(os.environ.get("CONTOUR_WGRAD_WGS_THIN", str(self._wgrad_wgs)))
         self._dw9_ws: Optional[Tensor] = None       # first layer's 9 x CO accumulator (zero between uses)
         # InstanceNorm workspaces (atomics targets) of all layers of one pass: slices of ONE arena per direction that
         # is zeroed by one fill at the start of the pass (instead of one memset launch per layer)
@@ -600,7 +601,8 @@ class UNetEngine:
             # experiment knob (CONTOUR_WGRAD_WGS=n): cap the weight-gradient launch at ~n workgroups so that it leaves CUs to
             # the input-gradient chain running beside it (its workgroups own a CU's whole LDS)
             co, ci = shape[1], shape[2]
-            kw["splits"] = max(1, self._wgrad_wgs // (-(-co // 64) * -(-ci // 64)))
+            wgs = self._wgrad_wgs_thin if max(co, ci) <= 64 else self._wgrad_wgs      # (thin = the HBM-bound 256^2 / 128^2 levels)
+            kw["splits"] = max(1, wgs // (-(-co // 64) * -(-ci // 64)))
         slabs = ops.conv_wgrad(srcs, z, ws, parts=True, **kw)
         if not third:
             ops.grad_unprep_parts(ws, slabs, shape[1], grad, kind, accumulate=True)

@@ -438,7 +438,9 @@ int cu_tconv_try(const cu_conv_desc* d, const void* src0, const void* src1, cons
     const int var = cu_env_int("CU_TCONV_VAR", 0);      // tuning knob: 1 = two slots, two workgroups per CU
     // (the norm-backward epilogue needs 146 registers: one workgroup per CU either way, so it takes the three-slot ring)
     // (the normalise-on-load form, XF, exists in the two-slot instance only)
-    if (CI == 32 && d->CO == 32) return ((var == 1 || a.xscale) && !a.nz) ? launch_tc<1, 1, 8, 2, true>(a, st) : launch_tc<1, 1, 8, 3>(a, st);
+    // (tuning: 2 = the two-slot form for launches with a statistics epilogue (forward) only, 3 = for the others only)
+    const bool two_slot = var == 1 || (var == 2 && a.stat_sums) || (var == 3 && !a.stat_sums);
+    if (CI == 32 && d->CO == 32) return ((two_slot || a.xscale) && !a.nz) ? launch_tc<1, 1, 8, 2, true>(a, st) : launch_tc<1, 1, 8, 3>(a, st);
     if (CI == 32 && d->CO == 64) return launch_tc<1, 2, 8, 3>(a, st);
     if (CI == 64 && d->CO == 32) return launch_tc<2, 1, 8, 2>(a, st);
     return launch_tc<2, 2, 4, 2, true>(a, st);

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
     constexpr bool XF1 = XF && MODE == 1;
     constexpr int XT = (XF && !XF1) ? 1 : 0;    // table DMA instructions per wave and tile
     constexpr int TAB0 = W_B + R * SLOT_B + 1024;        // XF: R tables of 1 KiB, then the dump kilobyte
-    static_assert(NBW >= 1 && W_B + R * SLOT_B + 1024 + (XF ? (R + 1) * 1024 : 0) <= 160 * 1024, "tconv: bad instance");
+    static_assert(NBW >= 1 && R >= 2 && R <= 4 && W_B + R * SLOT_B + 1024 + (XF ? (R + 1) * 1024 : 0) <= 160 * 1024, "tconv: bad instance");
     static_assert(!XF || (MODE != 2 && CI <= 128), "tconv: XF serves the forward instances");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -215,19 +215,17 @@ __global__ __launch_bounds__(512) void tconv_kernel(const TcArgs p) {
         }
     };
     int l = l_begin;
-    issue(l, 0);
-    if (R == 3) issue(l + l_step, 1);
+#pragma unroll
+    for (int k = 0; k < R - 1; ++k) issue(l + k * l_step, k);
     for (int it = 0; l < l_end; ++it, l += l_step) {
-        // DMA(it) must have landed; younger operations, in issue order: [R == 3: stores(it-2), DMA(it+1)], stores(it-1)
-        // (MODE 2 adds ZL hand-issued loads per iteration, issued BEFORE that iteration's DMA)
-        if (R == 3) {
-            if (it == 0) wait_vm<D + XT>();
-            else if (it == 1) wait_vm<ZL + D + XT + S>();
-            else wait_vm<ZL + D + XT + 2 * S>();
-        } else {
-            if (it == 0) wait_vm<0>();
-            else wait_vm<S>();
-        }
+        // DMA(it) must have landed.  An iteration issues, in this order: its ZL hand-issued loads (MODE 2), the DMA of tile
+        // it + R - 1 (DI instructions), its S stores.  Younger than DMA(it): the R - 2 - it prologue DMAs behind it and the `it`
+        // whole iterations so far (it <= R - 2); in the steady state the stores of iteration it - R + 1 and R - 2 whole iterations
+        constexpr int DI = D + XT, ITER = ZL + DI + S;
+        if (it >= R - 1) wait_vm<S + (R - 2) * ITER>();
+        else if (it == 0) wait_vm<(R - 2) * DI>();
+        else if (it == 1) wait_vm<(R >= 3 ? (R - 3) * DI + ITER : 0)>();
+        else wait_vm<(R >= 4 ? (R - 4) * DI + 2 * ITER : 0)>();          // it == 2 (R = 4)
         const int tile = tile_of(l);
         const int tx = tile % p.tiles_x, rest = tile / p.tiles_x;
         const int ty = rest % p.tiles_y, n = rest / p.tiles_y;
@@ -440,6 +438,7 @@ int cu_tconv_try(const cu_conv_desc* d, const void* src0, const void* src1, cons
     // (the normalise-on-load form, XF, exists in the two-slot instance only)
     // (tuning: 2 = the two-slot form for launches with a statistics epilogue (forward) only, 3 = for the others only)
     const bool two_slot = var == 1 || (var == 2 && a.stat_sums) || (var == 3 && !a.stat_sums);
+    if (CI == 32 && d->CO == 32 && var == 4) return launch_tc<1, 1, 8, 4>(a, st);      // (tuning: four slots)
     if (CI == 32 && d->CO == 32) return ((two_slot || a.xscale) && !a.nz) ? launch_tc<1, 1, 8, 2, true>(a, st) : launch_tc<1, 1, 8, 3>(a, st);
     if (CI == 32 && d->CO == 64) return launch_tc<1, 2, 8, 3>(a, st);
     if (CI == 64 && d->CO == 32) return launch_tc<2, 1, 8, 2>(a, st);

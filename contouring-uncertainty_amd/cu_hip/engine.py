@@ -196,6 +196,7 @@ class UNetEngine:
         self._prep_pending = None   # (event, stream that must wait for it, names it does not cover): see _prep_all
         self.prep_overlap = os.environ.get("CONTOUR_PREP_OVERLAP", "1") != "0"
         self.c1_bwd_main = os.environ.get("CONTOUR_C1_BWD_MAIN", "1") != "0"
+        self.wgrad_after_dgrad = os.environ.get("CONTOUR_WGRAD_AFTER_DGRAD", "0") == "1"
         self.red_stream = os.environ.get("CONTOUR_RED_STREAM", "1") != "0"       # slab sums on a third stream (else: weight-gradient stream)
         self._main_stream = None     # the stream a backward pass runs on, looked up once per pass (None outside a pass)
         self._on_side = False        # inside a weight-gradient task on the side stream
@@ -522,7 +523,8 @@ class UNetEngine:
 
     def _wgrad_task(self, reads, fn):
         """run ``fn`` (a weight-gradient launch + its slab sums) on the weight-gradient stream: now, or ``wgrad_lag`` tasks later"""
-        if not self.wgrad_lag or not self.side_wgrad or not reads[0].is_cuda or torch.cuda.is_current_stream_capturing():
+        if (not (self.wgrad_lag or self.wgrad_after_dgrad) or not self.side_wgrad or not reads[0].is_cuda
+                or torch.cuda.is_current_stream_capturing()):
             ctx = self._wgrad_stream(*reads)
             with ctx:
                 self._on_side = isinstance(ctx, _OnStream)
@@ -534,8 +536,17 @@ class UNetEngine:
         ev = torch.cuda.Event()
         ev.record()
         self._lagq.append((ev, reads, fn))
+        if self.wgrad_after_dgrad:          # (issued by _flush_after_dgrad, right behind the layer's input-gradient launch)
+            return
         while len(self._lagq) > self.wgrad_lag:
             self._run_lagged()
+
+    def _flush_after_dgrad(self):
+        """experiment (CONTOUR_WGRAD_AFTER_DGRAD=1): the layer's weight-gradient launches reach their stream AFTER its input-gradient
+        launch reached the main one -- same dependencies (the event was recorded before), other issue order"""
+        if self.wgrad_after_dgrad:
+            while self._lagq:
+                self._run_lagged()
 
     def _run_lagged(self):
         ev, reads, fn = self._lagq.pop(0)
@@ -628,7 +639,11 @@ class UNetEngine:
             torch.cuda.current_stream(dwk.device).wait_stream(self._red)
         self._ready(prefix)
 
-    def _conv_layer_bwd(self, P, G, ctx: UNetCtx, prefix: str, g: Tensor,
+    def _conv_layer_bwd(self, *a, **k):
+        self._conv_layer_bwd_impl(*a, **k)
+        self._flush_after_dgrad()
+
+    def _conv_layer_bwd_impl(self, P, G, ctx: UNetCtx, prefix: str, g: Tensor,
                         dsrc: Optional[List[Tuple[Tensor, int]]]):
         """g: dL/d(activated output), overwritten with dL/dz.  dsrc: [(tensor, accumulate)] per source or None."""
         rec = ctx.convs[prefix]
@@ -792,7 +807,11 @@ class UNetEngine:
         if full[2] is not None:
             self._pg_items.append(full[2])
 
-    def _convT_bwd(self, P, G, ctx: UNetCtx, rec: _UpRec, du: Tensor, d_in: Tensor, accum: int):
+    def _convT_bwd(self, *a, **k):
+        self._convT_bwd_impl(*a, **k)
+        self._flush_after_dgrad()
+
+    def _convT_bwd_impl(self, P, G, ctx: UNetCtx, rec: _UpRec, du: Tensor, d_in: Tensor, accum: int):
         w = P[f"{rec.prefix}.weight"]
         ci, co = w.shape[0], w.shape[1]
         n, h, w_, _ = rec.src.z.shape

@@ -130,7 +130,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     def _replay(self, plan, group, b1, b2, grad_scale) -> bool:
         """Launch the planned runs if the plan still describes the group exactly; False = take the full path."""
-        if plan["params"] is not group["params"] or plan["n_params"] != len(group["params"]):
+        if plan["params"] is not group["params"] or plan["ids"] != list(map(id, group["params"])):
             return False
         for p in plan["idle"]:
             if p.grad is not None:
@@ -199,7 +199,7 @@ class FusedAdam(torch.optim.Optimizer):
                         offs.append((p, off))
                         off += p.numel()
                     built.append((first, n, m, v, step, offs, steps))
-            self._plans[gi] = {"params": group["params"], "n_params": len(group["params"]), "launches": built,
+            self._plans[gi] = {"params": group["params"], "ids": list(map(id, group["params"])), "launches": built,
                                "idle": [p for p in group["params"] if p.grad is None]}
         if self.capturable and self._steps_dev is not None:
             ops.step_advance(self._steps_dev)
